@@ -1,0 +1,286 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules on CPU (build container only).
+
+TEST INFRASTRUCTURE.  The reference (/root/reference) has no tests or golden vectors
+(SURVEY.md section 4), so the oracle is pinned against the reference modules themselves: this script
+imports them (with `sys.modules` stubs for the missing third-party imports they never use on
+this path: torchvision, skimage) and stores inputs + expected outputs as small fixtures.  Only
+data is written; no reference source is copied.  The reference trainer classes cannot be
+constructed without CUDA (kwatsch/trainer_ae.py:51), so the train step is driven by the
+arithmetic of AETrainerEndToEnd.train restated here around the *reference* network modules.
+
+Run:  python oracle/make_golden.py          (needs /root/reference; not available on the GPU box)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("AESR_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+from oracle import lpips_oracle, step_oracle  # noqa: E402  (input generators + synthetic backbone spec)
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _fake_vgg16(pretrained=False, **kw):
+    """Stand-in for torchvision.models.vgg16: the public VGG16-D `features` layout filled with the
+    deterministic synthetic weights (the ImageNet weights are a network download, unavailable)."""
+    layers, cin = [], 3
+    for v in lpips_oracle.VGG16_CFG:
+        if v == "M":
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    feats = nn.Sequential(*layers)
+    feats.load_state_dict({k.replace("features.", ""): v for k, v in lpips_oracle.hash_vgg16_state().items()})
+    return types.SimpleNamespace(features=feats)
+
+
+def import_reference():
+    tv = _stub("torchvision")
+    tv.transforms = _stub("torchvision.transforms")
+    tv.utils = _stub("torchvision.utils", make_grid=None)
+    tv.models = _stub("torchvision.models", vgg16=_fake_vgg16)
+    _stub("skimage")
+    _stub("skimage.metrics", structural_similarity=None, peak_signal_noise_ratio=None)
+    _stub("skimage.measure")
+    sys.path.insert(0, REF)
+    import networks.acai_vanilla as av
+    import networks.acai_vanilla_strided as avs
+    import networks.acai_vanilla_modified as avm
+    import lpips.networks_basic as nb
+    return av, avs, avm, nb
+
+
+def np_state(sd):
+    return {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+def small_args(depth=8, latent=16, width=32, latent_width=8):
+    return dict(width=width, latent_width=latent_width, depth=depth, latent=latent, colors=1, device="cpu",
+                use_batchnorm=True, use_sigmoid=True, n_res_block=None)
+
+
+def gen_ae_small(av, avs, avm):
+    """fwd + bwd of one train-mode pass for each AE variant at odd/even sizes."""
+    classes = {"VanillaACAI": av.VanillaACAI, "VanillaACAIStrided": avs.VanillaACAIStrided, "LargerAE": avm.LargerAE}
+    for cname, cls in classes.items():
+        for (N, H, W) in ((2, 28, 28), (4, 33, 33), (2, 40, 36)):
+            torch.manual_seed(1000 + H)
+            model = cls(small_args())
+            model.train()
+            sd0 = np_state(model.state_dict())
+            x = torch.rand(N, 1, H, W)
+            x.requires_grad_(True)
+            z = model.encode(x)
+            out = model.decode(z)
+            # the decoder's output size differs from the input for odd sizes -> loss against a fixed target
+            tgt = torch.rand(out.shape, generator=torch.Generator().manual_seed(7))
+            loss = F.mse_loss(out, tgt) + 0.1 * (z ** 2).mean()
+            loss.backward()
+            rec = {"x": x.detach().numpy(), "tgt": tgt.numpy(), "z": z.detach().numpy(), "out": out.detach().numpy(),
+                   "loss": np.float64(loss.item()), "dx": x.grad.numpy()}
+            rec.update({"p0/" + k: v for k, v in sd0.items()})
+            rec.update({"grad/" + k: p.grad.numpy() for k, p in model.named_parameters()})
+            rec.update({"p1/" + k: v for k, v in np_state(model.state_dict()).items() if "running" in k or "num_b" in k})
+            model.eval()
+            with torch.no_grad():
+                rec["out_eval"] = model(x.detach()).numpy()
+            np.savez_compressed(os.path.join(OUT, "ae_small_%s_%dx%dx%d.npz" % (cname, N, H, W)), **rec)
+
+
+def gen_ae_init(av):
+    """RNG-exact init: seed -> parameter statistics of the full ACDC model (443 777 params)."""
+    torch.manual_seed(892372)
+    m = av.VanillaACAI(dict(width=128, latent_width=32, depth=32, latent=128, colors=1, device="cpu",
+                            use_batchnorm=True, use_sigmoid=True, n_res_block=None))
+    rec = {"nparams": np.int64(sum(p.numel() for p in m.parameters()))}
+    for k, p in m.named_parameters():
+        rec["sum/" + k] = np.float64(p.double().sum().item())
+        rec["abs/" + k] = np.float64(p.double().abs().sum().item())
+        rec["head/" + k] = p.detach().flatten()[:4].numpy()
+    np.savez_compressed(os.path.join(OUT, "ae_init_acdc.npz"), **rec)
+    return m
+
+
+def gen_ae_acdc_probe(m):
+    """Full-size C2/C3 model, 1 triplet at 160x160: sampled outputs / grads + norms."""
+    image, between = step_oracle.synthetic_triplets(1, 160, 160, seed=892372)
+    m.train()
+    z = m.encode(image)
+    out = m.decode(z)
+    loss = F.mse_loss(out, image)
+    loss.backward()
+    idx = np.random.RandomState(0).randint(0, out.numel(), size=64)
+    zidx = np.random.RandomState(1).randint(0, z.numel(), size=64)
+    rec = dict(loss=np.float64(loss.item()), out_idx=idx, out_val=out.detach().flatten()[idx].numpy(),
+               z_idx=zidx, z_val=z.detach().flatten()[zidx].numpy(),
+               out_norm=np.float64(out.double().norm().item()), z_norm=np.float64(z.double().norm().item()))
+    for k, p in m.named_parameters():
+        rec["gnorm/" + k] = np.float64(p.grad.double().norm().item())
+        rec["ghead/" + k] = p.grad.flatten()[:4].numpy()
+    for k, b in m.named_buffers():
+        if "running" in k:
+            rec["bn/" + k] = b.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "ae_acdc_probe.npz"), **rec)
+
+
+def build_pnetlin(nb):
+    net = nb.PNetLin(pnet_type="vgg", pnet_rand=True, pnet_tune=False, use_dropout=True, spatial=False,
+                     version="0.1", lpips=True)
+    lin_sd = torch.load(os.path.join(REF, "lpips", "weights", "v0.1", "vgg.pth"), map_location="cpu")
+    net.load_state_dict(lin_sd, strict=False)
+    net.eval()
+    return net, lin_sd
+
+
+def gen_lpips(nb):
+    net, lin_sd = build_pnetlin(nb)
+    # ship the lin-layer weights (data) with the product: LPIPS v0.1 linear calibration for VGG
+    wdir = os.path.join(ROOT, "superresolution_aniso_mri_amd", "lpips", "weights", "v0.1")
+    os.makedirs(wdir, exist_ok=True)
+    np.savez(os.path.join(wdir, "vgg_lin.npz"),
+             **{"lin%d" % k: lin_sd["lin%d.model.1.weight" % k].numpy().reshape(-1) for k in range(5)})
+    # (a) head only: synthetic tap features -> per-layer + total distance and grads wrt branch-1 features
+    g = torch.Generator().manual_seed(11)
+    shapes = [(2, 64, 12, 12), (2, 128, 6, 6), (2, 256, 3, 3), (2, 512, 2, 2), (2, 512, 1, 1)]
+    f0 = [torch.rand(s, generator=g) for s in shapes]
+    f1 = [torch.rand(s, generator=g).requires_grad_(True) for s in shapes]
+    import lpips.common as util
+    res = []
+    for k in range(5):
+        d = (util.normalize_tensor(f0[k]) - util.normalize_tensor(f1[k])) ** 2
+        res.append(nb.spatial_average(net.lins[k].model(d), keepdim=True))
+    val = sum(res)
+    val.sum().backward()
+    rec = {"val": val.detach().numpy()}
+    for k in range(5):
+        rec["f0_%d" % k], rec["f1_%d" % k] = f0[k].numpy(), f1[k].detach().numpy()
+        rec["res_%d" % k], rec["g1_%d" % k] = res[k].detach().numpy(), f1[k].grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "lpips_head.npz"), **rec)
+    # (b) full path on 1-channel images (broadcast in ScalingLayer), incl. the perceptual.py 2x-1 scaling
+    for (N, H, W) in ((2, 32, 32), (1, 48, 40)):
+        g = torch.Generator().manual_seed(100 + H)
+        ref = torch.rand(N, 1, H, W, generator=g)
+        syn = (ref + 0.1 * torch.randn(N, 1, H, W, generator=g)).clamp(0, 1).requires_grad_(True)
+        # trainer call: percept_criterion(reference, synthesized, normalize=True) -> PerceptualLoss.forward(
+        # pred=reference, target=synthesized) -> model.forward(target, pred) = PNetLin(in0=2*syn-1, in1=2*ref-1)
+        in0, in1 = 2 * syn - 1, 2 * ref - 1
+        d = net.forward(in0, in1)
+        d.mean().backward()
+        taps = net.net.forward(net.scaling_layer(in0))
+        rec = dict(ref=ref.numpy(), syn=syn.detach().numpy(), d=d.detach().numpy(), dsyn=syn.grad.numpy())
+        for k, t in enumerate(taps):
+            rec["tap%d_norm" % k] = np.float64(t.double().norm().item())
+            rec["tap%d_head" % k] = t.detach().flatten()[:8].numpy()
+        np.savez_compressed(os.path.join(OUT, "lpips_full_%dx%dx%d.npz" % (N, H, W)), **rec)
+    return net
+
+
+def gen_steps(av, net):
+    """k=3 ae_combined train steps (cardiac 0.5/0.5 lerp and brain per-sample alphas; LPIPS and MSE mix loss)."""
+    for tag, mix, brain in (("cardiac_lpips", "perceptual", False), ("brain_lpips", "perceptual", True),
+                            ("cardiac_mse", "mse", False)):
+        torch.manual_seed(4242)
+        model = av.VanillaACAI(small_args())
+        sd0 = np_state(model.state_dict())
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999))
+        lam = 0.05
+        B, H, W = 3, 32, 32
+        rec = {"p0/" + k: v for k, v in sd0.items()}
+        losses = []
+        for step in range(3):
+            image, between = step_oracle.synthetic_triplets(B, H, W, seed=500 + step)
+            rec["image_%d" % step], rec["between_%d" % step] = image.numpy(), between.numpy()
+            model.train()
+            z = model.encode(image)
+            out = model.decode(z)
+            loss_ae = F.mse_loss(out, image, reduction="mean")
+            if brain:
+                af = torch.tensor([[0.25], [0.5], [0.75]])
+                at = 1 - af
+                rec["alpha_from"], rec["alpha_to"] = af.numpy(), at.numpy()
+                z_mix = af[:, :, None, None] * z[:B] + at[:, :, None, None] * z[B:]
+            else:
+                a05 = torch.tensor([0.5])[:, None, None, None]
+                z_mix = a05 * z[:B] + (1 - a05) * z[B:]
+            s_mix = model.decode(z_mix)
+            z_ref = model.encode(between)
+            lat = F.mse_loss(z_mix, z_ref)
+            if mix == "perceptual":
+                # PerceptualLoss.forward(pred=between, target=s_mix, normalize=True) -> net(2*s_mix-1, 2*between-1)
+                extra = net.forward(2 * s_mix - 1, 2 * between - 1).mean()
+            else:
+                extra = F.mse_loss(between, s_mix)
+            loss = loss_ae + lam * extra
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append([loss.item(), loss_ae.item(), (lam * extra).item(), lat.item()])
+            if step == 0:
+                rec["z_0"], rec["out_0"], rec["s_mix_0"] = z.detach().numpy(), out.detach().numpy(), s_mix.detach().numpy()
+                rec.update({"grad0/" + k: p.grad.numpy().copy() for k, p in model.named_parameters()})
+        rec["losses"] = np.array(losses, dtype=np.float64)
+        rec.update({"p3/" + k: v for k, v in np_state(model.state_dict()).items()})
+        np.savez_compressed(os.path.join(OUT, "step_k3_%s.npz" % tag), **rec)
+
+
+def gen_supervolume(av):
+    """generate_hr_volumes.py:12-101 arithmetic (z=5, n=3) around the reference model in eval mode; the
+    reference function itself hard-codes .to('cuda') so its loop is restated here verbatim in meaning:
+    per alpha re-encode both neighbour stacks, lerp, decode, interleave, clamp."""
+    torch.manual_seed(77)
+    model = av.VanillaACAI(small_args())
+    # make running stats non-trivial
+    model.train()
+    with torch.no_grad():
+        model(torch.rand(4, 1, 32, 32))
+    model.eval()
+    vol = torch.rand(5, 1, 32, 32, generator=torch.Generator().manual_seed(3)) * 1.2 - 0.1
+    alpha_range = np.linspace(0, 1, 3 + 2, endpoint=True)[1:-1]
+    images2, images1 = vol[1:], vol[:-1]
+    interp = None
+    with torch.no_grad():
+        for alpha in alpha_range:
+            l1, l2 = model.encode(images2.float()), model.encode(images1.float())
+            inter = model.decode(alpha * l1 + (1 - alpha) * l2)
+            interp = inter if interp is None else torch.cat([interp, inter], dim=1)
+        new = None
+        for i in range(vol.shape[0] - 1):
+            new = torch.cat([vol[i], interp[i]]) if new is None else torch.cat([new, vol[i], interp[i]], dim=0)
+        new = torch.clamp(torch.cat([new, vol[i + 1]]), min=0, max=1.)
+    rec = {"vol": vol.numpy(), "alpha_range": alpha_range, "hr": new.numpy()}
+    rec.update({"p/" + k: v for k, v in np_state(model.state_dict()).items()})
+    np.savez_compressed(os.path.join(OUT, "supervolume.npz"), **rec)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(4)
+    av, avs, avm, nb = import_reference()
+    gen_ae_small(av, avs, avm)
+    m = gen_ae_init(av)
+    gen_ae_acdc_probe(m)
+    net = gen_lpips(nb)
+    gen_steps(av, net)
+    gen_supervolume(av)
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("wrote %d fixtures, %.1f KiB" % (len(os.listdir(OUT)), tot / 1024))
+
+
+if __name__ == "__main__":
+    main()

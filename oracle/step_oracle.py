@@ -1,0 +1,128 @@
+"""Oracle (TEST INFRASTRUCTURE, see oracle/__init__.py): the ``ae_combined`` training step and the
+slice-synthesis inference loop, restated on the CPU oracle networks.
+
+Follows
+  * kwatsch/cardiac/trainer_ae.py:10-50 (AETrainerEndToEnd.train), :79-130 (extra loss), :165-182 (lerp)
+  * kwatsch/brain/trainer_ae.py:92-132, :163-227, :255-281 (per-sample alpha_from / alpha_to)
+  * kwatsch/base_trainer.py:164-198 (get_loss: MSE mean), :348-351 (0.5/0.5 mix)
+  * kwatsch/trainer_ae.py:28-30 (Adam lr, betas (momentum|0.9, 0.999), weight_decay)
+  * generate_hr_volumes.py:12-69, :72-101 (create_super_volume / latent_space_interp)
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import lpips_oracle
+
+
+class OracleStep:
+    """One ``ae_combined`` trainer on the oracle AE (device-agnostic CPU restatement)."""
+
+    def __init__(self, ae, lr=1e-5, weight_decay=0.0, momentum=0.9, ex_loss_weight1=0.05,
+                 image_mix_loss_func="perceptual", vgg_sd=None, lin_w=None):
+        self.ae = ae
+        self.opt = torch.optim.Adam(ae.parameters(), lr=lr, weight_decay=weight_decay, betas=(momentum, 0.999))
+        self.lam = ex_loss_weight1
+        self.mix_loss = image_mix_loss_func
+        self.vgg_sd, self.lin_w = vgg_sd, lin_w
+
+    def extra_image_loss(self, reference, synthesized):
+        # kwatsch/cardiac/trainer_ae.py:103-130 without masks / laploss
+        if self.mix_loss == "perceptual":
+            return lpips_oracle.perceptual_loss(reference, synthesized, self.vgg_sd, self.lin_w,
+                                                normalize=True).mean()
+        return F.mse_loss(reference, synthesized)
+
+    def train(self, image, slice_between, alpha_from=None, alpha_to=None, update=True):
+        """image [2B,1,H,W] (from-slices then to-slices), slice_between [B,1,H,W].
+        alpha_* None -> cardiac 0.5/0.5 (trainer_ae.py:51, cardiac/trainer_ae.py:173);
+        else [B,1] per-sample coefficients (brain/trainer_ae.py:264-266)."""
+        ae = self.ae
+        B = image.shape[0] // 2
+        z = ae.encode(image, train=True)
+        out = ae.decode(z, train=True)
+        loss_ae_dist = F.mse_loss(out, image, reduction="mean")          # base_trainer.py:177
+        if alpha_from is None:
+            z_mix = 0.5 * z[:B] + (1 - 0.5) * z[B:]
+        else:
+            z_mix = alpha_from[:, :, None, None] * z[:B] + alpha_to[:, :, None, None] * z[B:]
+        s_mix = ae.decode(z_mix, train=True)
+        z_ref = ae.encode(slice_between, train=True)       # graph never back-propagated; updates BN stats (Q6)
+        loss_latent = F.mse_loss(z_mix, z_ref)
+        loss_extra = self.lam * self.extra_image_loss(slice_between, s_mix)
+        loss = loss_ae_dist + loss_extra
+        self.opt.zero_grad()
+        if update:
+            loss.backward()
+            self.opt.step()
+        return dict(loss_ae=float(loss.detach()), loss_ae_dist=float(loss_ae_dist.detach()),
+                    loss_ae_dist_extra=float(loss_extra.detach()), loss_latent_1=float(loss_latent.detach()), z=z.detach(), out=out.detach(), z_mix=z_mix.detach(),
+                    s_mix=s_mix.detach())
+
+
+def create_super_volume(ae, images, alpha_range, use_original=True):
+    """generate_hr_volumes.py:12-69 with the reference's per-alpha re-encoding collapsed (eval-mode BN
+    makes results batch-composition independent).  images [z,1,H,W] -> [(z-1)(n+1)+1, H, W]."""
+    with torch.no_grad():
+        lat = ae.encode(images.float(), train=False)
+        recon = images if use_original else ae.decode(lat, train=False)
+        interp = []
+        for alpha in alpha_range:
+            inter = float(alpha) * lat[1:] + (1 - float(alpha)) * lat[:-1]   # :88, later slice weighted alpha
+            interp.append(ae.decode(inter, train=False))
+        interp = torch.cat(interp, dim=1)                                   # [z-1, n, H, W]
+        parts = []
+        for i in range(images.shape[0] - 1):
+            parts += [recon[i], interp[i]]
+        parts.append(recon[-1])
+        return torch.clamp(torch.cat(parts, dim=0), min=0, max=1.)
+
+
+def synthetic_triplets(B, H, W, seed, device="cpu"):
+    """Smooth, correlated (from, to, between) triplets in [0,1]: sum of 8 Gaussian blobs
+    + low-pass noise; between = 0.5(from+to) + N(0, 0.02)."""
+    g = torch.Generator().manual_seed(int(seed))
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+
+    def blobs(c, s, a):
+        img = torch.zeros(B, H, W)
+        for k in range(c.shape[1]):
+            d = (yy[None] - c[:, k, 0, None, None]) ** 2 + (xx[None] - c[:, k, 1, None, None]) ** 2
+            img = img + a[:, k, None, None] * torch.exp(-d / (2 * s[:, k, None, None] ** 2))
+        return img
+
+    c = torch.rand(B, 8, 2, generator=g)
+    s = 0.04 + 0.12 * torch.rand(B, 8, generator=g)
+    a = 0.2 + 0.5 * torch.rand(B, 8, generator=g)
+    dc = 0.03 * torch.randn(B, 8, 2, generator=g)
+    frm = blobs(c, s, a)
+    to = blobs(c + dc, s, a)
+
+    def lowpass(n):
+        return F.avg_pool2d(F.pad(n[:, None], (2, 2, 2, 2), mode="reflect"), 5, stride=1)[:, 0]
+
+    frm = (frm + 0.05 * lowpass(torch.randn(B, H, W, generator=g))).clamp(0, 1)
+    to = (to + 0.05 * lowpass(torch.randn(B, H, W, generator=g))).clamp(0, 1)
+    btw = (0.5 * (frm + to) + 0.02 * torch.randn(B, H, W, generator=g)).clamp(0, 1)
+    image = torch.cat([frm[:, None], to[:, None]], dim=0).float().to(device)
+    return image, btw[:, None].float().to(device)
+
+
+def ssim(a, b, data_range=1.0, win=7, k1=0.01, k2=0.03):
+    """Mean SSIM, uniform win x win window, sample covariance (skimage ``structural_similarity`` defaults for
+    float images with explicit data_range; evaluate/metrics.py:139).  a, b: [N,1,H,W] or [H,W]."""
+    a = torch.as_tensor(a, dtype=torch.float64).reshape(-1, 1, *a.shape[-2:])
+    b = torch.as_tensor(b, dtype=torch.float64).reshape(-1, 1, *b.shape[-2:])
+    npx = win * win
+    cov_norm = npx / (npx - 1.0)
+    ux, uy = F.avg_pool2d(a, win, 1), F.avg_pool2d(b, win, 1)
+    uxx, uyy, uxy = F.avg_pool2d(a * a, win, 1), F.avg_pool2d(b * b, win, 1), F.avg_pool2d(a * b, win, 1)
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+    s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
+    return float(s.mean())
+
+
+def psnr(a, b, data_range=1.0):
+    mse = float(((torch.as_tensor(a, dtype=torch.float64) - torch.as_tensor(b, dtype=torch.float64)) ** 2).mean())
+    return 10 * np.log10(data_range ** 2 / max(mse, 1e-30))
