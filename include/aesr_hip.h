@@ -1,0 +1,132 @@
+/* libaesr_hip.so -- C ABI of the MI355X (gfx950) kernels behind the ae_combined hot path.
+ *
+ * The reference (qurAI-amsterdam/SuperResolution_aniso_MRI) is pure Python on PyTorch: it has no FFI of
+ * its own, every op below is an ATen/cuDNN call issued from the cited reference line.  This header is the
+ * boundary a maintainer binds instead (ctypes stub: INTEGRATION.md).  Conventions:
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer owned by the caller (PyTorch's
+ *     caching allocator in the shipped host code) unless named *_host; no allocation, no host sync and no
+ *     global state inside the library besides a tile-plan cache; workspaces are caller-provided and sized
+ *     by the *_workspace_* helpers;
+ *   - activations are fp32 NHWC ("[N,H,W,C]"); weights cross the boundary in PyTorch's [Cout][Cin][KH][KW];
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); all work is enqueued on it;
+ *   - every entry returns 0 on success, non-zero on error (AESR_ERR_*), never throws; the message of the
+ *     calling thread's last error is aesr_last_error_string();
+ *   - activation codes: 0 none, 1 LeakyReLU(slope), 2 ReLU, 3 sigmoid;
+ *   - BatchNorm "groups": a batch may consist of up to 4 consecutive sub-batches with independent batch
+ *     statistics; group g covers images [nstart[g], nstart[g+1]) (nstart has G+1 entries).
+ */
+#ifndef AESR_HIP_H
+#define AESR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AESR_ABI_VERSION 1
+#define AESR_ERR_ARG 1
+#define AESR_ERR_HIP 2
+#define AESR_ERR_UNSUPPORTED 3
+
+int aesr_version(void);
+const char* aesr_last_error_string(void);
+
+/* ---- convolution, stride 1 (nn.Conv2d: networks/acai_vanilla.py:51,55-56,68,70,87-88,96,98;
+ *      lpips/pretrained_networks.py:107-116) ------------------------------------------------------------ */
+
+/* Number of floats of the packed-weight buffer for a [Cout][Cin][KS][KS] filter.
+ * transpose = 0: forward operand; 1: data-gradient operand (flipped taps, channels swapped). */
+size_t aesr_conv2d_packed_floats(int Cout, int Cin, int KS, int transpose);
+int aesr_conv2d_pack(const float* w, float* packed, int Cout, int Cin, int KS, int transpose, void* stream);
+
+/* out = act(conv(in, w) + bias)                         [MFMA implicit GEMM; Cin % 4 == 0]
+ * `packed` from aesr_conv2d_pack(transpose=0).  bias may be NULL.  Ho = H + 2*pad - KS + 1. */
+int aesr_conv2d_fwd(const float* in, const float* packed, const float* bias, float* out, int N, int H, int W, int Cin,
+                    int Cout, int KS, int pad, int act, float slope, void* stream);
+
+/* dx = conv_transpose(dy, w) * act'(x_saved)            [same kernel on the transposed packing; Cout % 4 == 0]
+ * dy is [N,Ho,Wo,Cout], dx is [N,H,W,Cin]; x_saved (may be NULL) is the saved OUTPUT of the activation that
+ * produced the convolution's input, mask_act its code: fuses the LeakyReLU/ReLU backward of the previous layer. */
+int aesr_conv2d_dgrad(const float* dy, const float* packed_t, const float* x_saved, float* dx, int N, int H, int W,
+                      int Cin, int Cout, int KS, int pad, int mask_act, float slope, void* stream);
+
+/* dw[Cout][Cin][KS][KS], db[Cout] (db may be NULL)      [MFMA split-K, fixed-order slab reduction]
+ * workspace: aesr_conv2d_wgrad_workspace_floats(...) floats. */
+size_t aesr_conv2d_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int KS, int pad);
+int aesr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W,
+                      int Cin, int Cout, int KS, int pad, void* stream);
+
+/* Bandwidth-bound special cases (K or N of the GEMM <= 4): weights in PyTorch layout, no packing.
+ * small-Cin forward (stem networks/acai_vanilla.py:51; VGG conv1_1 with lpips/networks_basic.py:93-100 folded:
+ * bcast != 0 means `in` has ONE channel and virtual channel c = ca[c]*in + cb[c]); transpose != 0 runs the data
+ * gradient of a Cout<=4 conv (w given as [Cin_fwd... see DESIGN.md]); x_saved/mask_act as in aesr_conv2d_dgrad. */
+int aesr_conv2d_smallcin_fwd(const float* in, const float* w, const float* bias, const float* y_saved, float* out, int N,
+                             int H, int W, int Cin, int Cout, int KS, int pad, int act, int mask_act, float slope,
+                             int transpose, int bcast, const float* ca_host, const float* cb_host, void* stream);
+int aesr_conv2d_smallcin_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout, int KS,
+                               int pad, int bcast, const float* ca_host, void* stream);
+/* 1x1 small-Cin weight/bias gradient (the stem).  workspace: aesr_small_wgrad_workspace_floats(Cout*(Cin+1)). */
+size_t aesr_small_wgrad_workspace_floats(int nout);
+int aesr_conv2d_smallcin_wgrad(const float* in, const float* dout, float* dw, float* db, float* workspace, int N, int H,
+                               int W, int Cin, int Cout, int pad, void* stream);
+/* 3x3 pad-1 Cout==1 weight/bias gradient (output conv networks/acai_vanilla.py:98).  Same workspace helper
+ * with nout = Cin*9+1. */
+int aesr_conv2d_cout1_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W,
+                            int Cin, void* stream);
+
+/* ---- BatchNorm2d (+AvgPool2d(2) / nearest Upsample x2) (networks/acai_vanilla.py:58-59,90-92) ------------ */
+#define AESR_BN_NONE 0
+#define AESR_BN_POOL 1
+#define AESR_BN_UP 2
+#define AESR_BN_NWG 256   /* partial rows per group of the stats / backward-reduce passes */
+
+/* sums[G][2][C] (double): per group and channel sum(y), sum(y^2).  partial: G*AESR_BN_NWG*2*C floats. */
+int aesr_bn_stats(const float* y, float* partial, double* sums, int HW, int C, int G, const int* nstart_host,
+                  void* stream);
+/* mean/invstd/scale/shift [G][C].  train: from sums and counts_dev[G] (double, elements per channel, global under
+ * data parallel); running_mean/var/num_batches_tracked updated group after group when update_running.
+ * eval (train == 0): from the running buffers; sums/counts ignored. */
+int aesr_bn_finalize(const double* sums, const double* counts_dev, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
+                     float* scale, float* shift, int C, int G, float momentum, float eps, int train, int update_running,
+                     void* stream);
+/* out = scale[g]*f(y) + shift[g], f = identity / 2x2 mean (floor) / nearest x2. */
+int aesr_bn_apply(const float* y, const float* scale, const float* shift, float* out, int N, int H, int W, int C, int mode,
+                  int G, const int* nstart_host, void* stream);
+/* backward, step 1: sums[G][2][C] (double) = sum(g), sum(g*xhat) with g the gradient w.r.t. the BN output seen
+ * through the pool / upsample.  gout is [N,Ho,Wo,C] (pool: Ho=H/2; up: Ho=2H; none: Ho=H). */
+int aesr_bn_bwd_reduce(const float* gout, const float* y, const float* mean, const float* invstd, float* partial,
+                       double* sums, int N, int H, int W, int C, int mode, int G, const int* nstart_host, void* stream);
+/* step 2: dpre = scale*(g - s1/M - xhat*s2/M) * act'(y);  dgamma = sum_g s2, dbeta = sum_g s1.
+ * coef: G*2*C floats of scratch. */
+int aesr_bn_bwd_apply(const float* gout, const float* y, const float* mean, const float* invstd, const float* scale,
+                      const double* sums, const double* counts_dev, float* coef, float* dgamma, float* dbeta,
+                      float* dpre, int N, int H, int W, int C, int mode, int act, float slope, int G,
+                      const int* nstart_host, void* stream);
+
+/* ---- latent lerp (kwatsch/cardiac/trainer_ae.py:173; kwatsch/brain/trainer_ae.py:264-266;
+ *      generate_hr_volumes.py:88) ------------------------------------------------------------------------- */
+/* z [2B][per], zmix [B][per]: zmix[b] = a_from[b]*z[b] + a_to[b]*z[B+b]; per % 4 == 0. */
+int aesr_lerp_fwd(const float* z, const float* a_from, const float* a_to, float* zmix, int B, size_t per, void* stream);
+int aesr_lerp_bwd(const float* dzmix, const float* a_from, const float* a_to, float* dz, int B, size_t per, void* stream);
+
+/* ---- losses (kwatsch/base_trainer.py:177; kwatsch/cardiac/trainer_ae.py:181) ------------------------------ */
+#define AESR_MSE_NPART 512
+/* loss[0] = mean((a-b)^2); partial: AESR_MSE_NPART doubles. */
+int aesr_mse_fwd(const float* a, const float* b, double* partial, float* loss, size_t n, void* stream);
+/* da = 2*(a-b)*gloss[0]/n */
+int aesr_mse_bwd(const float* a, const float* b, const float* gloss, float* da, size_t n, void* stream);
+/* dpre = dout * act'(y) from the saved activation output (sigmoid of networks/acai_vanilla.py:98). */
+int aesr_act_bwd(const float* dout, const float* y, float* dpre, size_t n, int act, float slope, void* stream);
+
+/* ---- Adam (torch.optim.Adam as used by kwatsch/trainer_ae.py:29-30) on a flat buffer ---------------------- */
+/* state: 4 floats {step, 1-beta1^t, sqrt(1-beta2^t), unused}; the step is advanced on the device. */
+int aesr_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* state, size_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AESR_HIP_H */

@@ -1,0 +1,106 @@
+"""ctypes binding of libaesr_hip.so (C ABI: include/aesr_hip.h).
+
+There is NO fallback: if the shared library is missing or an entry point is absent this module raises at
+import time, and every wrapper raises RuntimeError with the library's own message when a call fails.
+PyTorch is used only for device memory and the current HIP stream.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaesr_hip.so")
+
+P = c_void_p          # device pointer
+IP = ctypes.POINTER(c_int)
+FP = ctypes.POINTER(c_float)
+
+# name -> (restype, argtypes); must list every symbol include/aesr_hip.h declares (checked by tests)
+SIGNATURES = {
+    "aesr_version": (c_int, []),
+    "aesr_last_error_string": (c_char_p, []),
+    "aesr_conv2d_packed_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "aesr_conv2d_pack": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "aesr_conv2d_fwd": (c_int, [P, P, P, P] + [c_int] * 8 + [c_float, P]),
+    "aesr_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 8 + [c_float, P]),
+    "aesr_conv2d_wgrad_workspace_floats": (c_size_t, [c_int] * 7),
+    "aesr_conv2d_wgrad": (c_int, [P, P, P, P, P] + [c_int] * 7 + [P]),
+    "aesr_conv2d_smallcin_fwd": (c_int, [P, P, P, P, P] + [c_int] * 9 + [c_float, c_int, c_int, FP, FP, P]),
+    "aesr_conv2d_smallcin_dgrad": (c_int, [P, P, P] + [c_int] * 8 + [FP, P]),
+    "aesr_small_wgrad_workspace_floats": (c_size_t, [c_int]),
+    "aesr_conv2d_smallcin_wgrad": (c_int, [P, P, P, P, P] + [c_int] * 6 + [P]),
+    "aesr_conv2d_cout1_wgrad": (c_int, [P, P, P, P, P] + [c_int] * 4 + [P]),
+    "aesr_bn_stats": (c_int, [P, P, P, c_int, c_int, c_int, IP, P]),
+    "aesr_bn_finalize": (c_int, [P] * 11 + [c_int, c_int, c_float, c_float, c_int, c_int, P]),
+    "aesr_bn_apply": (c_int, [P, P, P, P] + [c_int] * 6 + [IP, P]),
+    "aesr_bn_bwd_reduce": (c_int, [P] * 6 + [c_int] * 6 + [IP, P]),
+    "aesr_bn_bwd_apply": (c_int, [P] * 11 + [c_int] * 6 + [c_float, c_int, IP, P]),
+    "aesr_lerp_fwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
+    "aesr_lerp_bwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
+    "aesr_mse_fwd": (c_int, [P, P, P, P, c_size_t, P]),
+    "aesr_mse_bwd": (c_int, [P, P, P, P, c_size_t, P]),
+    "aesr_act_bwd": (c_int, [P, P, P, c_size_t, c_int, c_float, P]),
+    "aesr_adam_step": (c_int, [P, P, P, P, P, c_size_t] + [c_float] * 5 + [P]),
+}
+
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+BN_NONE, BN_POOL, BN_UP = 0, 1, 2
+BN_NWG = 256
+MSE_NPART = 512
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libaesr_hip.so not found at %s -- build it with `python __graft_entry__.py` (or `make -C "
+            "superresolution_aniso_mri_amd/csrc`). The HIP extension is mandatory: there is no CPU/eager fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise RuntimeError("libaesr_hip.so does not export %s (stale build?)" % name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    return lib.aesr_last_error_string().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (code %d): %s" % (what, rc, last_error()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def int_array(vals):
+    return (c_int * len(vals))(*[int(v) for v in vals])
+
+
+def float_array(vals):
+    return (c_float * len(vals))(*[float(v) for v in vals])
+
+
+def require_gpu_tensor(t, name, dtype=torch.float32):
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (got %s): the HIP path has no CPU fallback" % (name, t.device))
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    return t

@@ -1,0 +1,342 @@
+// extern "C" entry points of libaesr_hip.so (declared in include/aesr_hip.h) + the host-side tile planners.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "../../include/aesr_hip.h"
+#include "aesr_kernels.h"
+
+// ---- error string ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void aesr_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- tile planning ------------------------------------------------------------------------------------------
+static void cout_padding(int Cout, int* CoutP, int* NB) {
+    if (Cout <= 16) { *CoutP = 16; *NB = 1; }
+    else if (Cout <= 32) { *CoutP = 32; *NB = 2; }
+    else { *CoutP = round_up(Cout, 64); *NB = 4; }
+}
+
+struct ConvPlan { int TI, TH, TW, NB, MBW, CinP, CoutP; };
+static std::mutex g_plan_mu;
+static std::map<std::tuple<int, int, int, int, int, int>, ConvPlan> g_conv_plans;
+
+// Pick the output tile (TI images x TH x TW) that minimises estimated MFMA time: idle M-block slots at tile
+// edges (the network's sizes are 162, 81, 40 ...) and the workgroup-count quantisation over 256 CUs.
+static ConvPlan plan_conv(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    const auto key = std::make_tuple(N, Ho, Wo, Cin, Cout, KS);
+    auto it = g_conv_plans.find(key);
+    if (it != g_conv_plans.end()) return it->second;
+    ConvPlan p;
+    cout_padding(Cout, &p.CoutP, &p.NB);
+    p.CinP = round_up(Cin, 16);
+    p.MBW = (p.NB == 4) ? 4 : 8;
+    const int maxpix = 64 * p.MBW, maxpatch = 680;   // 680 px * 80 B = 54 KB -> 3 workgroups per CU
+    const int ncout = p.CoutP / (16 * p.NB);
+    const double kmf = (double)KS * KS * (p.CinP / 16) * 4 * 32;   // MFMA cycles per (M-block, N-block)
+    double best = 1e300;
+    p.TI = 1; p.TH = 1; p.TW = 1;
+    auto consider = [&](int TI, int TH, int TW) {
+        const int PP = TI * (TH + KS - 1) * (TW + KS - 1);
+        const int TP = TI * TH * TW;
+        if (TP > maxpix || PP > maxpatch) return;
+        const int nblk = ceil_div(TP, 16);
+        const long nwg = (long)ceil_div(N, TI) * ceil_div(Ho, TH) * ceil_div(Wo, TW) * ncout;
+        const double per = ceil_div(nblk, 4) * p.NB * kmf + (double)PP * (p.CinP / 16) * 6.0 + 1500.0;
+        const double rounds = nwg <= 2048 ? (double)ceil_div((int)nwg, 256) : (double)nwg / 256.0;
+        const double t = per * rounds;
+        if (t < best * 0.999 || (t < best * 1.001 && TP > p.TI * p.TH * p.TW)) {
+            if (t < best) best = t;
+            p.TI = TI; p.TH = TH; p.TW = TW;
+        }
+    };
+    if (Ho * Wo <= maxpix && (Ho + KS - 1) * (Wo + KS - 1) <= maxpatch) {
+        for (int TI = 1; TI <= N && TI * Ho * Wo <= maxpix; ++TI) consider(TI, Ho, Wo);
+    }
+    for (int TH = 1; TH <= Ho && TH <= 64; ++TH)
+        for (int TW = 1; TW <= Wo && TW <= 64; ++TW) consider(1, TH, TW);
+    g_conv_plans[key] = p;
+    return p;
+}
+
+struct WgradPlan { int variant, ROWP, COT, WK, CinP, CoutP, TH, TW, S, nslab; size_t slab_floats; };
+static std::map<std::tuple<int, int, int, int, int, int>, WgradPlan> g_wgrad_plans;
+
+static WgradPlan plan_wgrad(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    const auto key = std::make_tuple(N, Ho, Wo, Cin, Cout, KS);
+    auto it = g_wgrad_plans.find(key);
+    if (it != g_wgrad_plans.end()) return it->second;
+    WgradPlan p;
+    int CIB, COBW;
+    if (Cout > 32) { p.variant = 1; p.ROWP = 32; p.COT = 64; p.WK = 1; CIB = 2; COBW = 1; }
+    else if (Cout > 16 || Cin > 16) { p.variant = 0; p.ROWP = 32; p.COT = 32; p.WK = 2; CIB = 2; COBW = 1; }
+    else { p.variant = 2; p.ROWP = 16; p.COT = 16; p.WK = 4; CIB = 1; COBW = 1; }
+    p.CinP = round_up(Cin, p.ROWP);
+    p.CoutP = round_up(Cout, p.COT);
+    const size_t max_lds = 72 * 1024;
+    double best = 1e300;
+    p.TH = 1; p.TW = 4;
+    for (int TW = 4; TW <= 64; TW += 4) {
+        if (TW - 4 >= Wo) break;
+        for (int TH = 1; TH <= 32 && TH <= Ho; ++TH) {
+            const int PP = (TH + KS - 1) * (TW + KS - 1), TP = TH * TW;
+            const size_t ldsb = ((size_t)PP * p.ROWP + (size_t)TP * p.COT) * 4;
+            if (ldsb > max_lds) break;
+            const double tiles = (double)ceil_div(Ho, TH) * ceil_div(Wo, TW);
+            const double mf = (double)ceil_div(TP / 4, p.WK) * (KS * KS * CIB * COBW + 1) * 32.0;
+            const double stage = (double)(PP * p.ROWP + TP * p.COT) / 4.0 / 256.0 * 24.0 + 800.0;
+            const double t = tiles * (mf + stage);
+            if (t < best) { best = t; p.TH = TH; p.TW = TW; }
+        }
+    }
+    const int ntiles = N * ceil_div(Ho, p.TH) * ceil_div(Wo, p.TW);
+    const int nchunks = (p.CinP / p.ROWP) * (p.CoutP / p.COT);
+    int S = 640 / nchunks;
+    if (S < 1) S = 1;
+    if (S > ntiles) S = ntiles;
+    p.S = S;
+    p.nslab = S * p.WK;
+    p.slab_floats = (size_t)p.nslab * (KS * KS + 1) * p.CinP * p.CoutP;
+    g_wgrad_plans[key] = p;
+    return p;
+}
+
+static bool fill_groups(BnGroups* gr, int G, const int* nstart_host) {
+    if (G < 1 || G > 4 || !nstart_host) return false;
+    gr->G = G;
+    for (int i = 0; i <= G; ++i) gr->nstart[i] = nstart_host[i];
+    for (int i = G + 1; i < 5; ++i) gr->nstart[i] = nstart_host[G];
+    return true;
+}
+
+// ---- C ABI ------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int aesr_version(void) { return AESR_ABI_VERSION; }
+const char* aesr_last_error_string(void) { return g_err; }
+
+size_t aesr_conv2d_packed_floats(int Cout, int Cin, int KS, int transpose) {
+    int NP, NB;
+    const int kin = transpose ? Cout : Cin, nout = transpose ? Cin : Cout;
+    cout_padding(nout, &NP, &NB);
+    return (size_t)KS * KS * round_up(kin, 16) * NP;
+}
+
+int aesr_conv2d_pack(const float* w, float* packed, int Cout, int Cin, int KS, int transpose, void* stream) {
+    AESR_CHECK_ARG(w && packed && Cout > 0 && Cin > 0 && (KS == 1 || KS == 3), "aesr_conv2d_pack: bad arguments");
+    int NP, NB;
+    const int kin = transpose ? Cout : Cin, nout = transpose ? Cin : Cout;
+    cout_padding(nout, &NP, &NB);
+    return aesr_launch_pack_weights(w, packed, Cout, Cin, KS, round_up(kin, 16), NP, transpose, (hipStream_t)stream);
+}
+
+static int run_igemm(const float* in, const float* packed, const float* bias, const float* ysave, float* out, int N, int H,
+                     int W, int Cin, int Cout, int KS, int pad, int act, int mask_act, float slope, hipStream_t st) {
+    const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
+    const ConvPlan p = plan_conv(N, Ho, Wo, Cin, Cout, KS);
+    IgemmArgs a;
+    a.in = in; a.wpk = packed; a.bias = bias; a.ysave = ysave; a.out = out;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = p.CinP; a.Cout = Cout; a.CoutP = p.CoutP; a.Ho = Ho; a.Wo = Wo; a.pad = pad;
+    a.TI = p.TI; a.TH = p.TH; a.TW = p.TW; a.tiles_y = ceil_div(Ho, p.TH); a.tiles_x = ceil_div(Wo, p.TW);
+    a.act = act; a.mask_act = mask_act; a.slope = slope;
+    return aesr_launch_conv_igemm(a, KS, p.NB, p.MBW, st);
+}
+
+int aesr_conv2d_fwd(const float* in, const float* packed, const float* bias, float* out, int N, int H, int W, int Cin,
+                    int Cout, int KS, int pad, int act, float slope, void* stream) {
+    AESR_CHECK_ARG(in && packed && out && N > 0 && H > 0 && W > 0, "aesr_conv2d_fwd: null pointer or empty shape");
+    AESR_CHECK_ARG(Cin % 4 == 0 && Cin > 0 && Cout > 0, "aesr_conv2d_fwd: Cin=%d must be a positive multiple of 4", Cin);
+    AESR_CHECK_ARG((KS == 1 || KS == 3) && pad >= 0 && pad < KS, "aesr_conv2d_fwd: unsupported KS=%d pad=%d", KS, pad);
+    return run_igemm(in, packed, bias, nullptr, out, N, H, W, Cin, Cout, KS, pad, act, ACT_NONE, slope, (hipStream_t)stream);
+}
+
+int aesr_conv2d_dgrad(const float* dy, const float* packed_t, const float* x_saved, float* dx, int N, int H, int W, int Cin,
+                      int Cout, int KS, int pad, int mask_act, float slope, void* stream) {
+    AESR_CHECK_ARG(dy && packed_t && dx && N > 0 && H > 0 && W > 0, "aesr_conv2d_dgrad: null pointer or empty shape");
+    AESR_CHECK_ARG(Cout % 4 == 0 && Cin > 0 && Cout > 0, "aesr_conv2d_dgrad: Cout=%d must be a positive multiple of 4", Cout);
+    AESR_CHECK_ARG((KS == 1 || KS == 3) && pad >= 0 && pad < KS, "aesr_conv2d_dgrad: unsupported KS=%d pad=%d", KS, pad);
+    const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
+    // dx = conv(dy [N,Ho,Wo,Cout], flipped w) with padding KS-1-pad -> output [N,H,W,Cin]
+    return run_igemm(dy, packed_t, nullptr, x_saved, dx, N, Ho, Wo, Cout, Cin, KS, KS - 1 - pad, ACT_NONE, mask_act, slope,
+                     (hipStream_t)stream);
+}
+
+size_t aesr_conv2d_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int KS, int pad) {
+    const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
+    return plan_wgrad(N, Ho, Wo, Cin, Cout, KS).slab_floats;
+}
+
+int aesr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W, int Cin,
+                      int Cout, int KS, int pad, void* stream) {
+    AESR_CHECK_ARG(x && dy && dw && workspace && N > 0, "aesr_conv2d_wgrad: null pointer or empty shape");
+    AESR_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0, "aesr_conv2d_wgrad: Cin=%d, Cout=%d must be multiples of 4", Cin, Cout);
+    AESR_CHECK_ARG((KS == 1 || KS == 3) && pad >= 0 && pad < KS, "aesr_conv2d_wgrad: unsupported KS=%d pad=%d", KS, pad);
+    const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
+    const WgradPlan p = plan_wgrad(N, Ho, Wo, Cin, Cout, KS);
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.slab = workspace;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = p.CinP; a.Cout = Cout; a.CoutP = p.CoutP; a.Ho = Ho; a.Wo = Wo; a.pad = pad;
+    a.TH = p.TH; a.TW = p.TW; a.tiles_y = ceil_div(Ho, p.TH); a.tiles_x = ceil_div(Wo, p.TW);
+    a.ntiles = N * a.tiles_y * a.tiles_x; a.S = p.S;
+    if (int e = aesr_launch_conv_wgrad(a, KS, p.variant, (hipStream_t)stream)) return e;
+    return aesr_launch_wgrad_reduce(workspace, dw, db, p.nslab, KS, Cin, p.CinP, Cout, p.CoutP, (hipStream_t)stream);
+}
+
+int aesr_conv2d_smallcin_fwd(const float* in, const float* w, const float* bias, const float* y_saved, float* out, int N,
+                             int H, int W, int Cin, int Cout, int KS, int pad, int act, int mask_act, float slope,
+                             int transpose, int bcast, const float* ca_host, const float* cb_host, void* stream) {
+    AESR_CHECK_ARG(in && w && out && N > 0 && Cin >= 1 && Cin <= 4 && Cout > 0, "aesr_conv2d_smallcin_fwd: need 1 <= Cin <= 4");
+    AESR_CHECK_ARG(!bcast || (ca_host && cb_host), "aesr_conv2d_smallcin_fwd: bcast needs ca/cb");
+    SmallArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.w = w; a.bias = bias; a.ysave = y_saved; a.out = out;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KS = KS; a.pad = pad;
+    a.Ho = H + 2 * pad - KS + 1; a.Wo = W + 2 * pad - KS + 1;
+    a.act = act; a.mask_act = mask_act; a.slope = slope; a.transpose = transpose; a.bcast = bcast;
+    for (int i = 0; i < Cin && bcast; ++i) { a.ca[i] = ca_host[i]; a.cb[i] = cb_host[i]; }
+    return aesr_launch_smallcin_fwd(a, (hipStream_t)stream);
+}
+
+int aesr_conv2d_smallcin_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout, int KS,
+                               int pad, int bcast, const float* ca_host, void* stream) {
+    AESR_CHECK_ARG(dy && w && dx && N > 0 && Cin >= 1 && Cin <= 4 && Cout > 0, "aesr_conv2d_smallcin_dgrad: need 1 <= Cin <= 4");
+    AESR_CHECK_ARG(!bcast || ca_host, "aesr_conv2d_smallcin_dgrad: bcast needs ca");
+    SmallDgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dy = dy; a.w = w; a.dx = dx; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KS = KS; a.pad = pad; a.bcast = bcast;
+    a.Ho = H + 2 * pad - KS + 1; a.Wo = W + 2 * pad - KS + 1;
+    for (int i = 0; i < Cin && bcast; ++i) a.ca[i] = ca_host[i];
+    return aesr_launch_smallcin_dgrad(a, (hipStream_t)stream);
+}
+
+#define SMALL_WGRAD_NWG 512
+size_t aesr_small_wgrad_workspace_floats(int nout) { return (size_t)SMALL_WGRAD_NWG * nout; }
+
+int aesr_conv2d_smallcin_wgrad(const float* in, const float* dout, float* dw, float* db, float* workspace, int N, int H,
+                               int W, int Cin, int Cout, int pad, void* stream) {
+    AESR_CHECK_ARG(in && dout && dw && db && workspace && Cin >= 1 && Cin <= 4, "aesr_conv2d_smallcin_wgrad: need 1 <= Cin <= 4");
+    AESR_CHECK_ARG(Cout > 0 && Cout <= 256 && 256 % Cout == 0, "aesr_conv2d_smallcin_wgrad: Cout=%d must divide 256", Cout);
+    SmallWgradArgs a;
+    a.in = in; a.dout = dout; a.partial = workspace; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.pad = pad;
+    a.Ho = H + 2 * pad; a.Wo = W + 2 * pad;
+    if (int e = aesr_launch_smallcin_wgrad(a, SMALL_WGRAD_NWG, (hipStream_t)stream)) return e;
+    return aesr_launch_sum_partials(workspace, SMALL_WGRAD_NWG, Cout * (Cin + 1), dw, Cout * Cin, db, (hipStream_t)stream);
+}
+
+int aesr_conv2d_cout1_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W,
+                            int Cin, void* stream) {
+    AESR_CHECK_ARG(x && dy && dw && db && workspace, "aesr_conv2d_cout1_wgrad: null pointer");
+    AESR_CHECK_ARG(Cin > 0 && Cin <= 128 && 256 % Cin == 0, "aesr_conv2d_cout1_wgrad: Cin=%d must divide 256", Cin);
+    Cout1WgradArgs a;
+    a.x = x; a.dy = dy; a.partial = workspace; a.N = N; a.H = H; a.W = W; a.Cin = Cin;
+    a.TH = H < 16 ? H : 16; a.TW = W < 16 ? W : 16;
+    while ((size_t)(a.TH + 2) * (a.TW + 2) * (Cin + 1) * 4 > 60 * 1024 && a.TH > 1) a.TH /= 2;
+    a.tiles_y = ceil_div(H, a.TH); a.tiles_x = ceil_div(W, a.TW); a.ntiles = N * a.tiles_y * a.tiles_x;
+    int nwg = a.ntiles < SMALL_WGRAD_NWG ? a.ntiles : SMALL_WGRAD_NWG;
+    if (int e = aesr_launch_cout1_wgrad(a, nwg, (hipStream_t)stream)) return e;
+    return aesr_launch_sum_partials(workspace, nwg, Cin * 9 + 1, dw, Cin * 9, db, (hipStream_t)stream);
+}
+
+int aesr_bn_stats(const float* y, float* partial, double* sums, int HW, int C, int G, const int* nstart_host, void* stream) {
+    BnGroups gr;
+    AESR_CHECK_ARG(y && partial && sums && fill_groups(&gr, G, nstart_host), "aesr_bn_stats: bad arguments");
+    if (int e = aesr_launch_bn_stats(y, partial, HW, C, gr, AESR_BN_NWG, (hipStream_t)stream)) return e;
+    return aesr_launch_bn_reduce(partial, sums, AESR_BN_NWG, C, G, (hipStream_t)stream);
+}
+
+int aesr_bn_finalize(const double* sums, const double* counts_dev, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                     int C, int G, float momentum, float eps, int train, int update_running, void* stream) {
+    AESR_CHECK_ARG(gamma && beta && mean && invstd && scale && shift && G >= 1 && G <= 4, "aesr_bn_finalize: bad arguments");
+    AESR_CHECK_ARG(!train || (sums && counts_dev), "aesr_bn_finalize: train mode needs sums and counts");
+    AESR_CHECK_ARG(train || (running_mean && running_var), "aesr_bn_finalize: eval mode needs running stats");
+    return aesr_launch_bn_finalize(sums, counts_dev, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, mean,
+                                   invstd, scale, shift, C, G, momentum, eps, train, update_running && running_mean && running_var,
+                                   (hipStream_t)stream);
+}
+
+static void bn_out_dims(int H, int W, int mode, int* Ho, int* Wo) {
+    if (mode == AESR_BN_POOL) { *Ho = H / 2; *Wo = W / 2; }
+    else if (mode == AESR_BN_UP) { *Ho = 2 * H; *Wo = 2 * W; }
+    else { *Ho = H; *Wo = W; }
+}
+
+int aesr_bn_apply(const float* y, const float* scale, const float* shift, float* out, int N, int H, int W, int C, int mode,
+                  int G, const int* nstart_host, void* stream) {
+    BnApplyArgs a;
+    AESR_CHECK_ARG(y && scale && shift && out && fill_groups(&a.gr, G, nstart_host), "aesr_bn_apply: bad arguments");
+    a.y = y; a.scale = scale; a.shift = shift; a.out = out; a.N = N; a.H = H; a.W = W; a.C = C; a.mode = mode;
+    bn_out_dims(H, W, mode, &a.Ho, &a.Wo);
+    AESR_CHECK_ARG(a.Ho > 0 && a.Wo > 0, "aesr_bn_apply: empty output");
+    return aesr_launch_bn_apply(a, (hipStream_t)stream);
+}
+
+int aesr_bn_bwd_reduce(const float* gout, const float* y, const float* mean, const float* invstd, float* partial, double* sums,
+                       int N, int H, int W, int C, int mode, int G, const int* nstart_host, void* stream) {
+    BnBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    AESR_CHECK_ARG(gout && y && mean && invstd && partial && sums && fill_groups(&a.gr, G, nstart_host), "aesr_bn_bwd_reduce: bad arguments");
+    a.gout = gout; a.y = y; a.mean = mean; a.invstd = invstd; a.partial = partial;
+    a.N = N; a.H = H; a.W = W; a.C = C; a.mode = mode;
+    bn_out_dims(H, W, mode, &a.Ho, &a.Wo);
+    if (int e = aesr_launch_bn_bwd_reduce(a, AESR_BN_NWG, (hipStream_t)stream)) return e;
+    return aesr_launch_bn_reduce(partial, sums, AESR_BN_NWG, C, G, (hipStream_t)stream);
+}
+
+int aesr_bn_bwd_apply(const float* gout, const float* y, const float* mean, const float* invstd, const float* scale,
+                      const double* sums, const double* counts_dev, float* coef, float* dgamma, float* dbeta, float* dpre, int N,
+                      int H, int W, int C, int mode, int act, float slope, int G, const int* nstart_host, void* stream) {
+    BnBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    AESR_CHECK_ARG(gout && y && mean && invstd && scale && sums && counts_dev && coef && dgamma && dbeta && dpre &&
+                       fill_groups(&a.gr, G, nstart_host), "aesr_bn_bwd_apply: bad arguments");
+    if (int e = aesr_launch_bn_bwd_finalize(sums, counts_dev, coef, dgamma, dbeta, C, G, (hipStream_t)stream)) return e;
+    a.gout = gout; a.y = y; a.mean = mean; a.invstd = invstd; a.scale = scale; a.coef = coef; a.dpre = dpre;
+    a.N = N; a.H = H; a.W = W; a.C = C; a.mode = mode; a.act = act; a.slope = slope;
+    bn_out_dims(H, W, mode, &a.Ho, &a.Wo);
+    return aesr_launch_bn_bwd_apply(a, (hipStream_t)stream);
+}
+
+int aesr_lerp_fwd(const float* z, const float* a_from, const float* a_to, float* zmix, int B, size_t per, void* stream) {
+    AESR_CHECK_ARG(z && a_from && a_to && zmix && B > 0 && per % 4 == 0, "aesr_lerp_fwd: bad arguments (per %% 4 == 0)");
+    return aesr_launch_lerp_fwd(z, a_from, a_to, zmix, B, per, (hipStream_t)stream);
+}
+
+int aesr_lerp_bwd(const float* dzmix, const float* a_from, const float* a_to, float* dz, int B, size_t per, void* stream) {
+    AESR_CHECK_ARG(dzmix && a_from && a_to && dz && B > 0 && per % 4 == 0, "aesr_lerp_bwd: bad arguments (per %% 4 == 0)");
+    return aesr_launch_lerp_bwd(dzmix, a_from, a_to, dz, B, per, (hipStream_t)stream);
+}
+
+int aesr_mse_fwd(const float* a, const float* b, double* partial, float* loss, size_t n, void* stream) {
+    AESR_CHECK_ARG(a && b && partial && loss && n > 0, "aesr_mse_fwd: bad arguments");
+    return aesr_launch_mse_fwd(a, b, partial, AESR_MSE_NPART, loss, n, (hipStream_t)stream);
+}
+
+int aesr_mse_bwd(const float* a, const float* b, const float* gloss, float* da, size_t n, void* stream) {
+    AESR_CHECK_ARG(a && b && gloss && da && n > 0, "aesr_mse_bwd: bad arguments");
+    return aesr_launch_mse_bwd(a, b, gloss, da, n, (hipStream_t)stream);
+}
+
+int aesr_act_bwd(const float* dout, const float* y, float* dpre, size_t n, int act, float slope, void* stream) {
+    AESR_CHECK_ARG(dout && y && dpre && n > 0, "aesr_act_bwd: bad arguments");
+    return aesr_launch_act_bwd(dout, y, dpre, n, act, slope, (hipStream_t)stream);
+}
+
+int aesr_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* state, size_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, void* stream) {
+    AESR_CHECK_ARG(p && g && exp_avg && exp_avg_sq && state && n > 0, "aesr_adam_step: bad arguments");
+    return aesr_launch_adam(p, g, exp_avg, exp_avg_sq, state, n, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream);
+}
+
+}  // extern "C"

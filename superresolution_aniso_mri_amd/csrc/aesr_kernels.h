@@ -1,0 +1,82 @@
+// Argument structs + host launchers of the aesr HIP kernels (shared by the kernel translation units and
+// the C-ABI layer aesr_api.hip).
+#pragma once
+#include "aesr_common.h"
+
+struct IgemmArgs {
+    const float* in; const float* wpk; const float* bias; const float* ysave; float* out;
+    int N, H, W, Cin, CinP, Cout, CoutP, Ho, Wo, pad;
+    int TI, TH, TW, tiles_y, tiles_x;
+    int act, mask_act;
+    float slope;
+};
+int aesr_launch_conv_igemm(const IgemmArgs& a, int KS, int NB, int MBW, hipStream_t st);
+int aesr_launch_pack_weights(const float* w, float* p, int Cout, int Cin, int KS, int KinP, int NoutP, int transpose, hipStream_t st);
+
+struct WgradArgs {
+    const float* x; const float* dy; float* slab;
+    int N, H, W, Cin, CinP, Cout, CoutP, Ho, Wo, pad;
+    int TH, TW, tiles_y, tiles_x, ntiles;
+    int S;
+};
+int aesr_launch_conv_wgrad(const WgradArgs& a, int KS, int variant, hipStream_t st);
+int aesr_launch_wgrad_reduce(const float* slab, float* dw, float* db, int nslab, int KS, int Cin, int CinP, int Cout, int CoutP, hipStream_t st);
+
+struct SmallArgs {
+    const float* in; const float* w; const float* bias; const float* ysave; float* out;
+    int N, H, W, Cin, Cout, Ho, Wo, KS, pad;
+    int act, mask_act;
+    float slope;
+    int transpose, bcast;
+    float ca[4], cb[4];
+};
+struct SmallDgradArgs {
+    const float* dy; const float* w; float* dx;
+    int N, H, W, Cin, Cout, Ho, Wo, KS, pad, bcast;
+    float ca[4];
+};
+struct SmallWgradArgs {
+    const float* in; const float* dout; float* partial;
+    int N, H, W, Cin, Cout, Ho, Wo, pad;
+};
+struct Cout1WgradArgs {
+    const float* x; const float* dy; float* partial;
+    int N, H, W, Cin, TH, TW, tiles_y, tiles_x, ntiles;
+};
+int aesr_launch_smallcin_fwd(const SmallArgs& a, hipStream_t st);
+int aesr_launch_smallcin_dgrad(const SmallDgradArgs& a, hipStream_t st);
+int aesr_launch_sum_partials(const float* partial, int np, int n, float* out0, int n0, float* out1, hipStream_t st);
+int aesr_launch_smallcin_wgrad(const SmallWgradArgs& a, int nwg, hipStream_t st);
+int aesr_launch_cout1_wgrad(const Cout1WgradArgs& a, int nwg, hipStream_t st);
+
+struct BnGroups { int G; int nstart[5]; };
+struct BnApplyArgs {
+    const float* y; const float* scale; const float* shift; float* out;
+    int N, H, W, C, Ho, Wo, mode;
+    BnGroups gr;
+};
+struct BnBwdArgs {
+    const float* gout; const float* y; const float* mean; const float* invstd; const float* scale; const float* coef;
+    float* partial; float* dpre;
+    int N, H, W, C, Ho, Wo, mode, act;
+    float slope;
+    BnGroups gr;
+};
+int aesr_launch_bn_stats(const float* y, float* partial, int HW, int C, const BnGroups& gr, int nwg, hipStream_t st);
+int aesr_launch_bn_reduce(const float* partial, double* sums, int nwg, int C, int G, hipStream_t st);
+int aesr_launch_bn_finalize(const double* sums, const double* counts, const float* gamma, const float* beta, float* rm, float* rv,
+                            long long* nbt, float* mean, float* invstd, float* scale, float* shift, int C, int G, float momentum,
+                            float eps, int train, int update_running, hipStream_t st);
+int aesr_launch_bn_apply(const BnApplyArgs& a, hipStream_t st);
+int aesr_launch_bn_bwd_reduce(const BnBwdArgs& a, int nwg, hipStream_t st);
+int aesr_launch_bn_bwd_finalize(const double* sums, const double* counts, float* coef, float* dgamma, float* dbeta, int C, int G, hipStream_t st);
+int aesr_launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t st);
+
+int aesr_launch_lerp_fwd(const float* z, const float* af, const float* at, float* zmix, int B, size_t per, hipStream_t st);
+int aesr_launch_lerp_bwd(const float* dmix, const float* af, const float* at, float* dz, int B, size_t per, hipStream_t st);
+int aesr_launch_mse_fwd(const float* a, const float* b, double* partial, int np, float* out, size_t n, hipStream_t st);
+int aesr_launch_mse_bwd(const float* a, const float* b, const float* g, float* da, size_t n, hipStream_t st);
+int aesr_launch_act_bwd(const float* dout, const float* y, float* dpre, size_t n, int act, float slope, hipStream_t st);
+int aesr_launch_adam(float* p, const float* g, float* m, float* v, float* state, size_t n, float lr, float beta1, float beta2,
+                     float eps, float wd, hipStream_t st);
+

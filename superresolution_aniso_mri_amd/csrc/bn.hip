@@ -1,0 +1,288 @@
+// BatchNorm2d (train + eval) with the following AvgPool2d(2) / nearest Upsample(x2) fused, NHWC, with
+// *statistic groups*: one launch normalises several independent sub-batches (e.g. enc(x[2B]) and
+// enc(slice_between[B]) of kwatsch/cardiac/trainer_ae.py:18,180), each with its own batch statistics,
+// exactly as if the reference had called the network once per sub-batch (running statistics are
+// updated group after group, in order).
+//
+//   stats    : per-channel sum / sum of squares partials  -> bn_reduce -> double [G][2][C]
+//              (under data parallel these sums are all-reduced across ranks = SyncBN)
+//   finalize : mean, biased var -> invstd, scale = gamma*invstd, shift = beta - mean*scale; running stats
+//              with momentum (unbiased var), num_batches_tracked (nn.BatchNorm2d semantics)
+//   apply    : out = scale*pool_or_up(y) + shift          (affine commutes with the 2x2 mean)
+//   backward : reduce sum(g), sum(g*xhat) -> apply dy = scale*(g - s1/M - xhat*s2/M) * act'(y)
+//
+// Replaces nn.BatchNorm2d + nn.AvgPool2d / nn.Upsample of networks/acai_vanilla.py:58-59,90-92.
+#include "aesr_kernels.h"
+
+enum { BN_MODE_NONE = 0, BN_MODE_POOL = 1, BN_MODE_UP = 2 };
+
+
+__device__ __forceinline__ int group_of(const BnGroups& gr, int n) {
+    int g = 0;
+    for (int k = 1; k < gr.G; ++k)
+        if (n >= gr.nstart[k]) g = k;
+    return g;
+}
+
+// ---- forward statistics ---------------------------------------------------------------------------------
+// partial[g][wg][2][C]; grid = (nwg, G)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, float* __restrict__ partial, int HW,
+                                                       int C, BnGroups gr) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [PL][2][C]
+    const int C4 = C >> 2, PL = 256 / C4;
+    const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
+    const int g = blockIdx.y;
+    const size_t p0 = (size_t)gr.nstart[g] * HW, p1 = (size_t)gr.nstart[g + 1] * HW;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (pl < PL) {
+        for (size_t p = p0 + (size_t)blockIdx.x * PL + pl; p < p1; p += (size_t)gridDim.x * PL) {
+            const f32x4 v = *(const f32x4*)(y + p * C + c4 * 4);
+            s += v;
+            q += v * v;
+        }
+        *(f32x4*)(red + (pl * 2 + 0) * C + c4 * 4) = s;
+        *(f32x4*)(red + (pl * 2 + 1) * C + c4 * 4) = q;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * C; o += 256) {
+        float t = 0.f;
+        for (int k = 0; k < PL; ++k) t += red[k * 2 * C + o];
+        partial[((size_t)g * gridDim.x + blockIdx.x) * 2 * C + o] = t;
+    }
+}
+
+// sums[g][2][C] (double) = sum_wg partial[g][wg][2][C]
+__global__ void bn_reduce_kernel(const float* __restrict__ partial, double* __restrict__ sums, int nwg, int C, int G) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= G * 2 * C) return;
+    const int g = o / (2 * C), r = o - g * 2 * C;
+    double s = 0.0;
+    for (int k = 0; k < nwg; ++k) s += (double)partial[((size_t)g * nwg + k) * 2 * C + r];
+    sums[o] = s;
+}
+
+// train: stats from sums/counts (+ running update, group after group); eval: stats from the running buffers
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ counts,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   long long* __restrict__ nbt, float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ scale, float* __restrict__ shift, int C, int G, float momentum,
+                                   float eps, int train, int update_running) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && train && update_running && nbt) *nbt += G;
+    if (c >= C) return;
+    for (int g = 0; g < G; ++g) {
+        float m, iv;
+        if (train) {
+            const double M = counts[g];
+            const double mu = sums[(g * 2 + 0) * C + c] / M;
+            double var = sums[(g * 2 + 1) * C + c] / M - mu * mu;
+            if (var < 0.0) var = 0.0;
+            m = (float)mu;
+            iv = (float)(1.0 / sqrt(var + (double)eps));
+            if (update_running) {
+                const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            }
+        } else {
+            m = running_mean[c];
+            iv = 1.f / sqrtf(running_var[c] + eps);
+        }
+        mean[g * C + c] = m;
+        invstd[g * C + c] = iv;
+        const float sc = gamma[c] * iv;
+        scale[g * C + c] = sc;
+        shift[g * C + c] = beta[c] - m * sc;
+    }
+}
+
+// ---- forward apply (+pool / +upsample) ----------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
+    const int C4 = a.C >> 2;
+    const size_t total = (size_t)a.N * a.Ho * a.Wo * C4;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c4 = idx % C4;
+        size_t pix = idx / C4;
+        const int x = pix % a.Wo;
+        pix /= a.Wo;
+        const int yy = pix % a.Ho;
+        const int n = pix / a.Ho;
+        const int g = group_of(a.gr, n);
+        const f32x4 sc = *(const f32x4*)(a.scale + g * a.C + c4 * 4);
+        const f32x4 sh = *(const f32x4*)(a.shift + g * a.C + c4 * 4);
+        f32x4 v;
+        if (a.mode == BN_MODE_POOL) {
+            const float* b = a.y + (((size_t)n * a.H + 2 * yy) * a.W + 2 * x) * a.C + c4 * 4;
+            const f32x4 v00 = *(const f32x4*)b, v01 = *(const f32x4*)(b + a.C);
+            const f32x4 v10 = *(const f32x4*)(b + (size_t)a.W * a.C), v11 = *(const f32x4*)(b + (size_t)a.W * a.C + a.C);
+            v = ((v00 + v01) + (v10 + v11)) * 0.25f;
+        } else if (a.mode == BN_MODE_UP) {
+            v = *(const f32x4*)(a.y + (((size_t)n * a.H + (yy >> 1)) * a.W + (x >> 1)) * a.C + c4 * 4);
+        } else {
+            v = *(const f32x4*)(a.y + (((size_t)n * a.H + yy) * a.W + x) * a.C + c4 * 4);
+        }
+        *(f32x4*)(a.out + idx * 4) = v * sc + sh;
+    }
+}
+
+// ---- backward --------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ f32x4 bn_gather_g(const BnBwdArgs& a, int n, int yy, int x, int c4) {
+    // gradient w.r.t. the BN output at full-resolution BN pixel (yy, x)
+    if (a.mode == BN_MODE_POOL) {
+        const int py = yy >> 1, px = x >> 1;
+        if (py >= a.Ho || px >= a.Wo) return (f32x4){0.f, 0.f, 0.f, 0.f};
+        return *(const f32x4*)(a.gout + (((size_t)n * a.Ho + py) * a.Wo + px) * a.C + c4 * 4) * 0.25f;
+    } else if (a.mode == BN_MODE_UP) {
+        const float* b = a.gout + (((size_t)n * a.Ho + 2 * yy) * a.Wo + 2 * x) * a.C + c4 * 4;
+        return (*(const f32x4*)b + *(const f32x4*)(b + a.C)) +
+               (*(const f32x4*)(b + (size_t)a.Wo * a.C) + *(const f32x4*)(b + (size_t)a.Wo * a.C + a.C));
+    }
+    return *(const f32x4*)(a.gout + (((size_t)n * a.H + yy) * a.W + x) * a.C + c4 * 4);
+}
+
+// grid = (nwg, G)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int C4 = a.C >> 2, PL = 256 / C4;
+    const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
+    const int g = blockIdx.y;
+    const int HW = a.H * a.W;
+    const size_t p0 = (size_t)a.gr.nstart[g] * HW, p1 = (size_t)a.gr.nstart[g + 1] * HW;
+    const f32x4 mu = *(const f32x4*)(a.mean + g * a.C + c4 * 4);
+    const f32x4 iv = *(const f32x4*)(a.invstd + g * a.C + c4 * 4);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (pl < PL) {
+        for (size_t p = p0 + (size_t)blockIdx.x * PL + pl; p < p1; p += (size_t)gridDim.x * PL) {
+            const int n = p / HW;
+            const int rem = p - (size_t)n * HW;
+            const int yy = rem / a.W, x = rem - yy * a.W;
+            const f32x4 gg = bn_gather_g(a, n, yy, x, c4);
+            const f32x4 xh = (*(const f32x4*)(a.y + p * a.C + c4 * 4) - mu) * iv;
+            s1 += gg;
+            s2 += gg * xh;
+        }
+        *(f32x4*)(red + (pl * 2 + 0) * a.C + c4 * 4) = s1;
+        *(f32x4*)(red + (pl * 2 + 1) * a.C + c4 * 4) = s2;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * a.C; o += 256) {
+        float t = 0.f;
+        for (int k = 0; k < PL; ++k) t += red[k * 2 * a.C + o];
+        a.partial[((size_t)g * gridDim.x + blockIdx.x) * 2 * a.C + o] = t;
+    }
+}
+
+// coef[g][2][C] = sums/M ; dgamma[c] = sum_g s2 ; dbeta[c] = sum_g s1
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ counts,
+                                       float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       int C, int G) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double dg = 0.0, db = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const double s1 = sums[(g * 2 + 0) * C + c], s2 = sums[(g * 2 + 1) * C + c];
+        coef[(g * 2 + 0) * C + c] = (float)(s1 / counts[g]);
+        coef[(g * 2 + 1) * C + c] = (float)(s2 / counts[g]);
+        db += s1;
+        dg += s2;
+    }
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)db;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+    const int C4 = a.C >> 2;
+    const size_t total = (size_t)a.N * a.H * a.W * C4;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c4 = idx % C4;
+        size_t pix = idx / C4;
+        const int x = pix % a.W;
+        pix /= a.W;
+        const int yy = pix % a.H;
+        const int n = pix / a.H;
+        const int g = group_of(a.gr, n);
+        const f32x4 mu = *(const f32x4*)(a.mean + g * a.C + c4 * 4);
+        const f32x4 iv = *(const f32x4*)(a.invstd + g * a.C + c4 * 4);
+        const f32x4 sc = *(const f32x4*)(a.scale + g * a.C + c4 * 4);
+        const f32x4 k1 = *(const f32x4*)(a.coef + (g * 2 + 0) * a.C + c4 * 4);
+        const f32x4 k2 = *(const f32x4*)(a.coef + (g * 2 + 1) * a.C + c4 * 4);
+        const f32x4 yv = *(const f32x4*)(a.y + idx * 4);
+        const f32x4 gg = bn_gather_g(a, n, yy, x, c4);
+        const f32x4 xh = (yv - mu) * iv;
+        f32x4 d = sc * (gg - k1 - xh * k2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] *= act_grad_from_output(yv[e], a.act, a.slope);
+        *(f32x4*)(a.dpre + idx * 4) = d;
+    }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------
+static int bn_check_c(int C, const char* who) {
+    if (C % 4 != 0 || 256 % (C / 4) != 0 || C > 1024) {
+        aesr_set_error("%s: unsupported channel count %d (need C/4 | 256)", who, C);
+        return AESR_ERR_ARG;
+    }
+    return AESR_OK;
+}
+
+int aesr_launch_bn_stats(const float* y, float* partial, int HW, int C, const BnGroups& gr, int nwg, hipStream_t st) {
+    if (int e = bn_check_c(C, "bn_stats")) return e;
+    const int PL = 256 / (C / 4);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nwg, gr.G), dim3(256), (size_t)PL * 2 * C * sizeof(float), st, y, partial, HW, C, gr);
+    AESR_LAUNCH_CHECK("bn_stats");
+    return AESR_OK;
+}
+
+int aesr_launch_bn_reduce(const float* partial, double* sums, int nwg, int C, int G, hipStream_t st) {
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3(ceil_div(G * 2 * C, 256)), dim3(256), 0, st, partial, sums, nwg, C, G);
+    AESR_LAUNCH_CHECK("bn_reduce");
+    return AESR_OK;
+}
+
+int aesr_launch_bn_finalize(const double* sums, const double* counts, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, long long* nbt, float* mean, float* invstd,
+                            float* scale, float* shift, int C, int G, float momentum, float eps, int train,
+                            int update_running, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, sums, counts, gamma, beta, running_mean,
+                       running_var, nbt, mean, invstd, scale, shift, C, G, momentum, eps, train, update_running);
+    AESR_LAUNCH_CHECK("bn_finalize");
+    return AESR_OK;
+}
+
+int aesr_launch_bn_apply(const BnApplyArgs& a, hipStream_t st) {
+    if (int e = bn_check_c(a.C, "bn_apply")) return e;
+    const size_t total = (size_t)a.N * a.Ho * a.Wo * (a.C / 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, st, a);
+    AESR_LAUNCH_CHECK("bn_apply");
+    return AESR_OK;
+}
+
+int aesr_launch_bn_bwd_reduce(const BnBwdArgs& a, int nwg, hipStream_t st) {
+    if (int e = bn_check_c(a.C, "bn_bwd_reduce")) return e;
+    const int PL = 256 / (a.C / 4);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nwg, a.gr.G), dim3(256), (size_t)PL * 2 * a.C * sizeof(float), st, a);
+    AESR_LAUNCH_CHECK("bn_bwd_reduce");
+    return AESR_OK;
+}
+
+int aesr_launch_bn_bwd_finalize(const double* sums, const double* counts, float* coef, float* dgamma, float* dbeta, int C,
+                                int G, hipStream_t st) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, sums, counts, coef, dgamma, dbeta, C, G);
+    AESR_LAUNCH_CHECK("bn_bwd_finalize");
+    return AESR_OK;
+}
+
+int aesr_launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t st) {
+    if (int e = bn_check_c(a.C, "bn_bwd_apply")) return e;
+    const size_t total = (size_t)a.N * a.H * a.W * (a.C / 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, a);
+    AESR_LAUNCH_CHECK("bn_bwd_apply");
+    return AESR_OK;
+}

@@ -1,0 +1,346 @@
+"""Host-side executor: runs a reference-shaped ``nn.Sequential`` (conv / LeakyReLU / BatchNorm / AvgPool /
+Upsample / Sigmoid stacks of networks/acai_vanilla.py:49-102) on the HIP kernels of libaesr_hip.so.
+
+The ``nn.Sequential`` only *holds* the parameters (so state_dict keys, parameter order and the reference's
+init are untouched); none of its modules' ``forward`` is ever called.  The stack is compiled
+into fused steps
+
+    conv (+LeakyReLU | ReLU | Sigmoid epilogue)        -> aesr_conv2d_fwd / aesr_conv2d_smallcin_fwd
+    BatchNorm (+AvgPool2d(2) | nearest Upsample x2)    -> aesr_bn_stats / finalize / apply
+
+and a hand-written backward walks them in reverse (dgrad with the previous activation's derivative fused,
+MFMA split-K wgrad, BatchNorm backward fused with the LeakyReLU derivative).  Activations are NHWC fp32.
+A pass may carry several *statistic groups* (sub-batches with independent BatchNorm batch statistics); only a
+leading prefix of the batch needs gradients.
+"""
+from ctypes import c_float
+
+import torch
+import torch.nn as nn
+
+from . import _hip
+from ._hip import lib, ptr, stream, check
+
+LRELU_SLOPE = 0.01
+
+
+def _act_of(m):
+    if isinstance(m, nn.LeakyReLU):
+        return _hip.ACT_LRELU, float(m.negative_slope)
+    if isinstance(m, nn.ReLU):
+        return _hip.ACT_RELU, 0.0
+    if isinstance(m, nn.Sigmoid):
+        return _hip.ACT_SIGMOID, 0.0
+    return None
+
+
+class ConvStep:
+    kind = "conv"
+
+    def __init__(self, mod, act, slope):
+        ks, st, pd = mod.kernel_size, mod.stride, mod.padding
+        if ks[0] != ks[1] or st != (1, 1) or pd[0] != pd[1] or ks[0] not in (1, 3) or mod.dilation != (1, 1) or mod.groups != 1:
+            raise NotImplementedError("HIP conv path supports square 1x1/3x3 stride-1 convolutions, got %r" % (mod,))
+        self.mod, self.act, self.slope = mod, act, slope
+        self.cin, self.cout, self.ks, self.pad = mod.in_channels, mod.out_channels, ks[0], pd[0]
+        self.packed = None      # forward operand
+        self.packed_t = None    # data-gradient operand
+        self.packed_epoch = -1
+
+    @property
+    def mfma_fwd(self):
+        return self.cin % 4 == 0
+
+    def out_hw(self, h, w):
+        return h + 2 * self.pad - self.ks + 1, w + 2 * self.pad - self.ks + 1
+
+
+class BnStep:
+    kind = "bn"
+
+    def __init__(self, mod, mode):
+        self.mod, self.mode, self.c = mod, mode, mod.num_features
+
+    def out_hw(self, h, w):
+        if self.mode == _hip.BN_POOL:
+            return h // 2, w // 2
+        if self.mode == _hip.BN_UP:
+            return 2 * h, 2 * w
+        return h, w
+
+
+def compile_steps(seq):
+    mods = list(seq)
+    steps, i = [], 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Conv2d):
+            act, slope = _hip.ACT_NONE, 0.0
+            if i + 1 < len(mods) and _act_of(mods[i + 1]) is not None:
+                act, slope = _act_of(mods[i + 1])
+                i += 1
+            steps.append(ConvStep(m, act, slope))
+        elif isinstance(m, nn.BatchNorm2d):
+            mode = _hip.BN_NONE
+            if i + 1 < len(mods) and isinstance(mods[i + 1], nn.AvgPool2d):
+                mode = _hip.BN_POOL
+                i += 1
+            elif i + 1 < len(mods) and isinstance(mods[i + 1], nn.Upsample):
+                if mods[i + 1].mode != "nearest":
+                    raise NotImplementedError("only nearest Upsample is fused (got %s)" % mods[i + 1].mode)
+                mode = _hip.BN_UP
+                i += 1
+            steps.append(BnStep(m, mode))
+        else:
+            raise NotImplementedError("no HIP lowering for %r at position %d (use_batchnorm=False stacks are not "
+                                      "covered)" % (m, i))
+        i += 1
+    for k, s in enumerate(steps):
+        if s.kind == "bn" and (k == 0 or steps[k - 1].kind != "conv"):
+            raise NotImplementedError("BatchNorm must follow a convolution")
+    return steps
+
+
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+class SequentialRunner:
+    """Executes one compiled stack.  ``weights_epoch`` must be bumped whenever parameters change in place."""
+
+    def __init__(self, seq):
+        self.seq = seq
+        self.steps = compile_steps(seq)
+        self.weights_epoch = 0
+        self.params = [p for p in seq.parameters()]
+
+    def mark_weights_dirty(self):
+        self.weights_epoch += 1
+
+    # ---- weight packing ------------------------------------------------------------------------------------
+    def _ensure_packed(self, s):
+        w = s.mod.weight
+        epoch = (self.weights_epoch, w._version, w.data_ptr())
+        if s.packed_epoch == epoch:
+            return
+        _hip.require_gpu_tensor(w, "conv weight")
+        if s.cin % 4 == 0:
+            n = lib.aesr_conv2d_packed_floats(s.cout, s.cin, s.ks, 0)
+            if s.packed is None or s.packed.numel() != n:
+                s.packed = _empty((n,), w)
+            check(lib.aesr_conv2d_pack(ptr(w), ptr(s.packed), s.cout, s.cin, s.ks, 0, stream()), "aesr_conv2d_pack")
+        if s.cout % 4 == 0:
+            n = lib.aesr_conv2d_packed_floats(s.cout, s.cin, s.ks, 1)
+            if s.packed_t is None or s.packed_t.numel() != n:
+                s.packed_t = _empty((n,), w)
+            check(lib.aesr_conv2d_pack(ptr(w), ptr(s.packed_t), s.cout, s.cin, s.ks, 1, stream()), "aesr_conv2d_pack")
+        s.packed_epoch = epoch
+
+    # ---- forward ---------------------------------------------------------------------------------------------
+    def forward(self, x, nstart, train, save):
+        """x: NHWC fp32 [N,H,W,C]; nstart: group boundaries (len G+1).  Returns (out, saved)."""
+        _hip.require_gpu_tensor(x, "input")
+        N, H, W, C = x.shape
+        G = len(nstart) - 1
+        saved = []
+        cur = x
+        for s in self.steps:
+            if s.kind == "conv":
+                if C != s.cin:
+                    raise RuntimeError("channel mismatch: tensor has %d channels, conv expects %d" % (C, s.cin))
+                self._ensure_packed(s)
+                Ho, Wo = s.out_hw(H, W)
+                out = _empty((N, Ho, Wo, s.cout), x)
+                bias = s.mod.bias
+                if s.mfma_fwd:
+                    check(lib.aesr_conv2d_fwd(ptr(cur), ptr(s.packed), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, s.ks,
+                                              s.pad, s.act, s.slope, stream()), "aesr_conv2d_fwd")
+                elif s.cin <= 4:
+                    check(lib.aesr_conv2d_smallcin_fwd(ptr(cur), ptr(s.mod.weight), ptr(bias), None, ptr(out), N, H, W,
+                                                       s.cin, s.cout, s.ks, s.pad, s.act, _hip.ACT_NONE, s.slope, 0, 0,
+                                                       None, None, stream()), "aesr_conv2d_smallcin_fwd")
+                else:
+                    raise NotImplementedError("conv with Cin=%d (neither <=4 nor a multiple of 4)" % s.cin)
+                if save:
+                    saved.append((cur, out))
+                cur, H, W, C = out, Ho, Wo, s.cout
+            else:
+                bn = s.mod
+                st = self._bn_forward_stats(bn, cur, N, H, W, C, nstart, train)
+                Ho, Wo = s.out_hw(H, W)
+                out = _empty((N, Ho, Wo, C), x)
+                check(lib.aesr_bn_apply(ptr(cur), ptr(st["scale"]), ptr(st["shift"]), ptr(out), N, H, W, C, s.mode, G,
+                                        _hip.int_array(nstart), stream()), "aesr_bn_apply")
+                if save:
+                    saved.append((cur, st))
+                cur, H, W = out, Ho, Wo
+        return cur, saved
+
+    sync_bn = None   # optional callable(sums[G,2,C] double, counts[G] double) -> all-reduced in place (data parallel)
+
+    def _bn_forward_stats(self, bn, y, N, H, W, C, nstart, train):
+        G = len(nstart) - 1
+        dev = y.device
+        st = {k: torch.empty((G, C), device=dev, dtype=torch.float32) for k in ("mean", "invstd", "scale", "shift")}
+        use_batch = train or bn.running_mean is None
+        sums = counts = None
+        if use_batch:
+            partial = torch.empty((G * _hip.BN_NWG * 2 * C,), device=dev, dtype=torch.float32)
+            sums = torch.empty((G, 2, C), device=dev, dtype=torch.float64)
+            check(lib.aesr_bn_stats(ptr(y), ptr(partial), ptr(sums), H * W, C, G, _hip.int_array(nstart), stream()),
+                  "aesr_bn_stats")
+            counts = torch.tensor([float((nstart[g + 1] - nstart[g]) * H * W) for g in range(G)], dtype=torch.float64,
+                                  device=dev)
+            if self.sync_bn is not None:
+                self.sync_bn(sums, counts)
+        st["counts"] = counts
+        momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+        update = bool(train and bn.track_running_stats and bn.running_mean is not None)
+        check(lib.aesr_bn_finalize(ptr(sums), ptr(counts), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+                                   ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(st["mean"]), ptr(st["invstd"]),
+                                   ptr(st["scale"]), ptr(st["shift"]), C, G, momentum, float(bn.eps), int(use_batch),
+                                   int(update), stream()), "aesr_bn_finalize")
+        return st
+
+    # ---- backward --------------------------------------------------------------------------------------------
+    def backward(self, gout, saved, nstart, ngrad, need_input_grad):
+        """gout: NHWC gradient of the pass output (all N images; only the first ``ngrad`` are used).
+        Returns (dx or None, {param: grad})."""
+        steps = self.steps
+        grads = {}
+        G = 0
+        while G < len(nstart) - 1 and nstart[G + 1] <= ngrad:
+            G += 1
+        if G == 0 or nstart[G] != ngrad:
+            raise RuntimeError("the images that need gradients must be whole leading statistic groups")
+        ns = list(nstart[:G + 1])
+        g = gout[:ngrad]
+        if not g.is_contiguous():
+            g = g.contiguous()
+        for k in range(len(steps) - 1, -1, -1):
+            s = steps[k]
+            if s.kind == "conv":
+                xin, yout = saved[k]
+                N, H, W, _ = xin.shape
+                N = ngrad
+                Ho, Wo = s.out_hw(H, W)
+                if k == len(steps) - 1 and s.act != _hip.ACT_NONE:
+                    dpre = torch.empty_like(g)
+                    check(lib.aesr_act_bwd(ptr(g), ptr(yout), ptr(dpre), g.numel(), s.act, s.slope, stream()), "aesr_act_bwd")
+                    g = dpre
+                # -- weight / bias gradient
+                dw = torch.empty_like(s.mod.weight)
+                db = torch.empty_like(s.mod.bias) if s.mod.bias is not None else None
+                if s.cin % 4 == 0 and s.cout % 4 == 0:
+                    nws = lib.aesr_conv2d_wgrad_workspace_floats(N, H, W, s.cin, s.cout, s.ks, s.pad)
+                    ws = _empty((nws,), g)
+                    check(lib.aesr_conv2d_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout, s.ks,
+                                                s.pad, stream()), "aesr_conv2d_wgrad")
+                elif s.cin <= 4 and s.ks == 1 and db is not None:
+                    ws = _empty((lib.aesr_small_wgrad_workspace_floats(s.cout * (s.cin + 1)),), g)
+                    check(lib.aesr_conv2d_smallcin_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout,
+                                                         s.pad, stream()), "aesr_conv2d_smallcin_wgrad")
+                elif s.cout == 1 and s.ks == 3 and s.pad == 1 and db is not None:
+                    ws = _empty((lib.aesr_small_wgrad_workspace_floats(s.cin * 9 + 1),), g)
+                    check(lib.aesr_conv2d_cout1_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, stream()),
+                          "aesr_conv2d_cout1_wgrad")
+                else:
+                    raise NotImplementedError("no wgrad kernel for conv %d->%d k%d" % (s.cin, s.cout, s.ks))
+                grads[s.mod.weight] = dw
+                if db is not None:
+                    grads[s.mod.bias] = db
+                # -- data gradient (fused with the derivative of the activation that produced our input)
+                if k == 0 and not need_input_grad:
+                    g = None
+                    break
+                mask, mask_act, mslope = None, _hip.ACT_NONE, 0.0
+                if k > 0 and steps[k - 1].kind == "conv":
+                    mask, mask_act, mslope = saved[k - 1][1], steps[k - 1].act, steps[k - 1].slope
+                    if mask_act == _hip.ACT_NONE:
+                        mask = None
+                dx = _empty((N, H, W, s.cin), g)
+                if s.cin <= 4 and mask is None:
+                    check(lib.aesr_conv2d_smallcin_dgrad(ptr(g), ptr(s.mod.weight), ptr(dx), N, H, W, s.cin, s.cout, s.ks,
+                                                         s.pad, 0, None, stream()), "aesr_conv2d_smallcin_dgrad")
+                elif s.cout % 4 == 0:
+                    check(lib.aesr_conv2d_dgrad(ptr(g), ptr(s.packed_t), ptr(mask), ptr(dx), N, H, W, s.cin, s.cout, s.ks,
+                                                s.pad, mask_act, mslope, stream()), "aesr_conv2d_dgrad")
+                elif s.cout <= 4:
+                    # data gradient of a tiny-Cout conv == small-Cin forward conv with the flipped/transposed filter
+                    check(lib.aesr_conv2d_smallcin_fwd(ptr(g), ptr(s.mod.weight), None, ptr(mask), ptr(dx), N, Ho, Wo, s.cout,
+                                                       s.cin, s.ks, s.ks - 1 - s.pad, _hip.ACT_NONE, mask_act, mslope, 1, 0,
+                                                       None, None, stream()), "aesr_conv2d_smallcin_fwd(dgrad)")
+                else:
+                    raise NotImplementedError("no dgrad kernel for conv %d->%d" % (s.cin, s.cout))
+                g = dx
+            else:
+                y, st = saved[k]
+                prev = steps[k - 1]
+                _, H, W, C = y.shape
+                N = ngrad
+                dev = y.device
+                partial = torch.empty((G * _hip.BN_NWG * 2 * C,), device=dev, dtype=torch.float32)
+                sums = torch.empty((G, 2, C), device=dev, dtype=torch.float64)
+                nsa = _hip.int_array(ns)
+                check(lib.aesr_bn_bwd_reduce(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(partial), ptr(sums), N, H,
+                                             W, C, s.mode, G, nsa, stream()), "aesr_bn_bwd_reduce")
+                if self.sync_bn is not None:
+                    self.sync_bn(sums, None)
+                coef = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
+                dgamma, dbeta = torch.empty_like(s.mod.weight), torch.empty_like(s.mod.bias)
+                dpre = _empty((N, H, W, C), y)
+                check(lib.aesr_bn_bwd_apply(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(sums),
+                                            ptr(st["counts"]), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dpre), N, H, W, C,
+                                            s.mode, prev.act, prev.slope, G, nsa, stream()), "aesr_bn_bwd_apply")
+                grads[s.mod.weight], grads[s.mod.bias] = dgamma, dbeta
+                g = dpre
+        return g, grads
+
+
+class _PassFn(torch.autograd.Function):
+    """One pass of a compiled stack as a single autograd node (NHWC in, NHWC out)."""
+
+    @staticmethod
+    def forward(ctx, runner, nstart, ngrad, train, x, *params):
+        need = any(ctx.needs_input_grad) and ngrad > 0       # grad mode is off inside forward(); this is the truth
+        out, saved = runner.forward(x.detach(), nstart, train, save=need)
+        ctx.runner, ctx.nstart, ctx.ngrad, ctx.saved = runner, nstart, ngrad, saved
+        ctx.x_needs_grad = x.requires_grad
+        ctx.nparams = len(params)
+        ctx.N = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        runner = ctx.runner
+        if not gout.is_contiguous():
+            gout = gout.contiguous()
+        dx, grads = runner.backward(gout, ctx.saved, ctx.nstart, ctx.ngrad, ctx.x_needs_grad)
+        ctx.saved = None
+        if dx is not None and ctx.ngrad < ctx.N:
+            full = torch.zeros((ctx.N,) + tuple(dx.shape[1:]), device=dx.device, dtype=dx.dtype)
+            full[:ctx.ngrad] = dx
+            dx = full
+        return (None, None, None, None, dx) + tuple(grads.get(p) for p in runner.params)
+
+
+def run_pass(runner, x_nhwc, nstart=None, ngrad=None, train=True):
+    n = x_nhwc.shape[0]
+    nstart = tuple(nstart) if nstart is not None else (0, n)
+    ngrad = n if ngrad is None else int(ngrad)
+    return _PassFn.apply(runner, nstart, ngrad, bool(train), x_nhwc, *runner.params)
+
+
+# ---- layout helpers (zero-copy where the memory already is NHWC) -----------------------------------------------
+def to_nhwc(t):
+    """Logical NCHW tensor -> contiguous [N,H,W,C] view/copy."""
+    if t.dim() != 4:
+        raise ValueError("expected a 4-D NCHW tensor, got shape %s" % (tuple(t.shape),))
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.permute(0, 2, 3, 1).contiguous()       # no-op copy when t is channels_last or C == 1
+
+
+def to_nchw_view(t_nhwc):
+    """[N,H,W,C] -> logical NCHW view (channels_last strides, no copy)."""
+    return t_nhwc.permute(0, 3, 1, 2)

@@ -1,0 +1,176 @@
+"""MI355X-native ``VanillaACAI`` auto-encoder: same constructor arguments, state_dict keys and initialisation as
+the reference's networks/acai_vanilla.py:39-138, but every forward/backward runs on the HIP kernels of
+libaesr_hip.so (no ATen convolution / batch-norm is ever dispatched).
+
+The ``enc`` / ``dec`` attributes are ``nn.Sequential`` containers of stock torch modules used purely as parameter
+holders (checkpoint compatibility); ``HipAE`` executes them through
+``superresolution_aniso_mri_amd.engine``.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import engine
+
+activation = nn.LeakyReLU
+
+
+def Initializer(layers, slope=0.2):
+    """Reference init (networks/acai_vanilla.py:39-46): N(0, 1/sqrt((1+slope^2)*prod(w.shape[:-1]))) for every
+    layer that has a ``weight`` (BatchNorm gamma included), zero biases."""
+    for layer in layers:
+        if hasattr(layer, "weight"):
+            w = layer.weight.data
+            w.normal_(std=1 / np.sqrt((1 + slope ** 2) * np.prod(w.shape[:-1])))
+        if hasattr(layer, "bias"):
+            layer.bias.data.zero_()
+
+
+def _block(kp, k, use_batchnorm):
+    layers = [nn.Conv2d(kp, k, 3, padding=1), activation(), nn.Conv2d(k, k, 3, padding=1), activation()]
+    if use_batchnorm:
+        layers.append(nn.BatchNorm2d(k))
+    return layers
+
+
+def Encoder(scales, depth, latent, colors, n_res_block=None, use_batchnorm=False, stem=None, downsample="avgpool"):
+    """networks/acai_vanilla.py:49-72 (``stem``/``downsample`` cover the LargerAE / strided variants)."""
+    if n_res_block is not None:
+        raise NotImplementedError("n_res_block is not used by any ae_combined configuration")
+    stem = depth if stem is None else stem
+    layers = [nn.Conv2d(colors, stem, 1, padding=1)]
+    kp = stem
+    for scale in range(scales):
+        k = depth << scale
+        layers += _block(kp, k, use_batchnorm)
+        layers.append(nn.AvgPool2d(2) if downsample == "avgpool" else nn.Conv2d(k, k, 2, stride=2, padding=0))
+        kp = k
+    k = depth << scales
+    layers += [nn.Conv2d(kp, k, 3, padding=1), activation(), nn.Conv2d(k, latent, 3, padding=1)]
+    Initializer(layers)
+    return nn.Sequential(*layers)
+
+
+def Decoder(scales, depth, latent, colors, n_res_block=None, use_upsample=True, use_batchnorm=False, use_sigmoid=False,
+            stem_1x1=False):
+    """networks/acai_vanilla.py:75-102 (``stem_1x1``: the LargerAE 1x1 conv (+BN) in front)."""
+    if n_res_block is not None or not use_upsample:
+        raise NotImplementedError("ResBlock / ConvTranspose decoders are not part of the ae_combined path")
+    layers, kp = [], latent
+    if stem_1x1:
+        c1 = depth << scales
+        layers += [nn.Conv2d(latent, c1, 1, padding=0), activation()]
+        if use_batchnorm:
+            layers.append(nn.BatchNorm2d(c1))
+        kp = c1
+    for scale in range(scales - 1, -1, -1):
+        k = depth << scale
+        layers += _block(kp, k, use_batchnorm)
+        layers.append(nn.Upsample(scale_factor=2))
+        kp = k
+    layers += [nn.Conv2d(kp, depth, 3, padding=1), activation()]
+    layers.append(nn.Conv2d(depth, colors, 3, padding=1))
+    if use_sigmoid:
+        layers.append(nn.Sigmoid())
+    Initializer(layers)
+    return nn.Sequential(*layers)
+
+
+def num_scales(args):
+    return int(round(math.log(args["width"] // args["latent_width"], 2)))
+
+
+class HipAE(nn.Module):
+    """Common behaviour of the auto-encoder family: encode / decode / forward on the HIP engine."""
+
+    def _fill_defaults(self, args):
+        args.setdefault("n_res_block", None)
+        args.setdefault("use_batchnorm", False)
+        args.setdefault("use_sigmoid", False)
+        args.setdefault("gpu_ids", [0])
+
+    def _runner(self, name):
+        cache = self.__dict__.setdefault("_runners", {})
+        r = cache.get(name)
+        if r is None:
+            r = engine.SequentialRunner(getattr(self, name))
+            cache[name] = r
+        return r
+
+    def mark_weights_dirty(self):
+        for r in self.__dict__.get("_runners", {}).values():
+            r.mark_weights_dirty()
+
+    def set_sync_bn(self, fn):
+        """Data parallel: ``fn(sums, counts)`` all-reduces BatchNorm partial sums across ranks (SyncBN)."""
+        for name in ("enc", "dec"):
+            self._runner(name).sync_bn = fn
+
+    # -- multi-group passes (one launch sequence, independent BatchNorm statistics per sub-batch) ---------
+    def _pass(self, name, tensors, needs_grad=None):
+        if needs_grad is None:
+            needs_grad = [True] * len(tensors)
+        if any(g and not p for p, g in zip(needs_grad[:-1], needs_grad[1:])):
+            raise ValueError("sub-batches that need gradients must come first")
+        xs = [engine.to_nhwc(t) for t in tensors]
+        x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=0)
+        nstart = [0]
+        for t in xs:
+            nstart.append(nstart[-1] + t.shape[0])
+        ngrad = sum(t.shape[0] for t, g in zip(xs, needs_grad) if g)
+        if not self.training:
+            nstart = [0, nstart[-1]]          # eval: running statistics, groups are irrelevant
+            ngrad = nstart[-1] if ngrad > 0 else 0
+        out = engine.run_pass(self._runner(name), x, nstart, ngrad, train=self.training)
+        out = engine.to_nchw_view(out)
+        if len(xs) == 1:
+            return [out]
+        return list(torch.split(out, [t.shape[0] for t in xs], dim=0))
+
+    def encode_multi(self, images, needs_grad=None):
+        return self._pass("enc", images, needs_grad)
+
+    def decode_multi(self, latents, needs_grad=None):
+        return self._pass("dec", latents, needs_grad)
+
+    def encode(self, img):
+        return self._pass("enc", [img])[0]
+
+    def decode(self, z):
+        return self._pass("dec", [z])[0]
+
+    def forward(self, img):
+        return self.decode(self.encode(img))
+
+    def load_state_dict(self, *a, **kw):
+        r = super().load_state_dict(*a, **kw)
+        self.mark_weights_dirty()
+        return r
+
+
+class VanillaACAI(HipAE):
+
+    def __init__(self, args):
+        super().__init__()
+        scales = num_scales(args)
+        self._fill_defaults(args)
+        self.enc = Encoder(scales, args["depth"], args["latent"], args["colors"], n_res_block=args["n_res_block"],
+                           use_batchnorm=args["use_batchnorm"]).to(args["device"])
+        self.dec = Decoder(scales, args["depth"], args["latent"], args["colors"], n_res_block=args["n_res_block"],
+                           use_batchnorm=args["use_batchnorm"], use_sigmoid=args["use_sigmoid"]).to(args["device"])
+
+
+def create_decoder(args):
+    return Decoder(num_scales(args), args["depth"], args["latent"], args["colors"], n_res_block=args["n_res_block"],
+                   use_batchnorm=args["use_batchnorm"], use_sigmoid=args["use_sigmoid"]).to(args["device"])
+
+
+def lerp(start, end, weights):
+    return start + weights * (end - start)
+
+
+def swap_halves(x):
+    a, b = x.split(x.shape[0] // 2)
+    return torch.cat([b, a])

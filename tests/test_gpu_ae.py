@@ -1,0 +1,121 @@
+"""-m gpu: the HIP auto-encoders against the vectors generated from the reference's own modules
+(tests/golden/ae_small_*.npz, ae_acdc_probe.npz) and against the CPU oracle on fresh inputs.
+Stated tolerances (fp32): forward rel-L2 <= 1e-5, gradients rel-L2 <= 1e-4, BN running stats <= 1e-5."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SMALL = dict(width=32, latent_width=8, depth=8, latent=16, colors=1, use_batchnorm=True, use_sigmoid=True, device="cuda")
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _model(cname, args):
+    from superresolution_aniso_mri_amd.networks import acai_vanilla, acai_vanilla_modified
+    cls = {"VanillaACAI": acai_vanilla.VanillaACAI, "LargerAE": acai_vanilla_modified.LargerAE}[cname]
+    return cls(dict(args))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "ae_small_VanillaACAI_*.npz")) +
+                                        glob.glob(os.path.join(GOLDEN, "ae_small_LargerAE_*.npz"))))
+def test_ae_small_vs_reference_vectors(path):
+    rec = dict(np.load(path))
+    cname = os.path.basename(path).split("_")[2]
+    model = _model(cname, SMALL)
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in rec.items() if k.startswith("p0/")})
+    model.train()
+    x = torch.from_numpy(rec["x"]).cuda().requires_grad_(True)
+    z = model.encode(x)
+    out = model.decode(z)
+    assert z.shape == rec["z"].shape and out.shape == rec["out"].shape
+    loss = F.mse_loss(out, torch.from_numpy(rec["tgt"]).cuda()) + 0.1 * (z ** 2).mean()
+    loss.backward()
+    assert rel_l2(z.detach(), rec["z"]) < 1e-5
+    assert rel_l2(out.detach(), rec["out"]) < 1e-5
+    assert abs(loss.item() - float(rec["loss"])) < 1e-5 * abs(float(rec["loss"]))
+    assert rel_l2(x.grad, rec["dx"]) < 1e-4
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+        assert rel_l2(p.grad, rec["grad/" + k]) < 1e-4, k
+    sd = model.state_dict()
+    for k, v in rec.items():
+        if k.startswith("p1/"):
+            if "num_batches" in k:
+                assert int(sd[k[3:]]) == int(v)
+            else:
+                assert rel_l2(sd[k[3:]], v) < 1e-5, k
+    model.eval()
+    with torch.no_grad():
+        out_eval = model(x.detach())
+    assert rel_l2(out_eval, rec["out_eval"]) < 1e-5
+
+
+def test_acdc_full_size_probe():
+    """Full C2/C3 architecture (443 777 params), 160x160: sampled outputs + gradient norms of the reference."""
+    rec = dict(np.load(os.path.join(GOLDEN, "ae_acdc_probe.npz")))
+    from oracle import step_oracle
+    torch.manual_seed(892372)
+    model = _model("VanillaACAI", dict(width=128, latent_width=32, depth=32, latent=128, colors=1, use_batchnorm=True,
+                                        use_sigmoid=True, device="cpu"))
+    init = dict(np.load(os.path.join(GOLDEN, "ae_init_acdc.npz")))
+    for k, p in model.named_parameters():       # RNG-exact reference initialisation
+        assert np.array_equal(p.detach().flatten()[:4].numpy(), init["head/" + k]), k
+    model = model.cuda()
+    model.train()
+    image, _ = step_oracle.synthetic_triplets(1, 160, 160, seed=892372)
+    image = image.cuda()
+    z = model.encode(image)
+    out = model.decode(z)
+    assert tuple(z.shape) == (2, 128, 40, 40) and tuple(out.shape) == (2, 1, 160, 160)
+    loss = F.mse_loss(out, image)
+    loss.backward()
+    assert abs(loss.item() - float(rec["loss"])) < 1e-5 * float(rec["loss"])
+    # logical NCHW indexing of the channels_last views
+    np.testing.assert_allclose(out.detach().cpu().contiguous().flatten()[rec["out_idx"]].numpy(), rec["out_val"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(z.detach().cpu().contiguous().flatten()[rec["z_idx"]].numpy(), rec["z_val"], rtol=1e-4, atol=1e-5)
+    for k, p in model.named_parameters():
+        gn = p.grad.double().norm().item()
+        assert abs(gn - float(rec["gnorm/" + k])) <= 1e-4 * float(rec["gnorm/" + k]) + 1e-9, k
+    for k, b in model.named_buffers():
+        if "running" in k:
+            assert rel_l2(b, rec["bn/" + k]) < 1e-5, k
+
+
+def test_grouped_passes_equal_sequential_passes():
+    """enc([x, between]) with two statistic groups == enc(x) then enc(between) (outputs, running stats, grads)."""
+    from oracle import ae_oracle
+    torch.manual_seed(5)
+    model = _model("VanillaACAI", SMALL)
+    oracle = ae_oracle.OracleAE(SMALL, init=False).load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    x, btw = torch.rand(4, 1, 32, 32), torch.rand(2, 1, 32, 32)
+    model.train()
+    z_x, z_b = model.encode_multi([x.cuda(), btw.cuda()], needs_grad=[True, False])
+    zo_x = oracle.encode(x, train=True)
+    zo_b = oracle.encode(btw, train=True)
+    assert rel_l2(z_x.detach(), zo_x.detach()) < 1e-5 and rel_l2(z_b.detach(), zo_b.detach()) < 1e-5
+    (z_x ** 2).mean().backward()
+    (zo_x ** 2).mean().backward()
+    for k, p in model.named_parameters():
+        if k.startswith("enc"):
+            assert rel_l2(p.grad, oracle.params[k].grad) < 1e-4, k
+    sd = model.state_dict()
+    for k, v in oracle.buffers.items():
+        if k.startswith("enc") and "running" in k:
+            assert rel_l2(sd[k], v) < 1e-5, k
+        if k.startswith("enc") and "num_batches" in k:
+            assert int(sd[k]) == int(v) == 2
+
+
+def test_cpu_tensor_is_refused_loudly():
+    model = _model("VanillaACAI", SMALL)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.encode(torch.rand(1, 1, 32, 32))

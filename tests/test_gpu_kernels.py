@@ -1,0 +1,316 @@
+"""-m gpu: every HIP kernel of libaesr_hip.so, called through the C ABI, against a PyTorch-CPU fp32 reference
+of the same op on the same seeded inputs.  Tolerances are fp32 summation-order tolerances (the MFMA path is an
+exact-fp32 fma chain): rel-L2 <= 1e-5 for forward ops, <= 1e-4 for long reductions (wgrad)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from superresolution_aniso_mri_amd import _hip
+    assert torch.cuda.is_available()
+    return _hip
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+_KEEP = []
+
+
+def D(t):
+    """Host tensor -> device tensor that stays alive until the test ends (kernels are asynchronous: a temporary
+    whose only reference dies right after hip.ptr() could be recycled by the caching allocator before it is read)."""
+    t = t.cuda() if not t.is_cuda else t
+    _KEEP.append(t)
+    return t
+
+
+@pytest.fixture(autouse=True)
+def _release_keepalive():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, KS, pad
+    (2, 162, 162, 32, 32, 3, 1),     # enc.1/enc.3 of the ACDC model (odd size, 27x18 tiles)
+    (3, 81, 81, 32, 64, 3, 1),
+    (2, 40, 40, 64, 128, 3, 1),
+    (2, 40, 40, 128, 128, 3, 1),
+    (5, 10, 10, 64, 64, 3, 1),       # multi-image tiles (TI > 1)
+    (2, 33, 35, 8, 16, 3, 1),        # channel counts below one MFMA block
+    (1, 20, 20, 16, 1, 3, 1),        # Cout = 1 padded to 16 (output conv)
+    (2, 17, 19, 16, 32, 1, 0),       # 1x1
+    (1, 7, 7, 4, 8, 3, 1),
+]
+
+
+def _pack(hip, w, transpose):
+    cout, cin, ks, _ = w.shape
+    n = hip.lib.aesr_conv2d_packed_floats(cout, cin, ks, transpose)
+    p = torch.empty(n, device="cuda")
+    hip.check(hip.lib.aesr_conv2d_pack(hip.ptr(w), hip.ptr(p), cout, cin, ks, transpose, hip.stream()), "pack")
+    return p
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("act", [0, 1, 3])
+def test_conv_fwd(hip, case, act):
+    N, H, W, Cin, Cout, KS, pad = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, KS, KS, generator=g) / np.sqrt(Cin * KS * KS)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, padding=pad)
+    ref = {0: ref, 1: F.leaky_relu(ref, 0.01), 3: torch.sigmoid(ref)}[act]
+    xd, wd, bd = nhwc(x).cuda(), w.cuda(), b.cuda()
+    Ho, Wo = ref.shape[2:]
+    out = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda")
+    hip.check(hip.lib.aesr_conv2d_fwd(hip.ptr(xd), hip.ptr(D(_pack(hip, wd, 0))), hip.ptr(bd), hip.ptr(out), N, H, W, Cin, Cout,
+                                      KS, pad, act, 0.01, hip.stream()), "conv_fwd")
+    torch.cuda.synchronize()
+    assert rel_l2(nchw(out), ref) < 1e-5
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[4] % 4 == 0])
+@pytest.mark.parametrize("masked", [False, True])
+def test_conv_dgrad(hip, case, masked):
+    N, H, W, Cin, Cout, KS, pad = case
+    g = torch.Generator().manual_seed(7 + hash(case) % 1000)
+    w = torch.randn(Cout, Cin, KS, KS, generator=g) / np.sqrt(Cout * KS * KS)
+    Ho, Wo = H + 2 * pad - KS + 1, W + 2 * pad - KS + 1
+    dy = torch.randn(N, Cout, Ho, Wo, generator=g)
+    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w, dy, padding=pad)
+    xs = torch.randn(N, Cin, H, W, generator=g)
+    if masked:
+        ref = ref * torch.where(xs > 0, torch.ones_like(xs), torch.full_like(xs, 0.01))
+    dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+    xsd = nhwc(xs).cuda() if masked else None
+    hip.check(hip.lib.aesr_conv2d_dgrad(hip.ptr(D(nhwc(dy))), hip.ptr(D(_pack(hip, D(w), 1))), hip.ptr(xsd), hip.ptr(dx),
+                                        N, H, W, Cin, Cout, KS, pad, 1 if masked else 0, 0.01, hip.stream()), "dgrad")
+    torch.cuda.synchronize()
+    assert rel_l2(nchw(dx), ref) < 1e-5
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[4] % 4 == 0])
+def test_conv_wgrad(hip, case):
+    N, H, W, Cin, Cout, KS, pad = case
+    g = torch.Generator().manual_seed(11 + hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    Ho, Wo = H + 2 * pad - KS + 1, W + 2 * pad - KS + 1
+    dy = torch.randn(N, Cout, Ho, Wo, generator=g)
+    ref_w = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, KS, KS), dy.double(), padding=pad)
+    ref_b = dy.double().sum((0, 2, 3))
+    dw = torch.full((Cout, Cin, KS, KS), float("nan"), device="cuda")
+    db = torch.full((Cout,), float("nan"), device="cuda")
+    ws = torch.empty(hip.lib.aesr_conv2d_wgrad_workspace_floats(N, H, W, Cin, Cout, KS, pad), device="cuda")
+    hip.check(hip.lib.aesr_conv2d_wgrad(hip.ptr(D(nhwc(x))), hip.ptr(D(nhwc(dy))), hip.ptr(dw), hip.ptr(db), hip.ptr(ws),
+                                        N, H, W, Cin, Cout, KS, pad, hip.stream()), "wgrad")
+    torch.cuda.synchronize()
+    assert rel_l2(dw, ref_w) < 2e-5
+    assert rel_l2(db, ref_b) < 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,ks,pad", [(1, 32, 1, 1), (1, 8, 1, 1), (3, 64, 3, 1), (2, 16, 3, 1)])
+def test_smallcin_fwd_dgrad_wgrad(hip, cin, cout, ks, pad):
+    N, H, W = 2, 21, 18
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    x = torch.randn(N, cin, H, W, generator=g).requires_grad_(True)
+    w = torch.randn(cout, cin, ks, ks, generator=g).requires_grad_(True)
+    b = torch.randn(cout, generator=g).requires_grad_(True)
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=pad), 0.01)
+    Ho, Wo = ref.shape[2:]
+    out = torch.empty((N, Ho, Wo, cout), device="cuda")
+    L = hip.lib
+    hip.check(L.aesr_conv2d_smallcin_fwd(hip.ptr(D(nhwc(x.detach()))), hip.ptr(D(w.detach())), hip.ptr(D(b.detach())), None,
+                                         hip.ptr(out), N, H, W, cin, cout, ks, pad, 1, 0, 0.01, 0, 0, None, None, hip.stream()), "fwd")
+    assert rel_l2(nchw(out), ref.detach()) < 1e-6
+    # gradients of the pre-activation conv
+    pre = F.conv2d(x, w, b, padding=pad)
+    dy = torch.randn(pre.shape, generator=g)
+    pre.backward(dy)
+    dx = torch.empty((N, H, W, cin), device="cuda")
+    hip.check(L.aesr_conv2d_smallcin_dgrad(hip.ptr(D(nhwc(dy))), hip.ptr(D(w.detach())), hip.ptr(dx), N, H, W, cin, cout, ks,
+                                           pad, 0, None, hip.stream()), "dgrad")
+    assert rel_l2(nchw(dx), x.grad) < 1e-5
+    if ks == 1:
+        dw, db = torch.empty_like(w, device="cuda"), torch.empty(cout, device="cuda")
+        ws = torch.empty(L.aesr_small_wgrad_workspace_floats(cout * (cin + 1)), device="cuda")
+        hip.check(L.aesr_conv2d_smallcin_wgrad(hip.ptr(D(nhwc(x.detach()))), hip.ptr(D(nhwc(dy))), hip.ptr(dw), hip.ptr(db),
+                                               hip.ptr(ws), N, H, W, cin, cout, pad, hip.stream()), "wgrad")
+        assert rel_l2(dw, w.grad) < 1e-5 and rel_l2(db, b.grad) < 1e-5
+
+
+def test_smallcin_bcast_matches_scaling_layer(hip):
+    """VGG conv1_1 on a 1-channel image with the LPIPS ScalingLayer (and the 2x-1 of perceptual.py) folded in."""
+    N, H, W, cout = 2, 16, 20, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(N, 1, H, W, generator=g).requires_grad_(True)
+    w = torch.randn(cout, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g) * 0.1
+    shift = torch.tensor([-.030, -.088, -.188])[None, :, None, None]
+    scale = torch.tensor([.458, .448, .450])[None, :, None, None]
+    ref = F.relu(F.conv2d(((2 * x - 1) - shift) / scale, w, b, padding=1))
+    ca = [2.0 / s for s in (.458, .448, .450)]
+    cb = [(-1.0 - sh) / s for sh, s in zip((-.030, -.088, -.188), (.458, .448, .450))]
+    out = torch.empty((N, H, W, cout), device="cuda")
+    L = hip.lib
+    hip.check(L.aesr_conv2d_smallcin_fwd(hip.ptr(D(x.detach().reshape(N, H, W, 1))), hip.ptr(D(w)), hip.ptr(D(b)), None,
+                                         hip.ptr(out), N, H, W, 3, cout, 3, 1, 2, 0, 0.0, 0, 1, hip.float_array(ca),
+                                         hip.float_array(cb), hip.stream()), "fwd")
+    assert rel_l2(nchw(out), ref.detach()) < 1e-5
+    dy = torch.randn(ref.shape, generator=g)
+    pre = F.conv2d(((2 * x - 1) - shift) / scale, w, b, padding=1)
+    pre.backward(dy)
+    dx = torch.empty((N, H, W, 1), device="cuda")
+    hip.check(L.aesr_conv2d_smallcin_dgrad(hip.ptr(D(nhwc(dy))), hip.ptr(D(w)), hip.ptr(dx), N, H, W, 3, cout, 3, 1, 1,
+                                           hip.float_array(ca), hip.stream()), "dgrad")
+    assert rel_l2(dx.reshape(N, 1, H, W), x.grad) < 1e-5
+
+
+def test_cout1_conv_backward(hip):
+    """Output conv 32->1: dgrad through the small-Cin forward kernel (transpose flag) + dedicated wgrad."""
+    N, H, W, cin = 2, 24, 20, 32
+    g = torch.Generator().manual_seed(9)
+    h = torch.randn(N, cin, H, W, generator=g).requires_grad_(True)
+    w = torch.randn(1, cin, 3, 3, generator=g).requires_grad_(True)
+    b = torch.zeros(1, requires_grad=True)
+    hl = F.leaky_relu(h, 0.01)
+    out = F.conv2d(hl, w, b, padding=1)
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy)
+    L = hip.lib
+    dx = torch.empty((N, H, W, cin), device="cuda")
+    hip.check(L.aesr_conv2d_smallcin_fwd(hip.ptr(D(nhwc(dy))), hip.ptr(D(w.detach())), None, hip.ptr(D(nhwc(hl.detach()))),
+                                         hip.ptr(dx), N, H, W, 1, cin, 3, 1, 0, 1, 0.01, 1, 0, None, None, hip.stream()), "dgrad")
+    assert rel_l2(nchw(dx), h.grad) < 1e-5
+    dw, db = torch.empty((1, cin, 3, 3), device="cuda"), torch.empty(1, device="cuda")
+    ws = torch.empty(L.aesr_small_wgrad_workspace_floats(cin * 9 + 1), device="cuda")
+    hip.check(L.aesr_conv2d_cout1_wgrad(hip.ptr(D(nhwc(hl.detach()))), hip.ptr(D(nhwc(dy))), hip.ptr(dw), hip.ptr(db),
+                                        hip.ptr(ws), N, H, W, cin, hip.stream()), "wgrad")
+    assert rel_l2(dw, w.grad) < 1e-5 and rel_l2(db, b.grad) < 1e-5
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(6, 33, 31, 32), (4, 40, 40, 64), (3, 9, 9, 8)])
+def test_bn_groups_fwd_bwd(hip, mode, shape):
+    """Two statistic groups (4+2 images etc.) == two independent nn.BatchNorm2d calls in sequence."""
+    N, H, W, C = shape
+    n0 = N - N // 3
+    nstart = [0, n0, N]
+    g = torch.Generator().manual_seed(N * H + C + mode)
+    pre = torch.randn(N, C, H, W, generator=g)
+    y = F.leaky_relu(pre, 0.01).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.normal_(generator=g)
+        bn.bias.normal_(generator=g)
+    post = {0: lambda t: t, 1: lambda t: F.avg_pool2d(t, 2), 2: lambda t: F.interpolate(t, scale_factor=2, mode="nearest")}[mode]
+    bn.train()
+    refs = [post(bn(y[a:b])) for a, b in zip(nstart[:-1], nstart[1:])]
+    ref = torch.cat(refs)
+    gout = torch.randn(ref.shape, generator=g)
+    (refs[0] * gout[:n0]).sum().backward()             # gradients only through group 0
+    L = hip.lib
+    yd = nhwc(y.detach()).cuda()
+    gam, bet = bn.weight.detach().cuda(), bn.bias.detach().cuda()
+    rm, rv, nbt = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros((), dtype=torch.int64, device="cuda")
+    G = 2
+    partial = torch.empty(G * hip.BN_NWG * 2 * C, device="cuda")
+    sums = torch.empty((G, 2, C), dtype=torch.float64, device="cuda")
+    ns = hip.int_array(nstart)
+    hip.check(L.aesr_bn_stats(hip.ptr(yd), hip.ptr(partial), hip.ptr(sums), H * W, C, G, ns, hip.stream()), "stats")
+    counts = torch.tensor([n0 * H * W, (N - n0) * H * W], dtype=torch.float64, device="cuda")
+    st = [torch.empty((G, C), device="cuda") for _ in range(4)]
+    hip.check(L.aesr_bn_finalize(hip.ptr(sums), hip.ptr(counts), hip.ptr(gam), hip.ptr(bet), hip.ptr(rm), hip.ptr(rv), hip.ptr(nbt),
+                                 *[hip.ptr(t) for t in st], C, G, 0.1, 1e-5, 1, 1, hip.stream()), "finalize")
+    Ho, Wo = ref.shape[2:]
+    out = torch.empty((N, Ho, Wo, C), device="cuda")
+    hip.check(L.aesr_bn_apply(hip.ptr(yd), hip.ptr(st[2]), hip.ptr(st[3]), hip.ptr(out), N, H, W, C, mode, G, ns, hip.stream()), "apply")
+    assert rel_l2(nchw(out), ref.detach()) < 1e-5
+    assert rel_l2(rm, bn.running_mean) < 1e-5 and rel_l2(rv, bn.running_var) < 1e-5 and int(nbt) == 2
+    # backward through group 0 only (N = n0, G = 1), fused with the LeakyReLU derivative of the producer
+    god = nhwc(gout[:n0]).cuda()
+    ns1 = hip.int_array([0, n0])
+    sums1 = torch.empty((1, 2, C), dtype=torch.float64, device="cuda")
+    hip.check(L.aesr_bn_bwd_reduce(hip.ptr(god), hip.ptr(yd), hip.ptr(st[0]), hip.ptr(st[1]), hip.ptr(partial), hip.ptr(sums1), n0, H, W,
+                                   C, mode, 1, ns1, hip.stream()), "bwd_reduce")
+    coef = torch.empty((1, 2, C), device="cuda")
+    dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dpre = torch.empty((n0, H, W, C), device="cuda")
+    hip.check(L.aesr_bn_bwd_apply(hip.ptr(god), hip.ptr(yd), hip.ptr(st[0]), hip.ptr(st[1]), hip.ptr(st[2]), hip.ptr(sums1), hip.ptr(counts),
+                                  hip.ptr(coef), hip.ptr(dgam), hip.ptr(dbet), hip.ptr(dpre), n0, H, W, C, mode, 1, 0.01, 1, ns1,
+                                  hip.stream()), "bwd_apply")
+    mask = torch.where(y.detach()[:n0] > 0, 1.0, 0.01)
+    assert rel_l2(nchw(dpre), y.grad[:n0] * mask) < 2e-5
+    assert rel_l2(dgam, bn.weight.grad) < 2e-5 and rel_l2(dbet, bn.bias.grad) < 2e-5
+
+
+def test_lerp_mse_act_adam(hip):
+    L = hip.lib
+    g = torch.Generator().manual_seed(3)
+    B, per = 3, 128 * 10 * 10
+    z = torch.randn(2 * B, per, generator=g)
+    af, at = torch.tensor([0.25, 0.5, 0.75]), torch.tensor([0.75, 0.5, 0.25])
+    zm = torch.empty(B, per, device="cuda")
+    hip.check(L.aesr_lerp_fwd(hip.ptr(D(z)), hip.ptr(D(af)), hip.ptr(D(at)), hip.ptr(zm), B, per, hip.stream()), "lerp")
+    assert torch.equal(zm.cpu(), af[:, None] * z[:B] + at[:, None] * z[B:])
+    d = torch.randn(B, per, generator=g)
+    dz = torch.empty(2 * B, per, device="cuda")
+    hip.check(L.aesr_lerp_bwd(hip.ptr(D(d)), hip.ptr(D(af)), hip.ptr(D(at)), hip.ptr(dz), B, per, hip.stream()), "lerp_bwd")
+    assert torch.equal(dz.cpu(), torch.cat([af[:, None] * d, at[:, None] * d]))
+    a = torch.rand(24 * 160 * 160, generator=g).requires_grad_(True)
+    b = torch.rand(24 * 160 * 160, generator=g)
+    ref = F.mse_loss(a, b)
+    ref.backward(torch.tensor(0.7))
+    part, loss = torch.empty(hip.MSE_NPART, dtype=torch.float64, device="cuda"), torch.empty(1, device="cuda")
+    hip.check(L.aesr_mse_fwd(hip.ptr(D(a.detach())), hip.ptr(D(b)), hip.ptr(part), hip.ptr(loss), a.numel(), hip.stream()), "mse")
+    assert abs(float(loss) - float(ref)) < 1e-6 * float(ref)
+    da = torch.empty(a.numel(), device="cuda")
+    hip.check(L.aesr_mse_bwd(hip.ptr(D(a.detach())), hip.ptr(D(b)), hip.ptr(D(torch.tensor([0.7]))), hip.ptr(da), a.numel(),
+                             hip.stream()), "mse_bwd")
+    assert rel_l2(da, a.grad) < 1e-6
+    y = torch.sigmoid(torch.randn(1000, generator=g))
+    dout = torch.randn(1000, generator=g)
+    dp = torch.empty(1000, device="cuda")
+    hip.check(L.aesr_act_bwd(hip.ptr(D(dout)), hip.ptr(D(y)), hip.ptr(dp), 1000, 3, 0.0, hip.stream()), "act_bwd")
+    assert rel_l2(dp, dout * y * (1 - y)) < 1e-6
+    # Adam: 3 steps against torch.optim.Adam
+    p = torch.randn(5000, generator=g)
+    pt = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    pd, m, v, state = p.cuda(), torch.zeros(5000, device="cuda"), torch.zeros(5000, device="cuda"), torch.zeros(4, device="cuda")
+    for _ in range(3):
+        gr = torch.randn(5000, generator=g)
+        pt.grad = gr.clone()
+        opt.step()
+        hip.check(L.aesr_adam_step(hip.ptr(pd), hip.ptr(D(gr)), hip.ptr(m), hip.ptr(v), hip.ptr(state), 5000, 1e-3, 0.9, 0.999, 1e-8,
+                                   0.01, hip.stream()), "adam")
+    assert rel_l2(pd, pt.detach()) < 1e-6 and float(state[0]) == 3.0
+
+
+def test_bad_arguments_fail_loudly(hip):
+    L = hip.lib
+    x = torch.zeros(16, device="cuda")
+    rc = L.aesr_conv2d_fwd(hip.ptr(x), hip.ptr(x), None, hip.ptr(x), 1, 4, 4, 3, 8, 3, 1, 0, 0.0, hip.stream())
+    assert rc != 0 and "multiple of 4" in hip.last_error()
+    rc = L.aesr_lerp_fwd(hip.ptr(x), hip.ptr(x), hip.ptr(x), hip.ptr(x), 1, 6, hip.stream())
+    assert rc != 0
+    with pytest.raises(RuntimeError):
+        hip.check(rc, "lerp")
