@@ -1,0 +1,156 @@
+#!/usr/bin/env python
+"""Headline benchmark: ``ae_combined`` training slices/s on synthetic ACDC-shaped batches (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3]
+
+A step = one ae_combined training step (4 network passes, backward, Adam) over one batch of 12 synthetic triplets
+(36 slices of 160x160) that is already resident in HBM.  N > 1: launched by torch.distributed.run, one rank per GPU
+over RCCL; the 12 triplets are sharded over the ranks (fixed global batch -> strong scaling).
+Rank 0 prints ONE JSON line (see DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# algorithmic conv FLOPs per training step (SURVEY.md section 8a / BASELINE.md section 2), B=12, 160x160, scales 2
+STEP_GFLOP = {"c2": 330.8, "c3": 894.5}
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def build_args(config, device):
+    from superresolution_aniso_mri_amd.networks.net_config import NetworkConfig
+    args = dict(model="ae_combined", dataset="ACDC", device=device, lr=1e-5, weight_decay=0.0, epochs=900, batch_size=12,
+                width=128, latent_width=32, depth=32, latent=128, ex_loss_weight1=0.05, use_percept_loss=False,
+                get_masks=False, use_loss_annealing=False, use_extra_latent_loss=False, epoch_threshold=500,
+                ae_class="VanillaACAI", downsample_steps=2, seed=892372,
+                image_mix_loss_func="mse" if config == "c2" else "perceptual", vgg_weights="synthetic-hash")
+    for k, v in NetworkConfig("ae_combined", dataset="ACDC").architecture.items():
+        args.setdefault(k, v)
+    return args
+
+
+def cpu_baseline(B, H, steps=3):
+    """The oracle (PyTorch-CPU restatement of the same step, MSE synthesis loss) on this host's cores."""
+    from oracle import ae_oracle, step_oracle
+    from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+    torch.manual_seed(892372)
+    ae = ae_oracle.OracleAE(ae_oracle.acdc_args())
+    st = step_oracle.OracleStep(ae, lr=1e-5, ex_loss_weight1=0.05, image_mix_loss_func="mse")
+    batch = synthetic_batch(B, H, H, seed=892372)
+    st.train(batch["image"], batch["slice_between"])            # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st.train(batch["image"], batch["slice_between"])
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(3 * B / dt, 2), "unit": "slices/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d steps (after 1 warm-up) of the same workload: B=%d triplets %dx%d, MSE synthesis loss, "
+                      "oracle/step_oracle.py on PyTorch-CPU fp32" % (steps, B, H, H), "s_per_step": round(dt, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=["c2", "c3"], default="c2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    opt = ap.parse_args()
+
+    from superresolution_aniso_mri_amd import engine
+    from superresolution_aniso_mri_amd.data_synth import shard_batch, synthetic_batch
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    from superresolution_aniso_mri_amd.parallel import DataParallelContext
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if opt.gpus > 1 and world != opt.gpus:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (opt.gpus, opt.gpus))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    dp = DataParallelContext(device=device)
+    B, H = 12, 160
+    torch.manual_seed(892372)
+    trainer = get_trainer_dynamic(build_args(opt.config, device))
+    if dp.active:
+        dp.attach(trainer)
+        dp.set_batch(B)
+    # a small pool of distinct batches, sharded by triplet and resident in HBM before the timed region
+    pool = []
+    for i in range(4):
+        b = synthetic_batch(B, H, H, seed=892372 + i)
+        if dp.active:
+            b = shard_batch(b, dp.rank, dp.world)
+        pool.append({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items()})
+
+    def run(n, first=0):
+        for i in range(n):
+            trainer.train(pool[(first + i) % len(pool)], keep_predictions=False)
+
+    run(opt.warmup)
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(opt.steps, opt.warmup)
+    torch.cuda.synchronize()
+    dp.barrier()
+    elapsed = dp.max_over_ranks(time.perf_counter() - t0)
+    ms_per_step = 1e3 * elapsed / opt.steps
+    value = 3 * B * opt.steps / elapsed
+    loss = trainer.losses["loss_ae"][-1]
+
+    roofline = None
+    if not opt.no_roofline:
+        # same steps again with one HIP-event pair around every MFMA convolution launch (on the launching stream)
+        engine.PROFILER = engine.KernelProfiler()
+        run(min(opt.steps, 5), 0)
+        summ = engine.PROFILER.summary()
+        engine.PROFILER = None
+        k = summ.get("conv_igemm_f32", {"launches": 0, "flops": 0.0, "ms": 1e-9})
+        ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["launches"] else 0.0
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_f32 (forward + data-gradient launches)", "achieved": round(ach, 2),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": None, "launches_per_step": k["launches"] // max(1, min(opt.steps, 5)),
+                    "avg_launch_us": round(1e3 * k["ms"] / max(1, k["launches"]), 2),
+                    "algorithmic_gflop_per_launch": round(k["flops"] / max(1, k["launches"]) / 1e9, 3),
+                    "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
+                    "measured": "HIP events around every launch, %d instrumented steps after the timed region" % min(opt.steps, 5)}
+        w = summ.get("conv_wgrad_f32")
+        if w and w["launches"]:
+            roofline["wgrad_achieved"] = round(w["flops"] / (w["ms"] * 1e-3) / 1e12, 2)
+            roofline["wgrad_ms_per_step"] = round(w["ms"] / min(opt.steps, 5), 3)
+        roofline["igemm_ms_per_step"] = round(k["ms"] / max(1, min(opt.steps, 5)), 3)
+
+    if dp.rank != 0:
+        return
+    line = {
+        "metric": "training slices/sec (ae_combined, 160x160, latent=128)", "value": round(value, 1), "unit": "slices/s",
+        "n_gpus": opt.gpus, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ACDC synthetic 12x(3x1x160x160) triplets, ae_combined latent=128 depth=32 scales=2, "
+                               + ("MSE synthesis loss (BASELINE configs[1])" if opt.config == "c2"
+                                  else "LPIPS-VGG synthesis loss lambda=0.05, synthetic backbone weights (BASELINE configs[2])"),
+                   "global_batch_triplets": B, "slices_per_step": 3 * B, "parallelism": "dp%d" % opt.gpus,
+                   "init": "reference Initializer, seed 892372, random weights"},
+        "step_algorithmic_gflop": STEP_GFLOP[opt.config],
+        "step_tflops": round(STEP_GFLOP[opt.config] / ms_per_step, 2),
+        "step_frac_of_f32_mfma_peak": round(STEP_GFLOP[opt.config] / ms_per_step / PEAK_F32_MFMA_TFLOPS, 4),
+        "final_loss": round(float(loss), 6),
+    }
+    if roofline is not None:
+        line["roofline"] = roofline
+    if opt.gpus == 1 and not opt.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(B, H)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,46 @@ from ._hip import lib, ptr, stream, check
 LRELU_SLOPE = 0.01
 
 
+class KernelProfiler:
+    """Optional HIP-event timing of the MFMA convolution launches (bench.py roofline): one event pair per launch on the
+    launching stream; durations are read after a synchronize.  Off (None) in normal operation."""
+
+    def __init__(self):
+        self.records = []      # (kind, flops, start_event, end_event)
+
+    def begin(self, kind, flops):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream())
+        self.records.append((kind, flops, e0, e1))
+
+    def end(self):
+        self.records[-1][3].record(torch.cuda.current_stream())
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, flops, e0, e1 in self.records:
+            d = out.setdefault(kind, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+PROFILER = None
+
+
+def _pb(kind, flops):
+    if PROFILER is not None:
+        PROFILER.begin(kind, flops)
+
+
+def _pe():
+    if PROFILER is not None:
+        PROFILER.end()
+
+
 def _act_of(m):
     if isinstance(m, nn.LeakyReLU):
         return _hip.ACT_LRELU, float(m.negative_slope)
@@ -153,8 +193,10 @@ class SequentialRunner:
                 out = _empty((N, Ho, Wo, s.cout), x)
                 bias = s.mod.bias
                 if s.mfma_fwd:
+                    _pb("conv_igemm_f32", 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
                     check(lib.aesr_conv2d_fwd(ptr(cur), ptr(s.packed), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, s.ks,
                                               s.pad, s.act, s.slope, stream()), "aesr_conv2d_fwd")
+                    _pe()
                 elif s.cin <= 4:
                     check(lib.aesr_conv2d_smallcin_fwd(ptr(cur), ptr(s.mod.weight), ptr(bias), None, ptr(out), N, H, W,
                                                        s.cin, s.cout, s.ks, s.pad, s.act, _hip.ACT_NONE, s.slope, 0, 0,
@@ -234,8 +276,10 @@ class SequentialRunner:
                 if s.cin % 4 == 0 and s.cout % 4 == 0:
                     nws = lib.aesr_conv2d_wgrad_workspace_floats(N, H, W, s.cin, s.cout, s.ks, s.pad)
                     ws = _empty((nws,), g)
+                    _pb("conv_wgrad_f32", 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
                     check(lib.aesr_conv2d_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout, s.ks,
                                                 s.pad, stream()), "aesr_conv2d_wgrad")
+                    _pe()
                 elif s.cin <= 4 and s.ks == 1 and db is not None:
                     ws = _empty((lib.aesr_small_wgrad_workspace_floats(s.cout * (s.cin + 1)),), g)
                     check(lib.aesr_conv2d_smallcin_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout,
@@ -263,8 +307,10 @@ class SequentialRunner:
                     check(lib.aesr_conv2d_smallcin_dgrad(ptr(g), ptr(s.mod.weight), ptr(dx), N, H, W, s.cin, s.cout, s.ks,
                                                          s.pad, 0, None, stream()), "aesr_conv2d_smallcin_dgrad")
                 elif s.cout % 4 == 0:
+                    _pb("conv_igemm_f32", 2.0 * N * H * W * s.cin * s.ks * s.ks * s.cout)
                     check(lib.aesr_conv2d_dgrad(ptr(g), ptr(s.packed_t), ptr(mask), ptr(dx), N, H, W, s.cin, s.cout, s.ks,
                                                 s.pad, mask_act, mslope, stream()), "aesr_conv2d_dgrad")
+                    _pe()
                 elif s.cout <= 4:
                     # data gradient of a tiny-Cout conv == small-Cin forward conv with the flipped/transposed filter
                     check(lib.aesr_conv2d_smallcin_fwd(ptr(g), ptr(s.mod.weight), None, ptr(mask), ptr(dx), N, Ho, Wo, s.cout,

@@ -1,0 +1,118 @@
+"""``AETrainerEndToEnd``: the ACDC ``ae_combined`` step of the reference (kwatsch/cardiac/trainer_ae.py:8-182).
+
+One step = loss_ae(MSE(dec(enc(x)), x)) + lambda * loss(slice_between, dec(0.5 z_from + 0.5 z_to)), with the
+reference's four network passes (enc(x[2B]), dec(z[2B]), dec(z_mix[B]), logging-only enc(slice_between[B]) which still
+updates the encoder's BatchNorm running statistics) issued as TWO batched launches sequences with
+per-sub-batch BatchNorm statistics: enc([x | slice_between]) and dec([z | z_mix])."""
+import os
+
+import torch
+
+from .. import trainer_ae as _tae
+from ... import ops
+
+
+class CombinedStepMixin(object):
+    """Shared ``ae_combined`` machinery of the cardiac / brain / MNIST trainers."""
+
+    def _extra_weight(self):
+        if self.args.get("use_loss_annealing"):
+            return float(self.loss_weights[self.epoch])
+        return self.args["ex_loss_weight1"]
+
+    def get_extra_image_loss(self, reference, synthesized, mask=None, is_test=False):
+        use_mask = self.args.get("get_masks") and mask is not None
+        if self.percept_criterion is not None and self.image_mix_loss_func == "perceptual":
+            if use_mask and self._mask_inputs:
+                m = mask[:synthesized.size(0)].to(synthesized.device)
+                reference, synthesized = reference * m, synthesized * m
+            ctxm = torch.no_grad() if is_test else torch.enable_grad()
+            with ctxm:
+                d = self.percept_criterion(reference, synthesized, normalize=True)
+                if use_mask and not self._mask_inputs:
+                    d = d * mask[:d.size(0)].to(d.device)
+                return d.mean()
+        if use_mask:
+            raise NotImplementedError("masked MSE synthesis loss is outside the ae_combined hot path of this build")
+        return ops.mse_loss(reference, synthesized)
+
+    _mask_inputs = True      # cardiac multiplies the images by the mask; brain multiplies the distances
+
+    def get_extra_loss(self, slice_between, s_between_mix, z_mix, z=None, mask=None, is_test=False):
+        loss_img = self._extra_weight() * self.get_extra_image_loss(slice_between, s_between_mix, mask=mask, is_test=is_test)
+        if self.args.get("use_extra_latent_loss"):
+            raise NotImplementedError("use_extra_latent_loss is not part of the README ae_combined recipes")
+        if self._log_extra_total:
+            self._log("loss_ae_extra", loss_img, is_test)
+        self._log("loss_ae_dist_extra", loss_img, is_test)
+        return loss_img
+
+    _log_extra_total = True
+
+    def synthesize_batch_images(self, **kwargs):
+        """Eval-style entry kept for callers (validate): lerp + decode (+ latent loss against enc(slice_between))."""
+        batch_item, z, between = kwargs.get("batch_item"), kwargs.get("z"), kwargs.get("slice_between", None)
+        is_eval = kwargs.get("is_eval", False)
+        z = z.to(self.args["device"])
+        a_from, a_to = self._mix_coefficients(batch_item, z.shape[0] // 2)
+        z_mix = ops.lerp_mix(z, a_from, a_to)
+        if is_eval:
+            s_mix = self.decode(z_mix, eval=True)
+            self.model.train()
+        else:
+            s_mix = self.model.decode(z_mix)
+        lat = 0
+        if kwargs.get("compute_latent_loss", False):
+            z_ref = self.encode(between, eval=is_eval)
+            lat = ops.mse_loss(z_mix.detach(), z_ref.detach())
+        return {"s_between_mix": s_mix, "z_mix": z_mix, "loss_latent": lat}
+
+    def train(self, batch_item, keep_predictions=True, eval_mode=False):
+        x = self._to_device(batch_item["image"])
+        between = self._to_device(batch_item["slice_between"])
+        self.model.train(not eval_mode)
+        self._iters += 1
+        B = x.shape[0] // 2
+        # enc(x[2B]) and the logging-only enc(slice_between[B]): one batched pass, two BatchNorm statistic groups
+        z, z_ref = self.model.encode_multi([x, between], needs_grad=[True, False])
+        a_from, a_to = self._mix_coefficients(batch_item, B)
+        z_mix = ops.lerp_mix(z, a_from, a_to)
+        # dec(z[2B]) and dec(z_mix[B]): one batched pass, two statistic groups
+        out, s_mix = self.model.decode_multi([z, z_mix])
+        loss_ae = self.get_loss(x, out, is_test=False)["loss_ae"]
+        loss_latent = ops.mse_loss(z_mix.detach(), z_ref.detach())
+        mask = batch_item["loss_mask"] if self.args.get("get_masks") else None
+        loss = loss_ae + self.get_extra_loss(between, s_mix, z_mix, z=z, mask=mask, is_test=False)
+        self._backward_and_step(loss, eval_mode)
+        self._log("loss_ae", loss)
+        self._log("loss_latent_1", loss_latent)
+        if keep_predictions:
+            s = s_mix.detach().cpu()
+            self.train_predictions = {"z_mix": z_mix.detach().cpu(), "pred_alphas": self._pred_alphas(batch_item),
+                                      "slice_inbetween_mix": s, "slice_inbetween_05": s, "reconstruction": out.detach().cpu()}
+
+    def _pred_alphas(self, batch_item):
+        return torch.tensor([0.5])
+
+    def _validate_synthesis(self, validation_batch, add_to_loss_ae):
+        z = self.test_predictions["z"].to(self.args["device"])
+        between = self._to_device(validation_batch["slice_between"])
+        r = self.synthesize_batch_images(batch_item=validation_batch, z=z, compute_latent_loss=True, slice_between=between,
+                                         is_eval=True)
+        self._log("loss_latent_1", r["loss_latent"], True)
+        mask = validation_batch["loss_mask"] if self.args.get("get_masks") else None
+        extra = self.get_extra_loss(between, r["s_between_mix"], r["z_mix"], mask=mask, is_test=True)
+        if add_to_loss_ae:
+            self.losses_test["loss_ae"][-1] = self.losses_test["loss_ae"][-1] + float(extra)
+
+
+class AETrainerEndToEnd(CombinedStepMixin, _tae.AEBaseTrainer):
+
+    def validate(self, validation_batch, image_dict=None, frame_id=8, generate_images=True):
+        res = super().validate(validation_batch, image_dict=image_dict, frame_id=frame_id, generate_images=generate_images)
+        self._validate_synthesis(validation_batch, add_to_loss_ae=False)
+        return res
+
+    def save_best_val_model(self, **kwargs):
+        if self._best_now("loss_ae_dist_extra"):
+            self.save_models(os.path.join(self.args["dir_models"], "caisr.models"), self.epoch + 1)

@@ -1,0 +1,91 @@
+"""``AEBaseTrainer``: constructor contract and plain-AE step of the reference's kwatsch/trainer_ae.py:16-109 on the
+HIP engine.  Optimiser = fused-kernel Adam with the reference's hyper-parameters (:28-30); device-agnostic
+construction (the reference's ``torch.cuda.FloatTensor`` at :51 made CPU construction impossible)."""
+from collections import defaultdict
+
+import torch
+
+from .. import ops
+from .base_trainer import BaseTrainer, LossLog
+
+
+class AEBaseTrainer(BaseTrainer):
+
+    def __init__(self, args, ae, max_grad_norm=0, model_file=None, eval_mode=False, **kwargs):
+        super(AEBaseTrainer, self).__init__()
+        self.args = args
+        self.model = ae
+        self.model_sr = kwargs.get("model_sr", None)
+        self.eval_model = eval_mode
+        self.model_file = model_file
+        self.do_chunk = False
+        self.eval_fixed_coeff = True
+        self.opt_ae = self._make_optimizer(args)
+        self._init_scheduler()
+        self.losses, self.losses_test = defaultdict(LossLog), defaultdict(LossLog)
+        self.loss_iters = list()
+        self.mean_losses, self.mean_losses_test = defaultdict(list), defaultdict(list)
+        self.train_predictions, self.test_predictions = None, None
+        self._iters = 1
+        self.max_grad_norm = max_grad_norm            # accepted, never applied by the ae / ae_combined trainers
+        self.use_multiple_gpu = False                 # the reference's "loss on cuda:1" trick is replaced by RCCL data parallel
+        self.alpha05 = torch.tensor([0.5], dtype=torch.float32, device=args["device"])[:, None, None, None]
+        self._init_laploss()
+        self._init_percept_loss()
+        self.determine_image_mix_loss_func()
+        self.ssim_criterion = None
+        self.epoch = 0
+        self.init_weight_annealing(self.args.get("epochs", 1))
+        if self.args.get("use_ssim_loss"):
+            raise NotImplementedError("ERROR - SSIM as loss is disabled (as in the reference)")
+        self.dp = None                                # set by parallel.DataParallelContext.attach()
+        self._step_graph = None
+        if model_file is not None:
+            self.model_file = model_file
+            self.load(model_file)
+        if self.model_sr is not None and kwargs.get("model_file_sr", None) is not None:
+            self.model_file_sr = kwargs.get("model_file_sr")
+            self.load_caisr(self.model_file_sr)
+
+    def _make_optimizer(self, args):
+        params = list(self.model.parameters())
+        momentum = args.get("momentum", 0.9)
+        kw = dict(lr=args.get("lr", 1e-5), weight_decay=args.get("weight_decay", 0.0), betas=(momentum, 0.999))
+        if params and params[0].is_cuda and not self.eval_model:
+            return ops.HipAdam(params, on_step=self.model.mark_weights_dirty, **kw)
+        # eval-only trainers / host-logic tests never step; a stock Adam keeps the checkpoint format
+        return torch.optim.Adam(params, **kw)
+
+    # ---- one optimisation step on an already built loss ----------------------------------------------------------
+    def _backward_and_step(self, loss, eval_mode):
+        self.opt_ae.zero_grad()
+        if not eval_mode:
+            if self.dp is not None and self.dp.active:
+                (loss * self.dp.weight).backward()      # SUM over ranks of w_r * grad(loss_r) == grad of the global mean
+                self.dp.allreduce_gradients(self.opt_ae)
+            else:
+                loss.backward()
+            self.opt_ae.step()
+        if self.opt_sched_ae is not None:
+            self.opt_sched_ae.step()
+
+    def train(self, batch_item, keep_predictions=True, eval_mode=False):
+        """Plain ``ae`` step (reference :71-109): reconstruction loss only; latent loss and the 0.5-mix are logged."""
+        x = self._to_device(batch_item["image"])
+        self.model.train(not eval_mode)
+        self._iters += 1
+        z = self.model.encode(x)
+        out = self.model.decode(z)
+        loss_ae = self.get_loss(x, out, is_test=False)["loss_ae"]
+        a_from, a_to = self._mix_coefficients(batch_item, x.shape[0] // 2)
+        lat = self.get_latent_loss(reference=self._to_device(batch_item["slice_between"]), alpha_from=a_from, alpha_to=a_to,
+                                   z=z.detach(), no_grad=True)
+        self.model.train(not eval_mode)
+        self._backward_and_step(loss_ae, eval_mode)
+        self._log("loss_ae", loss_ae)
+        self._log("loss_latent_1", lat["loss_latent"])
+        if keep_predictions:
+            mix = self._get_mixup_image(z=z.detach(), alpha_from=a_from, alpha_to=a_to, is_test=True)
+            s = mix["slice_inbetween_mix"].detach().cpu()
+            self.train_predictions = {"z_mix": lat["z_mix"].detach().cpu(), "pred_alphas": torch.tensor([0.5]),
+                                      "slice_inbetween_mix": s, "slice_inbetween_05": s, "reconstruction": out.detach().cpu()}

@@ -1,0 +1,182 @@
+"""Autograd wrappers of the non-network HIP ops of the ae_combined step (latent lerp, MSE) and the fused Adam.
+
+Follows kwatsch/cardiac/trainer_ae.py:173 / kwatsch/brain/trainer_ae.py:264-266 (lerp), kwatsch/base_trainer.py:177
+(``F.mse_loss`` mean) and kwatsch/trainer_ae.py:29-30 (``optim.Adam``).  No CPU fallback."""
+import torch
+
+from . import _hip, engine
+from ._hip import check, lib, ptr, stream
+
+
+def _flat_pair(a, b):
+    """Two same-shape tensors -> contiguous buffers with identical element order (NHWC if 4-D)."""
+    if a.shape != b.shape:
+        raise ValueError("shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    if a.dim() == 4:
+        return engine.to_nhwc(a), engine.to_nhwc(b)
+    return a.contiguous().float(), b.contiguous().float()
+
+
+class _LerpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, a_from, a_to):
+        B = z.shape[0] // 2
+        per = z[0].numel()
+        zmix = torch.empty((B,) + tuple(z.shape[1:]), device=z.device, dtype=torch.float32)
+        check(lib.aesr_lerp_fwd(ptr(z), ptr(a_from), ptr(a_to), ptr(zmix), B, per, stream()), "aesr_lerp_fwd")
+        ctx.save_for_backward(a_from, a_to)
+        return zmix
+
+    @staticmethod
+    def backward(ctx, dzmix):
+        a_from, a_to = ctx.saved_tensors
+        dzmix = dzmix.contiguous()
+        B = dzmix.shape[0]
+        dz = torch.empty((2 * B,) + tuple(dzmix.shape[1:]), device=dzmix.device, dtype=torch.float32)
+        check(lib.aesr_lerp_bwd(ptr(dzmix), ptr(a_from), ptr(a_to), ptr(dz), B, dzmix[0].numel(), stream()), "aesr_lerp_bwd")
+        return dz, None, None
+
+
+def lerp_mix(z, alpha_from, alpha_to):
+    """z: logical NCHW [2B,C,H,W] (rows i and i+B are a pair).  alpha_*: [B] or [B,1] or scalar.
+    Returns z_mix [B,C,H,W] = alpha_from*z[:B] + alpha_to*z[B:]."""
+    B = z.shape[0] // 2
+    if z.shape[0] != 2 * B or B == 0:
+        raise ValueError("lerp_mix needs an even, non-empty batch (got %d)" % z.shape[0])
+    zn = engine.to_nhwc(z) if z.dim() == 4 else z.contiguous()
+    _hip.require_gpu_tensor(zn, "z")
+    if zn[0].numel() % 4 != 0:
+        raise ValueError("latent size per image must be a multiple of 4")
+
+    def coef(a):
+        a = torch.as_tensor(a, dtype=torch.float32, device=z.device).reshape(-1)
+        if a.numel() == 1:
+            a = a.expand(B)
+        if a.numel() != B:
+            raise ValueError("need one mixing coefficient per pair (%d), got %d" % (B, a.numel()))
+        return a.contiguous()
+
+    out = _LerpFn.apply(zn, coef(alpha_from), coef(alpha_to))
+    return engine.to_nchw_view(out) if z.dim() == 4 else out
+
+
+class _MseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        partial = torch.empty(_hip.MSE_NPART, device=a.device, dtype=torch.float64)
+        loss = torch.empty(1, device=a.device, dtype=torch.float32)
+        check(lib.aesr_mse_fwd(ptr(a), ptr(b), ptr(partial), ptr(loss), a.numel(), stream()), "aesr_mse_fwd")
+        ctx.save_for_backward(a, b)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.reshape(1).contiguous().float()
+        da = torch.empty_like(a)
+        check(lib.aesr_mse_bwd(ptr(a), ptr(b), ptr(g), ptr(da), a.numel(), stream()), "aesr_mse_bwd")
+        db = -da if ctx.needs_input_grad[1] else None
+        return (da if ctx.needs_input_grad[0] else None), db
+
+
+def mse_loss(a, b):
+    """mean((a-b)^2) over all elements as a 0-dim device tensor (no host sync)."""
+    an, bn = _flat_pair(a, b)
+    _hip.require_gpu_tensor(an, "mse input")
+    _hip.require_gpu_tensor(bn, "mse target")
+    return _MseFn.apply(an, bn)
+
+
+class HipAdam(torch.optim.Adam):
+    """``torch.optim.Adam`` whose step is ONE fused HIP kernel over a flat parameter buffer.
+
+    Parameters are re-pointed at views of one flat fp32 buffer (same Parameter objects, so module state_dicts are
+    untouched); ``p.grad`` are views of a flat gradient buffer and ``exp_avg`` / ``exp_avg_sq`` views of flat moment
+    buffers, so ``state_dict()`` keeps the stock Adam layout the reference checkpoints use
+    (kwatsch/base_trainer.py:353-362).  The step counter lives on the device (graph-replay safe)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, on_step=None):
+        params = [p for p in params]
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.on_step = on_step
+        self._plist = [p for g in self.param_groups for p in g["params"]]
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("HipAdam supports a single parameter group")
+        dev = self._plist[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("HipAdam needs parameters on the GPU (got %s): no CPU fallback" % dev)
+        n = sum(p.numel() for p in self._plist)
+        self.flat_p = torch.empty(n, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flat_m = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flat_v = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.dev_state = torch.zeros(4, device=dev, dtype=torch.float32)
+        self._host_step = 0
+        off = 0
+        for p in self._plist:
+            k = p.numel()
+            self.flat_p[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + k].view_as(p.data)
+            p.grad = self.flat_g[off:off + k].view_as(p.data)
+            self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.flat_m[off:off + k].view_as(p.data),
+                             "exp_avg_sq": self.flat_v[off:off + k].view_as(p.data)}
+            off += k
+        self.numel = n
+
+    def _check_views(self):
+        off = 0
+        for p in self._plist:
+            k = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                g_old = p.grad
+                p.grad = self.flat_g[off:off + k].view_as(p.data)
+                if g_old is not None:
+                    p.grad.copy_(g_old)
+                else:
+                    p.grad.zero_()
+            off += k
+
+    def zero_grad(self, set_to_none=False):
+        self._check_views()
+        self.flat_g.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closures are not supported")
+        self._check_views()
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        check(lib.aesr_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), ptr(self.dev_state),
+                                 self.numel, float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
+                                 stream()), "aesr_adam_step")
+        self._host_step += 1
+        if self.on_step is not None:
+            self.on_step()
+
+    def state_dict(self):
+        step = float(self.dev_state[0].item())
+        for p in self._plist:
+            self.state[p]["step"] = torch.tensor(step)
+        return super().state_dict()
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        off, step = 0, 0.0
+        for p in self._plist:
+            k = p.numel()
+            st = self.state[p]
+            if "exp_avg" in st:
+                self.flat_m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.flat_v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                step = float(st["step"])
+            st["exp_avg"] = self.flat_m[off:off + k].view_as(p.data)
+            st["exp_avg_sq"] = self.flat_v[off:off + k].view_as(p.data)
+            off += k
+        self.dev_state.zero_()
+        self.dev_state[0] = step
+        if step > 0:
+            b1, b2 = self.param_groups[0]["betas"]
+            self.dev_state[1] = 1.0 - b1 ** step
+            self.dev_state[2] = (1.0 - b2 ** step) ** 0.5
+        self._host_step = int(step)
