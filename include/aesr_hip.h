@@ -71,6 +71,9 @@ int aesr_conv2d_smallcin_dgrad(const float* dy, const float* w, float* dx, int N
 size_t aesr_small_wgrad_workspace_floats(int nout);
 int aesr_conv2d_smallcin_wgrad(const float* in, const float* dout, float* dw, float* db, float* workspace, int N, int H,
                                int W, int Cin, int Cout, int pad, void* stream);
+/* 3x3 pad-1 Cout==1 forward (output conv networks/acai_vanilla.py:98 + Sigmoid): out[N,H,W,1] = act(conv(x, w[1][Cin][3][3]) + bias). */
+int aesr_conv2d_cout1_fwd(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int Cin, int act,
+                          float slope, void* stream);
 /* 3x3 pad-1 Cout==1 weight/bias gradient (output conv networks/acai_vanilla.py:98).  Same workspace helper
  * with nout = Cin*9+1. */
 int aesr_conv2d_cout1_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W,
@@ -105,6 +108,21 @@ int aesr_bn_bwd_apply(const float* gout, const float* y, const float* mean, cons
                       const double* sums, const double* counts_dev, float* coef, float* dgamma, float* dbeta,
                       float* dpre, int N, int H, int W, int C, int mode, int act, float slope, int G,
                       const int* nstart_host, void* stream);
+
+/* ---- LPIPS-VGG (lpips/networks_basic.py:63-91, lpips/common.py:12-14, lpips/pretrained_networks.py:107-116) ---- */
+/* nn.MaxPool2d(2): out [N,H/2,W/2,C]. */
+int aesr_maxpool2_fwd(const float* x, float* out, int N, int H, int W, int C, void* stream);
+/* dx = (scatter of gout to the FIRST maximum of each window + gadd) * (relu_mask ? x > 0 : 1); gadd may be NULL. */
+int aesr_maxpool2_bwd(const float* gout, const float* x, const float* gadd, float* dx, int N, int H, int W, int C,
+                      int relu_mask, void* stream);
+#define AESR_LPIPS_NCH 64
+/* One tap.  f is [2B,HW,C] (branch 0 = images 0..B-1, branch 1 = images B..2B-1), lin_w [C];
+ * partial [B][AESR_LPIPS_NCH] = chunk sums over pixels of sum_c w_c (f0/(|f0|+1e-10) - f1/(|f1|+1e-10))^2.  C in {64,128,256,512}. */
+int aesr_lpips_tap_fwd(const float* f, const float* lin_w, float* partial, int B, int HW, int C, void* stream);
+/* gradient of d w.r.t. branch 0 of the tap: gf0 [B,HW,C]; gd [B] = dL/dd[n]. */
+int aesr_lpips_tap_bwd(const float* f, const float* lin_w, const float* gd, float* gf0, int B, int HW, int C, void* stream);
+/* d[n] = sum_k (1/hw[k]) * sum_chunk partials[k][n][chunk]; partials_host: ntaps DEVICE pointers in a host array. */
+int aesr_lpips_finalize(const float* const* partials_host, const int* hw_host, int ntaps, float* d, int B, void* stream);
 
 /* ---- latent lerp (kwatsch/cardiac/trainer_ae.py:173; kwatsch/brain/trainer_ae.py:264-266;
  *      generate_hr_volumes.py:88) ------------------------------------------------------------------------- */

@@ -31,12 +31,18 @@ SIGNATURES = {
     "aesr_conv2d_smallcin_dgrad": (c_int, [P, P, P] + [c_int] * 8 + [FP, P]),
     "aesr_small_wgrad_workspace_floats": (c_size_t, [c_int]),
     "aesr_conv2d_smallcin_wgrad": (c_int, [P, P, P, P, P] + [c_int] * 6 + [P]),
+    "aesr_conv2d_cout1_fwd": (c_int, [P, P, P, P] + [c_int] * 5 + [c_float, P]),
     "aesr_conv2d_cout1_wgrad": (c_int, [P, P, P, P, P] + [c_int] * 4 + [P]),
     "aesr_bn_stats": (c_int, [P, P, P, c_int, c_int, c_int, IP, P]),
     "aesr_bn_finalize": (c_int, [P] * 11 + [c_int, c_int, c_float, c_float, c_int, c_int, P]),
     "aesr_bn_apply": (c_int, [P, P, P, P] + [c_int] * 6 + [IP, P]),
     "aesr_bn_bwd_reduce": (c_int, [P] * 6 + [c_int] * 6 + [IP, P]),
     "aesr_bn_bwd_apply": (c_int, [P] * 11 + [c_int] * 6 + [c_float, c_int, IP, P]),
+    "aesr_maxpool2_fwd": (c_int, [P, P] + [c_int] * 4 + [P]),
+    "aesr_maxpool2_bwd": (c_int, [P, P, P, P] + [c_int] * 5 + [P]),
+    "aesr_lpips_tap_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "aesr_lpips_tap_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "aesr_lpips_finalize": (c_int, [ctypes.POINTER(c_void_p), IP, c_int, P, c_int, P]),
     "aesr_lerp_fwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
     "aesr_lerp_bwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
     "aesr_mse_fwd": (c_int, [P, P, P, P, c_size_t, P]),
@@ -49,6 +55,7 @@ ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 BN_NONE, BN_POOL, BN_UP = 0, 1, 2
 BN_NWG = 256
 MSE_NPART = 512
+LPIPS_NCH = 64
 
 
 def _load():

@@ -234,6 +234,18 @@ int aesr_conv2d_smallcin_wgrad(const float* in, const float* dout, float* dw, fl
     return aesr_launch_sum_partials(workspace, SMALL_WGRAD_NWG, Cout * (Cin + 1), dw, Cout * Cin, db, (hipStream_t)stream);
 }
 
+int aesr_conv2d_cout1_fwd(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int Cin, int act,
+                          float slope, void* stream) {
+    AESR_CHECK_ARG(x && w && out && N > 0 && H > 0 && W > 0, "aesr_conv2d_cout1_fwd: null pointer or empty shape");
+    AESR_CHECK_ARG(Cin > 0 && Cin % 4 == 0 && Cin <= 256, "aesr_conv2d_cout1_fwd: Cin=%d must be a multiple of 4 (<= 256)", Cin);
+    Cout1FwdArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.out = out; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.act = act; a.slope = slope;
+    a.TH = H < 16 ? H : 16; a.TW = W < 16 ? W : 16;
+    while (((size_t)(a.TH + 2) * (a.TW + 2) * (Cin + 4) + 9 * Cin) * 4 > 64 * 1024 && a.TH > 1) a.TH /= 2;
+    a.tiles_y = ceil_div(H, a.TH); a.tiles_x = ceil_div(W, a.TW);
+    return aesr_launch_cout1_fwd(a, (hipStream_t)stream);
+}
+
 int aesr_conv2d_cout1_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W,
                             int Cin, void* stream) {
     AESR_CHECK_ARG(x && dy && dw && db && workspace, "aesr_conv2d_cout1_wgrad: null pointer");
@@ -306,6 +318,32 @@ int aesr_bn_bwd_apply(const float* gout, const float* y, const float* mean, cons
     a.N = N; a.H = H; a.W = W; a.C = C; a.mode = mode; a.act = act; a.slope = slope;
     bn_out_dims(H, W, mode, &a.Ho, &a.Wo);
     return aesr_launch_bn_bwd_apply(a, (hipStream_t)stream);
+}
+
+int aesr_maxpool2_fwd(const float* x, float* out, int N, int H, int W, int C, void* stream) {
+    AESR_CHECK_ARG(x && out && N > 0 && H >= 2 && W >= 2 && C % 4 == 0, "aesr_maxpool2_fwd: bad arguments (C %% 4 == 0, H,W >= 2)");
+    return aesr_launch_maxpool2_fwd(x, out, N, H, W, C, (hipStream_t)stream);
+}
+
+int aesr_maxpool2_bwd(const float* gout, const float* x, const float* gadd, float* dx, int N, int H, int W, int C, int relu_mask,
+                      void* stream) {
+    AESR_CHECK_ARG(gout && x && dx && N > 0 && H >= 2 && W >= 2 && C % 4 == 0, "aesr_maxpool2_bwd: bad arguments");
+    return aesr_launch_maxpool2_bwd(gout, x, gadd, dx, N, H, W, C, relu_mask, (hipStream_t)stream);
+}
+
+int aesr_lpips_tap_fwd(const float* f, const float* lin_w, float* partial, int B, int HW, int C, void* stream) {
+    AESR_CHECK_ARG(f && lin_w && partial && B > 0 && HW > 0, "aesr_lpips_tap_fwd: bad arguments");
+    return aesr_launch_lpips_tap_fwd(f, lin_w, partial, B, HW, C, (hipStream_t)stream);
+}
+
+int aesr_lpips_tap_bwd(const float* f, const float* lin_w, const float* gd, float* gf0, int B, int HW, int C, void* stream) {
+    AESR_CHECK_ARG(f && lin_w && gd && gf0 && B > 0 && HW > 0, "aesr_lpips_tap_bwd: bad arguments");
+    return aesr_launch_lpips_tap_bwd(f, lin_w, gd, gf0, B, HW, C, (hipStream_t)stream);
+}
+
+int aesr_lpips_finalize(const float* const* partials_host, const int* hw_host, int ntaps, float* d, int B, void* stream) {
+    AESR_CHECK_ARG(partials_host && hw_host && d && ntaps >= 1 && ntaps <= 8 && B > 0, "aesr_lpips_finalize: bad arguments");
+    return aesr_launch_lpips_finalize(partials_host, hw_host, ntaps, d, B, (hipStream_t)stream);
 }
 
 int aesr_lerp_fwd(const float* z, const float* a_from, const float* a_to, float* zmix, int B, size_t per, void* stream) {

@@ -43,6 +43,12 @@ struct Cout1WgradArgs {
     const float* x; const float* dy; float* partial;
     int N, H, W, Cin, TH, TW, tiles_y, tiles_x, ntiles;
 };
+struct Cout1FwdArgs {
+    const float* x; const float* w; const float* bias; float* out;
+    int N, H, W, Cin, TH, TW, tiles_y, tiles_x, act;
+    float slope;
+};
+int aesr_launch_cout1_fwd(const Cout1FwdArgs& a, hipStream_t st);
 int aesr_launch_smallcin_fwd(const SmallArgs& a, hipStream_t st);
 int aesr_launch_smallcin_dgrad(const SmallDgradArgs& a, hipStream_t st);
 int aesr_launch_sum_partials(const float* partial, int np, int n, float* out0, int n0, float* out1, hipStream_t st);
@@ -80,3 +86,9 @@ int aesr_launch_act_bwd(const float* dout, const float* y, float* dpre, size_t n
 int aesr_launch_adam(float* p, const float* g, float* m, float* v, float* state, size_t n, float lr, float beta1, float beta2,
                      float eps, float wd, hipStream_t st);
 
+
+int aesr_launch_maxpool2_fwd(const float* x, float* out, int N, int H, int W, int C, hipStream_t st);
+int aesr_launch_maxpool2_bwd(const float* gout, const float* x, const float* gadd, float* dx, int N, int H, int W, int C, int relu, hipStream_t st);
+int aesr_launch_lpips_tap_fwd(const float* f, const float* lin, float* partial, int B, int HW, int C, hipStream_t st);
+int aesr_launch_lpips_tap_bwd(const float* f, const float* lin, const float* gd, float* gf0, int B, int HW, int C, hipStream_t st);
+int aesr_launch_lpips_finalize(const float* const* partials, const int* hw, int ntaps, float* d, int B, hipStream_t st);

@@ -52,13 +52,22 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 }
 
 // sums[g][2][C] (double) = sum_wg partial[g][wg][2][C]
-__global__ void bn_reduce_kernel(const float* __restrict__ partial, double* __restrict__ sums, int nwg, int C, int G) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= G * 2 * C) return;
-    const int g = o / (2 * C), r = o - g * 2 * C;
+// block = 64 columns x 4 row-lanes: coalesced across columns, fixed summation order (bitwise reproducible)
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ partial, double* __restrict__ sums, int nwg,
+                                                        int C, int G) {
+    __shared__ double red[4][64];
+    const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + col;
+    const int n = G * 2 * C;
     double s = 0.0;
-    for (int k = 0; k < nwg; ++k) s += (double)partial[((size_t)g * nwg + k) * 2 * C + r];
-    sums[o] = s;
+    if (o < n) {
+        const int g = o / (2 * C), r = o - g * 2 * C;
+        const float* base = partial + (size_t)g * nwg * 2 * C + r;
+        for (int k = rl; k < nwg; k += 4) s += (double)base[(size_t)k * 2 * C];
+    }
+    red[rl][col] = s;
+    __syncthreads();
+    if (rl == 0 && o < n) sums[o] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
 // train: stats from sums/counts (+ running update, group after group); eval: stats from the running buffers
@@ -237,7 +246,7 @@ int aesr_launch_bn_stats(const float* y, float* partial, int HW, int C, const Bn
 }
 
 int aesr_launch_bn_reduce(const float* partial, double* sums, int nwg, int C, int G, hipStream_t st) {
-    hipLaunchKernelGGL(bn_reduce_kernel, dim3(ceil_div(G * 2 * C, 256)), dim3(256), 0, st, partial, sums, nwg, C, G);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3(ceil_div(G * 2 * C, 64)), dim3(256), 0, st, partial, sums, nwg, C, G);
     AESR_LAUNCH_CHECK("bn_reduce");
     return AESR_OK;
 }

@@ -43,6 +43,98 @@ __global__ __launch_bounds__(256) void conv_smallcin_fwd_kernel(SmallArgs a) {
     }
 }
 
+// Same op, one thread = one output pixel x 4 consecutive couts (Cout % 4 == 0): 16-byte stores, 32-bit index math.
+__global__ __launch_bounds__(256) void conv_smallcin_fwd4_kernel(SmallArgs a) {
+    const int C4 = a.Cout >> 2;
+    const int total = a.N * a.Ho * a.Wo * C4;
+    const int cmem = a.bcast ? 1 : a.Cin;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int c4 = idx % C4;
+        int pix = idx / C4;
+        const int x = pix % a.Wo;
+        pix /= a.Wo;
+        const int y = pix % a.Ho;
+        const int n = pix / a.Ho;
+        f32x4 s = a.bias ? *(const f32x4*)(a.bias + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < a.KS; ++ky) {
+            const int gy = y + ky - a.pad;
+            if (gy < 0 || gy >= a.H) continue;
+            for (int kx = 0; kx < a.KS; ++kx) {
+                const int gx = x + kx - a.pad;
+                if (gx < 0 || gx >= a.W) continue;
+                const float* ip = a.in + ((size_t)(n * a.H + gy) * a.W + gx) * cmem;
+                for (int ci = 0; ci < a.Cin; ++ci) {
+                    const float v = a.bcast ? a.ca[ci] * ip[0] + a.cb[ci] : ip[ci];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = c4 * 4 + e;
+                        const float wv = a.transpose
+                                             ? a.w[((ci * a.Cout + co) * a.KS + (a.KS - 1 - ky)) * a.KS + (a.KS - 1 - kx)]
+                                             : a.w[((co * a.Cin + ci) * a.KS + ky) * a.KS + kx];
+                        s[e] = fmaf(v, wv, s[e]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = act_apply(s[e], a.act, a.slope);
+        if (a.ysave) {
+            const f32x4 ys = *(const f32x4*)(a.ysave + (size_t)idx * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] *= act_grad_from_output(ys[e], a.mask_act, a.slope);
+        }
+        *(f32x4*)(a.out + (size_t)idx * 4) = s;
+    }
+}
+
+// Cout == 1, 3x3 pad 1 output convolution (networks/acai_vanilla.py:98): bandwidth-bound; one thread per output pixel,
+// the input patch (tile + halo, all Cin channels) staged once in LDS, weights broadcast from LDS.
+__global__ __launch_bounds__(256) void conv_cout1_fwd_kernel(Cout1FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int PW = a.TW + 2, PH = a.TH + 2, PP = PH * PW, TP = a.TH * a.TW;
+    const int CS = a.Cin + 4, C4 = a.Cin >> 2;
+    float* ldsP = lds;               // [PP][CS]
+    float* ldsW = lds + PP * CS;     // [9][Cin]
+    int tile = blockIdx.x;
+    const int tx = tile % a.tiles_x;
+    tile /= a.tiles_x;
+    const int ty = tile % a.tiles_y;
+    const int n = tile / a.tiles_y;
+    const int y0 = ty * a.TH, x0 = tx * a.TW;
+    for (int q = threadIdx.x; q < PP * C4; q += 256) {
+        const int p = q / C4, part = q - p * C4;
+        const int gy = y0 + p / PW - 1, gx = x0 + p % PW - 1;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            v = *(const f32x4*)(a.x + ((size_t)(n * a.H + gy) * a.W + gx) * a.Cin + part * 4);
+        *(f32x4*)(ldsP + p * CS + part * 4) = v;
+    }
+    for (int q = threadIdx.x; q < 9 * a.Cin; q += 256) {
+        const int tap = q / a.Cin, ci = q - tap * a.Cin;
+        ldsW[q] = a.w[ci * 9 + tap];
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < TP; p += 256) {
+        const int r = p / a.TW, c = p - r * a.TW;
+        const int y = y0 + r, x = x0 + c;
+        if (y >= a.H || x >= a.W) continue;
+        float s = a.bias ? a.bias[0] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float* pp = ldsP + ((r + t / 3) * PW + c + t % 3) * CS;
+            const float* ww = ldsW + t * a.Cin;
+            for (int k = 0; k < C4; ++k) {
+                const f32x4 v = *(const f32x4*)(pp + k * 4), wv = *(const f32x4*)(ww + k * 4);
+                s = fmaf(v[0], wv[0], s);
+                s = fmaf(v[1], wv[1], s);
+                s = fmaf(v[2], wv[2], s);
+                s = fmaf(v[3], wv[3], s);
+            }
+        }
+        a.out[(size_t)(n * a.H + y) * a.W + x] = act_apply(s, a.act, a.slope);
+    }
+}
+
 // dx[n,y,x,ci] = sum_{ky,kx,co} dy[n,y+pad-ky,x+pad-kx,co] * w[co,ci,ky,kx]      (forward conv stride 1)
 // bcast: the forward input was 1 channel expanded by c -> ca[c]*x+cb[c]; returns dx1 = sum_c ca[c]*dx[c]
 
@@ -176,18 +268,40 @@ __global__ __launch_bounds__(256) void conv_cout1_wgrad_kernel(Cout1WgradArgs a)
 }
 
 // out[o] = sum_p partial[p][o]  (fixed order; double accumulate), optional second output split at n0
+// block = 64 columns x 4 row-lanes
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int np, int n,
                                                            float* __restrict__ out0, int n0, float* __restrict__ out1) {
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= n) return;
+    __shared__ double red[4][64];
+    const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + col;
     double s = 0.0;
-    for (int p = 0; p < np; ++p) s += (double)partial[(size_t)p * n + o];
-    if (o < n0) out0[o] = (float)s;
-    else out1[o - n0] = (float)s;
+    if (o < n)
+        for (int p = rl; p < np; p += 4) s += (double)partial[(size_t)p * n + o];
+    red[rl][col] = s;
+    __syncthreads();
+    if (rl == 0 && o < n) {
+        s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        if (o < n0) out0[o] = (float)s;
+        else out1[o - n0] = (float)s;
+    }
+}
+
+int aesr_launch_cout1_fwd(const Cout1FwdArgs& a, hipStream_t st) {
+    const size_t shmem = ((size_t)(a.TH + 2) * (a.TW + 2) * (a.Cin + 4) + 9 * a.Cin) * sizeof(float);
+    hipLaunchKernelGGL(conv_cout1_fwd_kernel, dim3(a.N * a.tiles_y * a.tiles_x), dim3(256), shmem, st, a);
+    AESR_LAUNCH_CHECK("conv_cout1_fwd");
+    return AESR_OK;
 }
 
 int aesr_launch_smallcin_fwd(const SmallArgs& a, hipStream_t st) {
     const size_t total = (size_t)a.N * a.Ho * a.Wo * a.Cout;
+    if (a.Cout % 4 == 0 && total < (size_t)1 << 31) {
+        int grid4 = (int)((total / 4 + 255) / 256);
+        if (grid4 > 16384) grid4 = 16384;
+        hipLaunchKernelGGL(conv_smallcin_fwd4_kernel, dim3(grid4), dim3(256), 0, st, a);
+        AESR_LAUNCH_CHECK("conv_smallcin_fwd4");
+        return AESR_OK;
+    }
     int grid = (int)((total + 255) / 256);
     if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(conv_smallcin_fwd_kernel, dim3(grid), dim3(256), 0, st, a);
@@ -205,7 +319,7 @@ int aesr_launch_smallcin_dgrad(const SmallDgradArgs& a, hipStream_t st) {
 }
 
 int aesr_launch_sum_partials(const float* partial, int np, int n, float* out0, int n0, float* out1, hipStream_t st) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, partial, np, n, out0, n0, out1);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(n, 64)), dim3(256), 0, st, partial, np, n, out0, n0, out1);
     AESR_LAUNCH_CHECK("sum_partials");
     return AESR_OK;
 }

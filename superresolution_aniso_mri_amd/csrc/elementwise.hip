@@ -46,12 +46,13 @@ __global__ __launch_bounds__(256) void sqdiff_partial_kernel(const float* __rest
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void mean_finalize_kernel(const double* __restrict__ partial, int np, double inv_n, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < np; ++i) s += partial[i];
-        *out = (float)(s * inv_n);
-    }
+__global__ __launch_bounds__(64) void mean_finalize_kernel(const double* __restrict__ partial, int np, double inv_n,
+                                                          float* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += 64) s += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (threadIdx.x == 0) *out = (float)(s * inv_n);
 }
 
 // da = 2*(a-b)*g/n  (g: device scalar, upstream gradient of the loss)

@@ -192,7 +192,10 @@ class SequentialRunner:
                 Ho, Wo = s.out_hw(H, W)
                 out = _empty((N, Ho, Wo, s.cout), x)
                 bias = s.mod.bias
-                if s.mfma_fwd:
+                if s.cout == 1 and s.ks == 3 and s.pad == 1 and s.cin % 4 == 0:
+                    check(lib.aesr_conv2d_cout1_fwd(ptr(cur), ptr(s.mod.weight), ptr(bias), ptr(out), N, H, W, s.cin, s.act,
+                                                    s.slope, stream()), "aesr_conv2d_cout1_fwd")
+                elif s.mfma_fwd:
                     _pb("conv_igemm_f32", 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
                     check(lib.aesr_conv2d_fwd(ptr(cur), ptr(s.packed), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, s.ks,
                                               s.pad, s.act, s.slope, stream()), "aesr_conv2d_fwd")

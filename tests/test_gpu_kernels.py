@@ -207,6 +207,20 @@ def test_cout1_conv_backward(hip):
     assert rel_l2(dw, w.grad) < 1e-5 and rel_l2(db, b.grad) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 24, 20, 32), (1, 160, 160, 32), (3, 9, 7, 8)])
+def test_cout1_conv_forward_sigmoid(hip, shape):
+    N, H, W, cin = shape
+    g = torch.Generator().manual_seed(H)
+    h = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(1, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    b = torch.randn(1, generator=g)
+    ref = torch.sigmoid(F.conv2d(h, w, b, padding=1))
+    out = torch.full((N, H, W, 1), float("nan"), device="cuda")
+    hip.check(hip.lib.aesr_conv2d_cout1_fwd(hip.ptr(D(nhwc(h))), hip.ptr(D(w)), hip.ptr(D(b)), hip.ptr(out), N, H, W, cin, 3, 0.0,
+                                            hip.stream()), "cout1_fwd")
+    assert rel_l2(nchw(out), ref) < 1e-6
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(6, 33, 31, 32), (4, 40, 40, 64), (3, 9, 9, 8)])
 def test_bn_groups_fwd_bwd(hip, mode, shape):
