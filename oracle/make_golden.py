@@ -284,3 +284,16 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# tests/golden/net_config.json (plugin table of networks/net_config.py for every (model, dataset, ae_class)) is produced by:
+#   python - <<'PY'
+#   import sys, json; sys.path.insert(0, '/root/reference'); import networks.net_config as nc
+#   rows = {}
+#   for net in ['ae','aesr','ae_combined','aesr_combined','vae','vae_combined','vae2','acai','acai_combined']:
+#       for ds in [None,'ACDC','ACDCLBL','dHCP','ADNI','OASIS','MNIST3D','MNISTRoto']:
+#           for ae in ['VanillaACAI','LargerAE','VanillaACAIStrided']:
+#               try: rows['%s|%s|%s' % (net, ds, ae)] = nc.NetworkConfig(net, dataset=ds, ae_class=ae).architecture
+#               except ValueError: rows['%s|%s|%s' % (net, ds, ae)] = 'ValueError'
+#   json.dump({'MODULE_PATH': nc.MODULE_PATH, 'rows': rows}, open('tests/golden/net_config.json', 'w'), indent=0, sort_keys=True)
+#   PY
