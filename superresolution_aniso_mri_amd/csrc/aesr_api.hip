@@ -40,8 +40,8 @@ static ConvPlan plan_conv(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
     ConvPlan p;
     cout_padding(Cout, &p.CoutP, &p.NB);
     p.CinP = round_up(Cin, 16);
-    p.MBW = (p.NB == 4) ? 4 : 8;
-    const int maxpix = 64 * p.MBW, maxpatch = 680;   // 680 px * 80 B = 54 KB -> 3 workgroups per CU
+    p.MBW = (p.NB == 4) ? 2 : 4;                     // M-blocks per wave; 8 waves per workgroup
+    const int maxpix = 128 * p.MBW, maxpatch = 760;  // 760 px * 80 B = 61 KB -> two workgroups per CU
     const int ncout = p.CoutP / (16 * p.NB);
     const double kmf = (double)KS * KS * (p.CinP / 16) * 4 * 32;   // MFMA cycles per (M-block, N-block)
     double best = 1e300;
@@ -52,7 +52,7 @@ static ConvPlan plan_conv(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
         if (TP > maxpix || PP > maxpatch) return;
         const int nblk = ceil_div(TP, 16);
         const long nwg = (long)ceil_div(N, TI) * ceil_div(Ho, TH) * ceil_div(Wo, TW) * ncout;
-        const double per = ceil_div(nblk, 4) * p.NB * kmf + (double)PP * (p.CinP / 16) * 6.0 + 1500.0;
+        const double per = ceil_div(nblk, 8) * 2 * p.NB * kmf + (double)PP * (p.CinP / 16) * 3.0 + 1500.0;
         const double rounds = nwg <= 2048 ? (double)ceil_div((int)nwg, 256) : (double)nwg / 256.0;
         const double t = per * rounds;
         if (t < best * 0.999 || (t < best * 1.001 && TP > p.TI * p.TH * p.TW)) {

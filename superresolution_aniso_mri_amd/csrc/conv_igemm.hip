@@ -21,124 +21,240 @@
 //
 // Replaces the ATen/cuDNN conv2d calls behind networks/acai_vanilla.py:55-56,68,70,87-88,96,98 and
 // lpips/pretrained_networks.py:107-116.
+#include <stdlib.h>
+
 #include "aesr_kernels.h"
 
 
-constexpr int IG_S = 20;   // LDS floats per patch pixel: 16 channels + 4 pad (80 B keeps b128 alignment)
+constexpr int IG_S = 20;     // LDS floats per patch pixel: 16 channels + 4 pad (80 B keeps b128 alignment)
+constexpr int IG_NT = 512;   // threads per workgroup: 8 waves = 2 per SIMD from ONE workgroup (they fill each other's issue gaps)
+constexpr int IG_NW = IG_NT / 64;
+constexpr int IG_MAXP = 6;   // staging pieces (16 B) per thread: patch pixels * 4 <= IG_NT * IG_MAXP
 
+// Persistent workgroups: each walks work items (spatial tile x cout tile) item, item+G, ...  The pixel->LDS maps are
+// position independent, so every integer division happens once per kernel.  Software pipeline per 16-channel chunk:
+//   barrier | registers -> LDS | barrier | issue global loads of the NEXT chunk (or next item) | 9 taps of MFMAs
+// so HBM/L2 latency of the patch hides behind ~18k cycles of matrix work; weight fragments are prefetched one tap ahead.
+// MFMA operand roles: A = weights (M = 16 couts), B = activations (N = 16 pixels): a lane's 4 accumulator registers are
+// 4 CONSECUTIVE couts of one pixel -> bias/activation/mask/store of the epilogue are 16-byte wide.
 template <int KS, int NB, int MBW>
-__global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a) {
+__global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-
-    int tile = blockIdx.x;
-    const int tx = tile % a.tiles_x;
-    tile /= a.tiles_x;
-    const int ty = tile % a.tiles_y;
-    const int ti = tile / a.tiles_y;
-    const int n0 = ti * a.TI, y0 = ty * a.TH, x0 = tx * a.TW;
-    const int co0 = blockIdx.y * (16 * NB);
+    const int G = gridDim.x;
+    const int nitems = a.nitems, ncot = a.CoutP / (16 * NB);
 
     const int PW = a.TW + KS - 1, PH = a.TH + KS - 1;
     const int PPI = PH * PW, PP = a.TI * PPI;
     const int TPI = a.TH * a.TW, TP = a.TI * TPI;
-    const int nblk = (TP + 15) >> 4;
+    const int nbl = a.nbl;                    // M-blocks per wave (ceil(nblk / IG_NW)), wave-uniform by construction
+    const int nchunks = a.CinP >> 4;
+    const int tapstride = (a.CinP >> 2) * a.CoutP * 4;
+    const int chunkstride = 4 * a.CoutP * 4;
 
-    int a_off[MBW];
-    int my_nblk = 0;
+    // ---- position-independent maps (computed once) ------------------------------------------------------------
+    int a_off[MBW], pix[MBW];                 // pix = img<<20 | r<<10 | c of this lane's pixel of block i, or -1
 #pragma unroll
     for (int i = 0; i < MBW; ++i) {
-        const int blk = wave + 4 * i;
-        if (blk < nblk) my_nblk = i + 1;
-        int t = blk * 16 + l15;
-        if (t >= TP) t = 0;
-        const int img = t / TPI;
-        const int rem = t - img * TPI;
+        const int t = (wave + IG_NW * i) * 16 + l15;
+        const bool valid = t < TP;
+        const int tt = valid ? t : 0;
+        const int img = tt / TPI;
+        const int rem = tt - img * TPI;
         const int r = rem / a.TW;
         const int c = rem - r * a.TW;
         a_off[i] = (img * PPI + r * PW + c) * IG_S + 4 * g;
+        pix[i] = valid ? ((img << 20) | (r << 10) | c) : -1;
+    }
+    int piece[IG_MAXP];                        // img<<20 | pr<<10 | pc of the patch pixel of staging piece j, or -1
+#pragma unroll
+    for (int j = 0; j < IG_MAXP; ++j) {
+        const int q = tid + IG_NT * j;
+        int v = -1;
+        if (q < PP * 4) {
+            const int p = q >> 2;
+            const int img = p / PPI;
+            const int rem = p - img * PPI;
+            const int pr = rem / PW;
+            v = (img << 20) | (pr << 10) | (rem - pr * PW);
+        }
+        piece[j] = v;
+    }
+    const int part4 = (tid & 3) * 4;           // channel offset of this thread's pieces inside a chunk (q & 3 == tid & 3)
+
+    // ---- load state: (l_item, l_cc) is the chunk whose patch is in flight into R ----
+    int goff[IG_MAXP];
+    f32x4 R[IG_MAXP];
+    int l_item = blockIdx.x, l_cc = 0;
+    if (l_item >= nitems) return;
+
+#define IG_TILE_ORIGIN(item, n0, y0, x0, co0)                 \
+    {                                                         \
+        int tile_ = (item) / ncot;                            \
+        co0 = ((item) - tile_ * ncot) * (16 * NB);            \
+        const int tx_ = tile_ % a.tiles_x;                    \
+        tile_ /= a.tiles_x;                                   \
+        const int ty_ = tile_ % a.tiles_y;                    \
+        n0 = (tile_ / a.tiles_y) * a.TI;                      \
+        y0 = ty_ * a.TH;                                      \
+        x0 = tx_ * a.TW;                                      \
+    }
+#define IG_COMPUTE_GOFF(item)                                                                                     \
+    {                                                                                                             \
+        int n0_, y0_, x0_, co0_;                                                                                  \
+        IG_TILE_ORIGIN(item, n0_, y0_, x0_, co0_)                                                                 \
+        (void)co0_;                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < IG_MAXP; ++j) {                                                     \
+            int go = -2;                                                                                          \
+            if (piece[j] >= 0) {                                                                                  \
+                const int n = n0_ + (piece[j] >> 20), gy = y0_ + ((piece[j] >> 10) & 1023) - a.pad;               \
+                const int gx = x0_ + (piece[j] & 1023) - a.pad;                                                   \
+                go = (n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? ((n * a.H + gy) * a.W + gx) * a.Cin + part4 : -1; \
+            }                                                                                                     \
+            goff[j] = go;                                                                                         \
+        }                                                                                                         \
+    }
+#define IG_ISSUE_LOADS(cc)                                                                                  \
+    {                                                                                                       \
+        const bool chan_ok = (cc) * 16 + part4 < a.Cin;                                                     \
+        _Pragma("unroll") for (int j = 0; j < IG_MAXP; ++j) {                                               \
+            R[j] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                             \
+            if (goff[j] >= 0 && chan_ok && !(a.dbg & 1)) R[j] = *(const f32x4*)(a.in + goff[j] + (cc) * 16); \
+        }                                                                                                   \
     }
 
+    IG_COMPUTE_GOFF(l_item)
+    IG_ISSUE_LOADS(0)
+
+    // ---- compute state ----
+    int c_item = blockIdx.x, cc = 0;
+    int cn0, cy0, cx0, co0;
+    IG_TILE_ORIGIN(c_item, cn0, cy0, cx0, co0)
     f32x4 acc[MBW][NB];
 #pragma unroll
     for (int i = 0; i < MBW; ++i)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[i][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* wlane = a.wpk + (g * a.CoutP + l15) * 4;        // + co0*4 + cc*chunkstride + tap*tapstride + nb*64
+    f32x4 bcur[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bcur[nb] = *(const f32x4*)(wlane + co0 * 4 + nb * 64);
 
-    const int nchunks = a.CinP >> 4;
-    const size_t tapstride = (size_t)(a.CinP >> 2) * a.CoutP * 4;
-
-    for (int cc = 0; cc < nchunks; ++cc) {
-        // ---- stage the 16-channel slice of the input patch (zero-filled outside the image) ----
-        for (int q = tid; q < PP * 4; q += 256) {
-            const int p = q >> 2, part = q & 3;
-            const int img = p / PPI;
-            const int rem = p - img * PPI;
-            const int pr = rem / PW;
-            const int pc = rem - pr * PW;
-            const int n = n0 + img, gy = y0 + pr - a.pad, gx = x0 + pc - a.pad;
-            const int ci = cc * 16 + part * 4;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci < a.Cin)
-                v = *(const f32x4*)(a.in + (((size_t)n * a.H + gy) * a.W + gx) * a.Cin + ci);
-            *(f32x4*)(lds + p * IG_S + part * 4) = v;
-        }
+    bool first = true;
+    while (true) {
+        if (!first) __syncthreads();           // every wave has finished reading the previous chunk from LDS
+        first = false;
+#pragma unroll
+        for (int j = 0; j < IG_MAXP; ++j)
+            if (piece[j] >= 0) *(f32x4*)(lds + ((tid + IG_NT * j) >> 2) * IG_S + part4) = R[j];
         __syncthreads();
+        // advance the load state and put the next patch chunk in flight
+        if (l_cc + 1 < nchunks) {
+            ++l_cc;
+        } else {
+            l_item += G;
+            l_cc = 0;
+            if (l_item < nitems) IG_COMPUTE_GOFF(l_item)
+        }
+        if (l_item < nitems) IG_ISSUE_LOADS(l_cc)
 
-        const float* wc = a.wpk + ((size_t)(cc * 4 + g) * a.CoutP + co0 + l15) * 4;
+        const bool last_chunk = (cc + 1 == nchunks);
+        const float* wc = wlane + co0 * 4 + cc * chunkstride;
 #pragma unroll
         for (int tap = 0; tap < KS * KS; ++tap) {
-            const int tap_off = ((tap / KS) * PW + (tap % KS)) * IG_S;
-            f32x4 b[NB];
+            // prefetch the NEXT tap's weight fragments (next chunk / next item at the end) under this tap's MFMAs
+            f32x4 bnxt[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) b[nb] = *(const f32x4*)(wc + (size_t)tap * tapstride + nb * 64);
+            for (int nb = 0; nb < NB; ++nb) bnxt[nb] = bcur[nb];
+            if (a.dbg & 2) {
+            } else if (tap + 1 < KS * KS) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bnxt[nb] = *(const f32x4*)(wc + (tap + 1) * tapstride + nb * 64);
+            } else if (!last_chunk) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bnxt[nb] = *(const f32x4*)(wc + chunkstride + nb * 64);
+            } else if (c_item + G < nitems) {
+                const int nco0 = ((c_item + G) % ncot) * (16 * NB);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bnxt[nb] = *(const f32x4*)(wlane + nco0 * 4 + nb * 64);
+            }
+            const int tap_off = ((tap / KS) * PW + (tap % KS)) * IG_S;
+            f32x4 acur = *(const f32x4*)(lds + a_off[0] + tap_off);
 #pragma unroll
             for (int i = 0; i < MBW; ++i) {
-                if (i < my_nblk) {
-                    const f32x4 av = *(const f32x4*)(lds + a_off[i] + tap_off);
+                if (i < nbl) {
+                    f32x4 anxt = acur;
+                    if (i + 1 < MBW && i + 1 < nbl) anxt = *(const f32x4*)(lds + a_off[i + 1 < MBW ? i + 1 : i] + tap_off);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
-                            acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], b[nb][r], acc[i][nb], 0, 0, 0);
+                            acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[nb][r], acur[r], acc[i][nb], 0, 0, 0);
+                    acur = anxt;
                 }
             }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bcur[nb] = bnxt[nb];
         }
-        __syncthreads();
-    }
 
-    // ---- epilogue: C/D layout of 16x16x4: column (cout) = lane&15, row (pixel) = 4*(lane>>4)+j ----
+        if (!last_chunk) {
+            ++cc;
+            continue;
+        }
+        // ---- epilogue of c_item: D layout of 16x16x4: column (pixel) = lane&15, row (cout) = 4*(lane>>4)+j ----
+        const bool vec = (a.Cout & 3) == 0;
 #pragma unroll
-    for (int i = 0; i < MBW; ++i) {
-        if (i < my_nblk) {
+        for (int i = 0; i < MBW; ++i) {
+            if (i < nbl && pix[i] >= 0 && !(a.dbg & 4)) {
+                const int n = cn0 + (pix[i] >> 20), y = cy0 + ((pix[i] >> 10) & 1023), x = cx0 + (pix[i] & 1023);
+                if (n < a.N && y < a.Ho && x < a.Wo) {
+                    const int ob = ((n * a.Ho + y) * a.Wo + x) * a.Cout;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int t = (wave + 4 * i) * 16 + g * 4 + j;
-                if (t < TP) {
-                    const int img = t / TPI;
-                    const int rem = t - img * TPI;
-                    const int r = rem / a.TW;
-                    const int c = rem - r * a.TW;
-                    const int n = n0 + img, y = y0 + r, x = x0 + c;
-                    if (n < a.N && y < a.Ho && x < a.Wo) {
-                        const size_t obase = (((size_t)n * a.Ho + y) * a.Wo + x) * a.Cout;
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            const int co = co0 + nb * 16 + l15;
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int co = co0 + nb * 16 + 4 * g;
+                        f32x4 v = acc[i][nb];
+                        if (vec) {
                             if (co < a.Cout) {
-                                float v = acc[i][nb][j];
-                                if (a.bias) v += a.bias[co];
-                                v = act_apply(v, a.act, a.slope);
-                                if (a.ysave) v *= act_grad_from_output(a.ysave[obase + co], a.mask_act, a.slope);
-                                a.out[obase + co] = v;
+                                if (a.bias) v += *(const f32x4*)(a.bias + co);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act, a.slope);
+                                if (a.ysave) {
+                                    const f32x4 ys = *(const f32x4*)(a.ysave + ob + co);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_output(ys[e], a.mask_act, a.slope);
+                                }
+                                *(f32x4*)(a.out + ob + co) = v;
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (co + e < a.Cout) {
+                                    float s = v[e];
+                                    if (a.bias) s += a.bias[co + e];
+                                    s = act_apply(s, a.act, a.slope);
+                                    if (a.ysave) s *= act_grad_from_output(a.ysave[ob + co + e], a.mask_act, a.slope);
+                                    a.out[ob + co + e] = s;
+                                }
                             }
                         }
                     }
                 }
             }
         }
+        c_item += G;
+        if (c_item >= nitems) break;
+        cc = 0;
+        IG_TILE_ORIGIN(c_item, cn0, cy0, cx0, co0)
+#pragma unroll
+        for (int i = 0; i < MBW; ++i)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[i][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+#undef IG_TILE_ORIGIN
+#undef IG_COMPUTE_GOFF
+#undef IG_ISSUE_LOADS
 }
 
 // ---- weight packing --------------------------------------------------------------------------------
@@ -179,7 +295,7 @@ int aesr_launch_pack_weights(const float* w, float* p, int Cout, int Cin, int KS
 }
 
 template <int KS, int NB, int MBW>
-static int launch_one(const IgemmArgs& a, int ntiles, hipStream_t st) {
+static int launch_one(const IgemmArgs& a, hipStream_t st) {
     const int PP = a.TI * (a.TH + KS - 1) * (a.TW + KS - 1);
     const size_t shmem = (size_t)PP * IG_S * sizeof(float);
     if (shmem > 160 * 1024) {
@@ -191,28 +307,47 @@ static int launch_one(const IgemmArgs& a, int ntiles, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_f32<KS, NB, MBW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    dim3 grid(ntiles, a.CoutP / (16 * NB));
-    hipLaunchKernelGGL((conv_igemm_f32<KS, NB, MBW>), grid, dim3(256), shmem, st, a);
+    int grid = 2 * 256;                       // persistent: up to two 8-wave workgroups per CU
+    if (grid > a.nitems) grid = a.nitems;
+    hipLaunchKernelGGL((conv_igemm_f32<KS, NB, MBW>), dim3(grid), dim3(IG_NT), shmem, st, a);
     AESR_LAUNCH_CHECK("conv_igemm_f32");
     return AESR_OK;
 }
 
-int aesr_launch_conv_igemm(const IgemmArgs& a, int KS, int NB, int MBW, hipStream_t st) {
+int aesr_launch_conv_igemm(const IgemmArgs& a_in, int KS, int NB, int MBW, hipStream_t st) {
+    IgemmArgs a = a_in;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("AESR_IGEMM_DBG"); dbg = e ? atoi(e) : 0; }
+    a.dbg = dbg;
     const int TP = a.TI * a.TH * a.TW;
     const int nblk = (TP + 15) / 16;
-    if (nblk > 4 * MBW) {
-        aesr_set_error("conv_igemm: tile of %d pixels needs %d M-blocks > 4*MBW=%d", TP, nblk, 4 * MBW);
+    a.nbl = (nblk + IG_NW - 1) / IG_NW;
+    if (nblk > IG_NW * MBW) {
+        aesr_set_error("conv_igemm: tile of %d pixels needs %d M-blocks > %d", TP, nblk, IG_NW * MBW);
         return AESR_ERR_ARG;
     }
     if (a.CoutP % (16 * NB) != 0 || a.CinP % 16 != 0 || a.Cin % 4 != 0) {
         aesr_set_error("conv_igemm: bad channel padding Cin=%d CinP=%d CoutP=%d NB=%d", a.Cin, a.CinP, a.CoutP, NB);
         return AESR_ERR_ARG;
     }
-    const int ntiles = ceil_div(a.N, a.TI) * a.tiles_y * a.tiles_x;
+    const int PPc = a.TI * (a.TH + KS - 1) * (a.TW + KS - 1);
+    if (PPc * 4 > IG_NT * IG_MAXP) {
+        aesr_set_error("conv_igemm: patch of %d pixels exceeds the staging capacity", PPc);
+        return AESR_ERR_ARG;
+    }
+    if ((size_t)a.N * a.H * a.W * a.Cin >= ((size_t)1 << 31) || (size_t)a.N * a.Ho * a.Wo * a.Cout >= ((size_t)1 << 31)) {
+        aesr_set_error("conv_igemm: tensors beyond 2^31 elements need 64-bit indexing (not built)");
+        return AESR_ERR_UNSUPPORTED;
+    }
+    a.nitems = ceil_div(a.N, a.TI) * a.tiles_y * a.tiles_x * (a.CoutP / (16 * NB));
+    if (a.TH + KS - 1 > 1023 || a.TW + KS - 1 > 1023 || a.TI > 1023) {
+        aesr_set_error("conv_igemm: tile dimensions exceed the packed-coordinate range");
+        return AESR_ERR_ARG;
+    }
 #define IG_CASE(ks, nb, mbw) \
-    if (KS == ks && NB == nb && MBW == mbw) return launch_one<ks, nb, mbw>(a, ntiles, st);
-    IG_CASE(3, 1, 4) IG_CASE(3, 1, 8) IG_CASE(3, 2, 4) IG_CASE(3, 2, 8) IG_CASE(3, 4, 4) IG_CASE(3, 4, 8)
-    IG_CASE(1, 1, 4) IG_CASE(1, 1, 8) IG_CASE(1, 2, 4) IG_CASE(1, 2, 8) IG_CASE(1, 4, 4) IG_CASE(1, 4, 8)
+    if (KS == ks && NB == nb && MBW == mbw) return launch_one<ks, nb, mbw>(a, st);
+    IG_CASE(3, 1, 4) IG_CASE(3, 2, 4) IG_CASE(3, 4, 2)
+    IG_CASE(1, 1, 4) IG_CASE(1, 2, 4) IG_CASE(1, 4, 2)
 #undef IG_CASE
     aesr_set_error("conv_igemm: no instantiation for KS=%d NB=%d MBW=%d", KS, NB, MBW);
     return AESR_ERR_UNSUPPORTED;
