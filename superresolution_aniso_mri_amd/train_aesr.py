@@ -1,0 +1,115 @@
+"""Training loop of ``train_cardiac_aesr.py`` / ``train_brain_aesr.py`` (reference train_cardiac_aesr.py:119-214,
+train_brain_aesr.py:137-206) for the MI355X build: same flags, output layout (settings.yaml, models/<epoch>.models,
+log_images/, loss*.npz) and epoch bookkeeping (iters starts at 1, validate when (iters+1) % num_it_per_epoch == 0).
+
+Data: the reference's SimpleITK/NIfTI dataset readers and numpy augmentations are host-side I/O outside this build's
+hot path; ``--synthetic`` feeds device-resident synthetic triplets in the same batch layout.  Launch under
+``python -m torch.distributed.run --nproc-per-node N`` for data parallel training (one process per GPU, RCCL)."""
+import os
+from shutil import rmtree
+
+import numpy as np
+import torch
+
+from .data_synth import shard_batch, synthetic_batch
+from .kwatsch.arguments import parse_args
+from .kwatsch.common import saveExperimentSettings
+from .kwatsch.get_trainer import get_trainer_dynamic
+from .networks.net_config import NetworkConfig
+from .parallel import DataParallelContext
+
+
+def merge_args_architecture(args_dict, architecture):
+    """CLI wins unless the CLI value is None / absent (reference train_cardiac_aesr.py:23-30)."""
+    for key, value in architecture.items():
+        if key not in args_dict or args_dict[key] is None:
+            args_dict[key] = value
+    return args_dict
+
+
+def prepare_run(args, args_dict, writer):
+    out = args_dict["output_dir"]
+    if writer:
+        if not os.path.isdir(out):
+            os.makedirs(out, exist_ok=False)
+        elif args_dict["exper_id"] == "debug":
+            print("WARNING - prepare_run - Removing output dir {}".format(out))
+            rmtree(out)
+            os.makedirs(out, exist_ok=False)
+        else:
+            raise IsADirectoryError("ERROR - directory {} for experiment {} already exists. Remove first or choose another "
+                                    "exper_id".format(out, args_dict["exper_id"]))
+    args_dict["dir_images"] = os.path.join(out, "log_images")
+    args_dict["dir_models"] = os.path.join(out, "models")
+    if writer:
+        os.makedirs(args_dict["dir_images"], exist_ok=True)
+        os.makedirs(args_dict["dir_models"], exist_ok=True)
+        saveExperimentSettings(args, os.path.join(out, "settings.yaml"))
+
+
+def generate_epoch_range(args_dict):
+    if args_dict.get("model_filename"):
+        last = torch.load(os.path.expanduser(args_dict["model_filename"]), map_location="cpu")["epoch"]
+        return np.arange(last + 1, last + args_dict["epochs"] + 1)
+    return np.arange(1, args_dict["epochs"] + 1)
+
+
+def main(argv=None, brain=False):
+    args, args_dict = parse_args(argv)
+    cfg = NetworkConfig(args_dict["model"], dataset=args_dict["dataset"], ae_class=args_dict["ae_class"])
+    args_dict = merge_args_architecture(args_dict, cfg.architecture)
+    if not args_dict.get("synthetic"):
+        raise NotImplementedError(
+            "dataset '{}' needs the reference's SimpleITK/NIfTI readers, which are outside this build's hot path; run with "
+            "--synthetic (synthetic triplets in the same batch layout) or feed trainer.train() from your own loader".format(
+                args_dict["dataset"]))
+    dp = DataParallelContext()
+    if str(args_dict["device"]).startswith("cuda") and dp.world > 1:
+        args_dict["device"] = "cuda:%d" % dp.local_rank
+    if str(args_dict["device"]).startswith("cuda"):
+        dev = torch.device(args_dict["device"])
+        torch.cuda.set_device(dev.index if dev.index is not None else 0)
+    dp.device = args_dict["device"]
+    torch.manual_seed(args_dict["seed"])
+    prepare_run(args, args_dict, writer=(dp.rank == 0))
+    brain = brain or args_dict["dataset"] not in ("ACDC", "ACDCC", "ACDCLBL")
+    size = args_dict.get("synthetic_size") or args_dict["width"]
+    B = args_dict["batch_size"]
+
+    def make_batch(seed, n):
+        b = synthetic_batch(n, size, size, seed=seed, brain=brain)
+        return shard_batch(b, dp.rank, dp.world) if dp.active else b
+
+    trainer = get_trainer_dynamic(args_dict, model_file=args_dict["model_filename"])
+    if dp.active:
+        dp.attach(trainer)
+        dp.set_batch(B)
+    trainer.init_tensorboard(args_dict["output_dir"])
+    validation_batch = make_batch(args_dict["seed"] - 1, args_dict["test_batch_size"])
+    num_it_per_epoch = args_dict["iters_per_epoch"]
+    args.num_it_per_epoch = num_it_per_epoch
+    if dp.rank == 0:
+        saveExperimentSettings(args, os.path.join(args_dict["output_dir"], "settings.yaml"))
+    epoch, val_result, batch_item = 0, None, None
+    try:
+        for epoch in generate_epoch_range(args_dict):
+            trainer.reset_losses()
+            for it in range(num_it_per_epoch):
+                batch_item = make_batch(args_dict["seed"] + int(epoch) * 100003 + it, B)
+                do_validate = (trainer.iters + 1) % num_it_per_epoch == 0
+                trainer.train(batch_item, keep_predictions=do_validate)
+                if do_validate:
+                    val_result = trainer.validate(validation_batch, image_dict=None)
+                    trainer.show_loss_on_tensorboard()
+                    trainer.show_loss_on_tensorboard(eval_type="test")
+                    trainer.generate_train_images(epoch=int(epoch), batch_item=batch_item)
+                    if dp.rank == 0:
+                        print("epoch {:4d} it {:6d} loss_ae {:.6f} val {:.6f}".format(int(epoch), trainer.iters,
+                                                                                     trainer.mean_losses["loss_ae"][-1],
+                                                                                     trainer.mean_losses_test["loss_ae"][-1]))
+                    trainer.reset_losses()
+            trainer.end_epoch_processing(epoch=int(epoch), val_result_dict=val_result or {}, batch_item=batch_item)
+    except KeyboardInterrupt:
+        print("KeyboardInterrupt - Save model and exit")
+    trainer.save_models(os.path.join(args_dict["dir_models"], "{:0d}.models".format(int(epoch))), int(epoch))
+    return trainer

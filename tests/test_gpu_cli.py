@@ -1,0 +1,59 @@
+"""-m gpu: the drop-in scripts end to end on synthetic data: train_cardiac_aesr.py writes settings.yaml + .models,
+generate_hr_volumes.py reloads them through get_trainer_dynamic(src_path=..., model_nbr=...) and super-resolves a volume.
+Also BASELINE config 1 (MNIST-shaped 28x28, latent 16, B=32, LPIPS) as one trainer step against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_then_generate(tmp_path):
+    from superresolution_aniso_mri_amd import generate_hr_volumes, train_aesr
+    out = str(tmp_path / "expers")
+    tr = train_aesr.main(["--dataset=ACDC", "--model=ae_combined", "--batch_size=4", "--test_batch_size=4", "--latent=16",
+                          "--latent_width=8", "--width=32", "--depth=8", "--downsample_steps=2", "--epochs=2", "--lr=0.001",
+                          "--ex_loss_weight1=0.05", "--exper_id=t1", "--output_dir=" + out, "--synthetic", "--iters_per_epoch=3",
+                          "--image_mix_loss_func=mse", "--epoch_threshold=0"])
+    src = os.path.join(out, "t1")
+    assert os.path.isfile(os.path.join(src, "settings.yaml")) and os.path.isfile(os.path.join(src, "models", "2.models"))
+    assert tr.iters == 1 + 6 and len(tr.mean_losses["loss_ae"]) >= 1
+    assert os.path.isfile(os.path.join(src, "losses_train.npz"))
+    data = tmp_path / "vols"
+    data.mkdir()
+    np.save(str(data / "vol0.npy"), np.random.RandomState(0).rand(5, 32, 32).astype(np.float32) * 900.0)   # needs percentile normalisation
+    res = generate_hr_volumes.main(["--exper_dir=" + src, "--model_nbr=2", "--num_interpolations=3", "--data_input_dir=" + str(data),
+                                    "--output_dir=" + str(tmp_path / "hr"), "--save"])
+    hr = np.load(str(tmp_path / "hr" / "vol0.npy"))
+    assert hr.shape == (4 * 4 + 1, 32, 32) and hr.min() >= 0 and hr.max() <= 1 and len(res) == 1
+
+
+def test_config1_mnist_shaped_step_vs_oracle():
+    from oracle import ae_oracle, lpips_oracle, step_oracle
+    from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    from superresolution_aniso_mri_amd.networks.net_config import NetworkConfig
+    cfg = dict(width=28, latent_width=7, depth=32, latent=16, colors=1, use_batchnorm=True, use_sigmoid=True)
+    args = dict(model="ae_combined", dataset="MNISTRoto", device="cuda", lr=1e-5, weight_decay=0.0, epochs=2, ex_loss_weight1=0.001,
+                use_percept_loss=False, get_masks=False, use_loss_annealing=False, use_extra_latent_loss=False, epoch_threshold=100,
+                ae_class="VanillaACAI", image_mix_loss_func="perceptual", vgg_weights="synthetic-hash", **cfg)
+    for k, v in NetworkConfig("ae_combined", dataset="MNISTRoto").architecture.items():
+        args.setdefault(k, v)
+    torch.manual_seed(1)
+    trainer = get_trainer_dynamic(args)
+    assert type(trainer).__name__ == "AECombinedTrainerMNIST"
+    oracle = ae_oracle.OracleAE(cfg, init=False).load_state_dict({k: v.detach().cpu() for k, v in trainer.model.state_dict().items()})
+    lin = np.load(os.path.join(os.path.dirname(__file__), "..", "superresolution_aniso_mri_amd", "lpips", "weights", "v0.1", "vgg_lin.npz"))
+    ost = step_oracle.OracleStep(oracle, lr=1e-5, ex_loss_weight1=0.001, image_mix_loss_func="perceptual",
+                                 vgg_sd=lpips_oracle.hash_vgg16_state(),
+                                 lin_w=[torch.from_numpy(lin["lin%d" % k]).reshape(1, -1, 1, 1) for k in range(5)])
+    batch = synthetic_batch(32, 28, 28, seed=9, brain=True)
+    trainer.train(batch)
+    ref = ost.train(batch["image"], batch["slice_between"], batch["alpha_from"], batch["alpha_to"])
+    for key, want in (("loss_ae", ref["loss_ae"]), ("loss_ae_dist", ref["loss_ae_dist"]), ("loss_ae_dist_extra", ref["loss_ae_dist_extra"]),
+                      ("loss_latent_1", ref["loss_latent_1"])):
+        assert abs(trainer.losses[key][-1] - want) <= 3e-5 * abs(want), key
+    rel = float((trainer.train_predictions["reconstruction"].double() - ref["out"].double()).norm() / ref["out"].double().norm())
+    assert rel < 1e-5

@@ -1,0 +1,72 @@
+"""-m gpu: slice-synthesis inference (encode once -> lerp for every alpha -> one decode batch -> interleave -> clamp)
+against the vector produced by the reference's per-alpha re-encoding loop (tests/golden/supervolume.npz), plus the
+size-independent properties at a BASELINE size (256x256): original slices are passed through bit-exactly,
+alpha -> 0 / 1 limits, output count (z-1)(n+1)+1."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _trainer(args_extra, state=None):
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    from superresolution_aniso_mri_amd.networks.net_config import NetworkConfig
+    args = dict(model="ae_combined", dataset="ACDC", device="cuda", lr=1e-5, weight_decay=0.0, epochs=2, ex_loss_weight1=0.05,
+                use_percept_loss=False, get_masks=False, use_loss_annealing=False, use_extra_latent_loss=False, epoch_threshold=100,
+                ae_class="VanillaACAI", image_mix_loss_func="mse")
+    args.update(args_extra)
+    for k, v in NetworkConfig("ae_combined", dataset="ACDC").architecture.items():
+        args.setdefault(k, v)
+    tr = get_trainer_dynamic(args, eval_mode=True)
+    if state is not None:
+        tr.model.load_state_dict(state)
+    return tr
+
+
+def test_create_super_volume_vs_reference_loop():
+    from superresolution_aniso_mri_amd.generate_hr_volumes import create_super_volume, latent_space_interp
+    rec = dict(np.load(os.path.join(GOLDEN, "supervolume.npz")))
+    tr = _trainer(dict(width=32, latent_width=8, depth=8, latent=16), {k[2:]: torch.from_numpy(v) for k, v in rec.items() if k.startswith("p/")})
+    vol = torch.from_numpy(rec["vol"])
+    res = create_super_volume(tr, vol, rec["alpha_range"], use_original=True)
+    hr = res["upsampled_image"]
+    assert hr.shape == rec["hr"].shape and not hr.is_cuda and res["upsampled_labels"] is None
+    np.testing.assert_allclose(hr.numpy(), rec["hr"], rtol=1e-5, atol=2e-6)
+    # single-alpha helper, reference argument order (later slices first)
+    one = latent_space_interp(float(rec["alpha_range"][1]), tr, vol[1:], vol[:-1])["inter_image"]
+    np.testing.assert_allclose(one[:, 0].numpy().clip(0, 1), rec["hr"][2::4], rtol=1e-5, atol=2e-6)
+
+
+def test_super_volume_properties_at_dhcp_size():
+    """BASELINE config 5 shape (256x256, width=256 / latent_width=64 -> 2 pooling stages, latent 128)."""
+    from superresolution_aniso_mri_amd.generate_hr_volumes import create_super_volume
+    torch.manual_seed(3)
+    tr = _trainer(dict(width=256, latent_width=64, depth=32, latent=128))
+    Z, n = 6, 6
+    vol = torch.rand(Z, 1, 256, 256)
+    alphas = np.linspace(0, 1, n + 2)[1:-1]
+    hr = create_super_volume(tr, vol, alphas, use_original=True)["upsampled_image"]
+    assert hr.shape == ((Z - 1) * (n + 1) + 1, 256, 256)
+    assert torch.equal(hr[::n + 1], vol[:, 0])                       # originals untouched (already in [0,1])
+    assert float(hr.min()) >= 0 and float(hr.max()) <= 1
+    rec = create_super_volume(tr, vol, alphas, use_original=False)["upsampled_image"]
+    # alpha = 1 must reproduce the reconstruction of the LATER slice, alpha = 0 of the EARLIER one
+    lim = create_super_volume(tr, vol, [1.0, 0.0], use_original=False)["upsampled_image"]
+    np.testing.assert_allclose(lim[1::3][:Z - 1].numpy(), rec[n + 1::n + 1].numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(lim[2::3][:Z - 1].numpy(), rec[0:-1:n + 1].numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_patch_tiled_interpolation_matches_whole_image_on_tiles():
+    from superresolution_aniso_mri_amd.kwatsch.img_interpolation import latent_space_interp, latent_space_interp_diff_patch_size
+    torch.manual_seed(4)
+    tr = _trainer(dict(width=32, latent_width=8, depth=8, latent=16))
+    a, b = torch.rand(3, 1, 64, 64), torch.rand(3, 1, 64, 64)
+    tiled = latent_space_interp_diff_patch_size(0.25, tr, a, b, (32, 32))
+    assert tiled.shape == (3, 1, 64, 64)
+    # each 32x32 tile is an independent image for the network: compare the top-left tile
+    whole = latent_space_interp(0.75, tr, a[:, :, :32, :32], b[:, :, :32, :32])["inter_image"]     # alpha*enc(a)+(1-alpha)*enc(b)
+    np.testing.assert_allclose(tiled[:, :, :32, :32].numpy(), whole.numpy(), rtol=1e-5, atol=1e-6)
