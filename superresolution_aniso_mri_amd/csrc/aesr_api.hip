@@ -69,8 +69,10 @@ static ConvPlan plan_conv(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
     return p;
 }
 
-struct WgradPlan { int variant, ROWP, COT, WK, CinP, CoutP, TH, TW, S, nslab; size_t slab_floats; };
+struct WgradPlan { int variant, COT, CinP, CoutP, TH, TW, S, nslab, PWS, TWS, PSX, PSD; size_t slab_floats; };
 static std::map<std::tuple<int, int, int, int, int, int>, WgradPlan> g_wgrad_plans;
+
+static int plane_stride(int n) { return round_up(n, 64) + 4; }    // = 4 (mod 64): 16 channel planes hit 16 distinct bank quads
 
 static WgradPlan plan_wgrad(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
@@ -78,35 +80,38 @@ static WgradPlan plan_wgrad(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
     auto it = g_wgrad_plans.find(key);
     if (it != g_wgrad_plans.end()) return it->second;
     WgradPlan p;
-    int CIB, COBW;
-    if (Cout > 32) { p.variant = 1; p.ROWP = 32; p.COT = 64; p.WK = 1; CIB = 2; COBW = 1; }
-    else if (Cout > 16 || Cin > 16) { p.variant = 0; p.ROWP = 32; p.COT = 32; p.WK = 2; CIB = 2; COBW = 1; }
-    else { p.variant = 2; p.ROWP = 16; p.COT = 16; p.WK = 4; CIB = 1; COBW = 1; }
-    p.CinP = round_up(Cin, p.ROWP);
+    p.variant = Cout > 32 ? 1 : 0;
+    p.COT = p.variant ? 64 : 32;
+    const int cibw = p.variant ? 2 : 1;
+    p.CinP = round_up(Cin, 32);
     p.CoutP = round_up(Cout, p.COT);
-    const size_t max_lds = 72 * 1024;
+    const size_t max_lds = 52 * 1024;        // three workgroups per CU
     double best = 1e300;
-    p.TH = 1; p.TW = 4;
-    for (int TW = 4; TW <= 64; TW += 4) {
-        if (TW - 4 >= Wo) break;
+    p.TH = 1; p.TW = 8;
+    for (int TW = 8; TW <= 64; TW += 8) {
+        if (TW - 8 >= Wo) break;
         for (int TH = 1; TH <= 32 && TH <= Ho; ++TH) {
-            const int PP = (TH + KS - 1) * (TW + KS - 1), TP = TH * TW;
-            const size_t ldsb = ((size_t)PP * p.ROWP + (size_t)TP * p.COT) * 4;
+            const int PH = TH + KS - 1, PWS = TW + KS - 1 + ((TW + KS - 1) & 1);
+            const size_t ldsb = ((size_t)32 * plane_stride(PH * PWS) + (size_t)p.COT * plane_stride(TH * TW)) * 4;
             if (ldsb > max_lds) break;
             const double tiles = (double)ceil_div(Ho, TH) * ceil_div(Wo, TW);
-            const double mf = (double)ceil_div(TP / 4, p.WK) * (KS * KS * CIB * COBW + 1) * 32.0;
-            const double stage = (double)(PP * p.ROWP + TP * p.COT) / 4.0 / 256.0 * 24.0 + 800.0;
+            const double mf = (double)(TH * TW / 8) * (2 * KS * KS * cibw + 2) * 32.0;
+            const double stage = ((double)PH * (TW + KS - 1) * 8 + (double)TH * TW * (p.COT / 4)) / 256.0 * 40.0 + 600.0;
             const double t = tiles * (mf + stage);
             if (t < best) { best = t; p.TH = TH; p.TW = TW; }
         }
     }
+    p.PWS = p.TW + KS - 1 + ((p.TW + KS - 1) & 1);
+    p.TWS = p.TW;
+    p.PSX = plane_stride((p.TH + KS - 1) * p.PWS);
+    p.PSD = plane_stride(p.TH * p.TW);
     const int ntiles = N * ceil_div(Ho, p.TH) * ceil_div(Wo, p.TW);
-    const int nchunks = (p.CinP / p.ROWP) * (p.CoutP / p.COT);
-    int S = 640 / nchunks;
+    const int nchunks = (p.CinP / 32) * (p.CoutP / p.COT);
+    int S = 768 / nchunks;
     if (S < 1) S = 1;
     if (S > ntiles) S = ntiles;
     p.S = S;
-    p.nslab = S * p.WK;
+    p.nslab = S;
     p.slab_floats = (size_t)p.nslab * (KS * KS + 1) * p.CinP * p.CoutP;
     g_wgrad_plans[key] = p;
     return p;
@@ -189,6 +194,7 @@ int aesr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, flo
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = p.CinP; a.Cout = Cout; a.CoutP = p.CoutP; a.Ho = Ho; a.Wo = Wo; a.pad = pad;
     a.TH = p.TH; a.TW = p.TW; a.tiles_y = ceil_div(Ho, p.TH); a.tiles_x = ceil_div(Wo, p.TW);
     a.ntiles = N * a.tiles_y * a.tiles_x; a.S = p.S;
+    a.PWS = p.PWS; a.TWS = p.TWS; a.PSX = p.PSX; a.PSD = p.PSD;
     if (int e = aesr_launch_conv_wgrad(a, KS, p.variant, (hipStream_t)stream)) return e;
     return aesr_launch_wgrad_reduce(workspace, dw, db, p.nslab, KS, Cin, p.CinP, Cout, p.CoutP, (hipStream_t)stream);
 }

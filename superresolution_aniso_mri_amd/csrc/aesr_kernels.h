@@ -18,6 +18,7 @@ struct WgradArgs {
     int N, H, W, Cin, CinP, Cout, CoutP, Ho, Wo, pad;
     int TH, TW, tiles_y, tiles_x, ntiles;
     int S;
+    int PWS, TWS, PSX, PSD;   // LDS row / plane strides in floats (even; planes = 4 mod 64)
 };
 int aesr_launch_conv_wgrad(const WgradArgs& a, int KS, int variant, hipStream_t st);
 int aesr_launch_wgrad_reduce(const float* slab, float* dw, float* db, int nslab, int KS, int Cin, int CinP, int Cout, int CoutP, hipStream_t st);
