@@ -56,6 +56,36 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
         float s = 0;
         for (int j = 0; j < 8; ++j) s += acc[j][0];
         out[blockIdx.x * 512 + threadIdx.x] = s;
+    } else if constexpr (V == 4) {
+        // igemm-like chunk structure: [barrier, 6 x ds_write_b128, barrier, 36 block-taps x (ds_read_b128 + 8 MFMA)]
+        f32x4 acc[8];
+        for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0, 0, 0, 0};
+        const float* base = lds + lane * 20;
+        f32x4 bq = (f32x4){b0, b0 + 1, b0 + 2, b0 + 3};
+        f32x4 R = (f32x4){a0, a0, a0, a0};
+        for (int it = 0; it < iters / 9; ++it) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *(f32x4*)(lds + ((threadIdx.x + 512 * j) & 4095) * 4) = R;
+            __syncthreads();
+            f32x4 acur = *(const f32x4*)base;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) {
+                    f32x4 anxt = *(const f32x4*)(base + ((tap * 4 + blk + 1) & 7) * 1280);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[blk * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[r], acur[r], acc[blk * 2 + j], 0, 0, 0);
+                    acur = anxt;
+                }
+            }
+            R = acc[0];
+        }
+        float s = 0;
+        for (int j = 0; j < 8; ++j) s += acc[j][0];
+        out[blockIdx.x * 512 + threadIdx.x] = s;
     } else {
         f32x16 acc[2];
         for (int j = 0; j < 2; ++j)
@@ -71,10 +101,10 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
 }
 
 template <int V>
-void run(const char* name, double flop_per_iter_per_wave) {
+void run(const char* name, double flop_per_iter_per_wave, int grid = 1024) {
     float* out;
     hipMalloc(&out, 1024 * 512 * 4);
-    const int iters = 4000, grid = 1024;       // 2 x 8-wave workgroups per CU -> 4 waves / SIMD (V0..V2 fit)
+    const int iters = 4000;       // grid 1024: 2 x 8-wave workgroups per CU -> 4 waves / SIMD; 256: 2 waves / SIMD
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -86,7 +116,7 @@ void run(const char* name, double flop_per_iter_per_wave) {
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    const double fl = flop_per_iter_per_wave * iters * grid * 8;
+    const double fl = flop_per_iter_per_wave * (V == 4 ? (iters / 9) * 9 : iters) * grid * 8;
     printf("%-44s %8.3f ms  %7.1f TFLOP/s\n", name, ms, fl / (ms * 1e-3) / 1e12);
     hipFree(out);
 }
@@ -96,5 +126,9 @@ int main() {
     run<1>("pure MFMA 16x16x4, 2 alternating accumulators", 32.0 * 2048);
     run<2>("2 alternating acc + ds_read_b128 per 8 MFMA", 32.0 * 2048);
     run<3>("pure MFMA 32x32x2, 2 alternating accumulators", 16.0 * 4096);
+    run<2>("V2 at 2 waves/SIMD (grid 256)", 32.0 * 2048, 256);
+    run<2>("V2 at 1 wave-pair... grid 512 (2 WG/CU)", 32.0 * 2048, 512);
+    run<4>("chunked: barriers + 6 ds_write + 288 MFMA, 4 waves/SIMD", 32.0 * 2048, 1024);
+    run<4>("chunked: barriers + 6 ds_write + 288 MFMA, 2 waves/SIMD", 32.0 * 2048, 256);
     return 0;
 }

@@ -143,7 +143,7 @@ int aesr_conv2d_pack(const float* w, float* packed, int Cout, int Cin, int KS, i
     int NP, NB;
     const int kin = transpose ? Cout : Cin, nout = transpose ? Cin : Cout;
     cout_padding(nout, &NP, &NB);
-    return aesr_launch_pack_weights(w, packed, Cout, Cin, KS, round_up(kin, 16), NP, transpose, (hipStream_t)stream);
+    return aesr_launch_pack_weights(w, packed, Cout, Cin, KS, round_up(kin, 16), NP, 16 * NB, transpose, (hipStream_t)stream);
 }
 
 static int run_igemm(const float* in, const float* packed, const float* bias, const float* ysave, float* out, int N, int H,

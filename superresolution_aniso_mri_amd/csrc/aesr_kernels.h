@@ -6,12 +6,12 @@
 struct IgemmArgs {
     const float* in; const float* wpk; const float* bias; const float* ysave; float* out;
     int N, H, W, Cin, CinP, Cout, CoutP, Ho, Wo, pad;
-    int TI, TH, TW, tiles_y, tiles_x, nbl, nitems, dbg;
+    int TI, TH, TW, tiles_y, tiles_x, nitems, dbg;
     int act, mask_act;
     float slope;
 };
 int aesr_launch_conv_igemm(const IgemmArgs& a, int KS, int NB, int MBW, hipStream_t st);
-int aesr_launch_pack_weights(const float* w, float* p, int Cout, int Cin, int KS, int KinP, int NoutP, int transpose, hipStream_t st);
+int aesr_launch_pack_weights(const float* w, float* p, int Cout, int Cin, int KS, int KinP, int NoutP, int TN, int transpose, hipStream_t st);
 
 struct WgradArgs {
     const float* x; const float* dy; float* slab;

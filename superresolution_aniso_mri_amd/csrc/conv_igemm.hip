@@ -11,9 +11,10 @@
 //    in LDS as [pixel][16 ci + 4 pad]; every one of the KS*KS taps re-reads it at a shifted offset
 //    with one ds_read_b128 per M-block (4 MFMA k-steps: lane (pixel, g) holds ci = 4g..4g+3, MFMA r
 //    contracts over ci = {r, 4+r, 8+r, 12+r}).
-//  * B operand (weights): pre-packed on the device as [tap][ci/4][CoutP][4] so that the matching
-//    fragment is ONE coalesced 16-byte global load per lane, straight to registers (L2-resident;
-//    no LDS traffic, no staging barrier for weights).
+//  * weights: pre-packed on the device as [ci chunk][cout tile][tap][ci/4][TN][4], i.e. the slice one (chunk, cout tile)
+//    needs is ONE contiguous block that is staged in LDS next to the patch (same register-prefetch pipeline); the
+//    fragment of a tap is one conflict-free ds_read_b128 per lane.  The tap loop issues no global loads at all
+//    (vmcnt retires in order: a weight load behind the patch prefetch would wait for HBM).
 //  * Epilogue: bias + {none, LeakyReLU, ReLU, sigmoid}, or (dgrad use) multiply by the activation
 //    derivative taken from the saved forward output.
 //
@@ -49,10 +50,11 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
     const int PW = a.TW + KS - 1, PH = a.TH + KS - 1;
     const int PPI = PH * PW, PP = a.TI * PPI;
     const int TPI = a.TH * a.TW, TP = a.TI * TPI;
-    const int nbl = a.nbl;                    // M-blocks per wave (ceil(nblk / IG_NW)), wave-uniform by construction
     const int nchunks = a.CinP >> 4;
-    const int tapstride = (a.CinP >> 2) * a.CoutP * 4;
-    const int chunkstride = 4 * a.CoutP * 4;
+    constexpr int TN = 16 * NB;
+    constexpr int NWP = KS * KS * 4 * TN;                 // 16-byte weight pieces per (chunk, cout tile)
+    constexpr int WP = (NWP + IG_NT - 1) / IG_NT;         // ... per thread
+    float* ldsW = lds + PP * IG_S;                        // [tap][ci/4][TN][4]
 
     // ---- position-independent maps (computed once) ------------------------------------------------------------
     int a_off[MBW], pix[MBW];                 // pix = img<<20 | r<<10 | c of this lane's pixel of block i, or -1
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
 
     // ---- load state: (l_item, l_cc) is the chunk whose patch is in flight into R ----
     int goff[IG_MAXP];
-    f32x4 R[IG_MAXP];
+    f32x4 R[IG_MAXP], RW[WP];
     int l_item = blockIdx.x, l_cc = 0;
     if (l_item >= nitems) return;
 
@@ -116,8 +118,14 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
             goff[j] = go;                                                                                         \
         }                                                                                                         \
     }
-#define IG_ISSUE_LOADS(cc)                                                                                  \
+#define IG_ISSUE_LOADS(item, cc)                                                                            \
     {                                                                                                       \
+        const float* wsrc_ = a.wpk + ((size_t)(cc) * ncot + ((item) % ncot)) * (NWP * 4);                   \
+        _Pragma("unroll") for (int j = 0; j < WP; ++j) {                                                    \
+            const int w_ = tid + IG_NT * j;                                                                 \
+            RW[j] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                            \
+            if (w_ < NWP && !(a.dbg & 2)) RW[j] = *(const f32x4*)(wsrc_ + w_ * 4);                          \
+        }                                                                                                   \
         const bool chan_ok = (cc) * 16 + part4 < a.Cin;                                                     \
         _Pragma("unroll") for (int j = 0; j < IG_MAXP; ++j) {                                               \
             R[j] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                             \
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
     }
 
     IG_COMPUTE_GOFF(l_item)
-    IG_ISSUE_LOADS(0)
+    IG_ISSUE_LOADS(l_item, 0)
 
     // ---- compute state ----
     int c_item = blockIdx.x, cc = 0;
@@ -137,10 +145,7 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
     for (int i = 0; i < MBW; ++i)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[i][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* wlane = a.wpk + (g * a.CoutP + l15) * 4;        // + co0*4 + cc*chunkstride + tap*tapstride + nb*64
-    f32x4 bcur[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bcur[nb] = *(const f32x4*)(wlane + co0 * 4 + nb * 64);
+    const float* wfrag = ldsW + (g * TN + l15) * 4;              // + tap * 4*TN*4 + nb*64
 
     bool first = true;
     while (true) {
@@ -149,6 +154,9 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
 #pragma unroll
         for (int j = 0; j < IG_MAXP; ++j)
             if (piece[j] >= 0) *(f32x4*)(lds + ((tid + IG_NT * j) >> 2) * IG_S + part4) = R[j];
+#pragma unroll
+        for (int j = 0; j < WP; ++j)
+            if (tid + IG_NT * j < NWP) *(f32x4*)(ldsW + (tid + IG_NT * j) * 4) = RW[j];
         __syncthreads();
         // advance the load state and put the next patch chunk in flight
         if (l_cc + 1 < nchunks) {
@@ -158,45 +166,27 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
             l_cc = 0;
             if (l_item < nitems) IG_COMPUTE_GOFF(l_item)
         }
-        if (l_item < nitems) IG_ISSUE_LOADS(l_cc)
+        if (l_item < nitems) IG_ISSUE_LOADS(l_item, l_cc)
 
         const bool last_chunk = (cc + 1 == nchunks);
-        const float* wc = wlane + co0 * 4 + cc * chunkstride;
 #pragma unroll
         for (int tap = 0; tap < KS * KS; ++tap) {
-            // prefetch the NEXT tap's weight fragments (next chunk / next item at the end) under this tap's MFMAs
-            f32x4 bnxt[NB];
+            f32x4 bcur[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bnxt[nb] = bcur[nb];
-            if (a.dbg & 2) {
-            } else if (tap + 1 < KS * KS) {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) bnxt[nb] = *(const f32x4*)(wc + (tap + 1) * tapstride + nb * 64);
-            } else if (!last_chunk) {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) bnxt[nb] = *(const f32x4*)(wc + chunkstride + nb * 64);
-            } else if (c_item + G < nitems) {
-                const int nco0 = ((c_item + G) % ncot) * (16 * NB);
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) bnxt[nb] = *(const f32x4*)(wlane + nco0 * 4 + nb * 64);
-            }
+            for (int nb = 0; nb < NB; ++nb) bcur[nb] = *(const f32x4*)(wfrag + tap * (4 * TN * 4) + nb * 64);
             const int tap_off = ((tap / KS) * PW + (tap % KS)) * IG_S;
             f32x4 acur = *(const f32x4*)(lds + a_off[0] + tap_off);
 #pragma unroll
             for (int i = 0; i < MBW; ++i) {
-                if (i < nbl) {
-                    f32x4 anxt = acur;
-                    if (i + 1 < MBW && i + 1 < nbl) anxt = *(const f32x4*)(lds + a_off[i + 1 < MBW ? i + 1 : i] + tap_off);
+                f32x4 anxt = acur;
+                if (i + 1 < MBW) anxt = *(const f32x4*)(lds + a_off[i + 1 < MBW ? i + 1 : i] + tap_off);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[nb][r], acur[r], acc[i][nb], 0, 0, 0);
-                    acur = anxt;
-                }
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[nb][r], acur[r], acc[i][nb], 0, 0, 0);
+                acur = anxt;
             }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bcur[nb] = bnxt[nb];
         }
 
         if (!last_chunk) {
@@ -207,7 +197,7 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
         const bool vec = (a.Cout & 3) == 0;
 #pragma unroll
         for (int i = 0; i < MBW; ++i) {
-            if (i < nbl && pix[i] >= 0 && !(a.dbg & 4)) {
+            if (pix[i] >= 0 && !(a.dbg & 4)) {
                 const int n = cn0 + (pix[i] >> 20), y = cy0 + ((pix[i] >> 10) & 1023), x = cx0 + (pix[i] & 1023);
                 if (n < a.N && y < a.Ho && x < a.Wo) {
                     const int ob = ((n * a.Ho + y) * a.Wo + x) * a.Cout;
@@ -258,21 +248,25 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
 }
 
 // ---- weight packing --------------------------------------------------------------------------------
-// forward : P[tap][ci/4][co][ci%4]            = W[co][ci][ky][kx],                tap = ky*KS+kx
-// dgrad   : P[tap'][co/4][ci][co%4]           = W[co][ci][ky][kx],  tap' = (KS-1-ky)*KS + (KS-1-kx)
-//           (the "input channels" of the dgrad GEMM are the forward Cout and vice versa)
+// P[ci chunk][cout tile][tap][q(4)][col(TN)][r(4)]   K-side channel kc = chunk*16 + q*4 + r, N-side channel no = tile*TN + col
+// forward : P = W[no][kc][ky][kx],                  tap = ky*KS+kx
+// dgrad   : P = W[kc][no][KS-1-ky][KS-1-kx]         (the "input channels" of the dgrad GEMM are the forward Cout)
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int KS,
-                                    int KinP, int NoutP, int transpose) {
-    // p has KS*KS * (KinP/4) * NoutP * 4 elements; K-side channel = (transpose ? co : ci)
+                                    int KinP, int NoutP, int TN, int transpose) {
     const size_t total = (size_t)KS * KS * KinP * NoutP;
+    const int ncot = NoutP / TN, KS2 = KS * KS;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int r = idx & 3;
         size_t rest = idx >> 2;
-        const int no = rest % NoutP;
-        rest /= NoutP;
-        const int kq = rest % (KinP / 4);
-        const int tap = rest / (KinP / 4);
-        const int kc = kq * 4 + r;
+        const int col = rest % TN;
+        rest /= TN;
+        const int q = rest & 3;
+        rest >>= 2;
+        const int tap = rest % KS2;
+        rest /= KS2;
+        const int cot = rest % ncot;
+        const int chunk = rest / ncot;
+        const int kc = chunk * 16 + q * 4 + r, no = cot * TN + col;
         float v = 0.f;
         if (!transpose) {
             if (kc < Cin && no < Cout) v = w[(((size_t)no * Cin + kc) * KS + tap / KS) * KS + tap % KS];
@@ -284,12 +278,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
-int aesr_launch_pack_weights(const float* w, float* p, int Cout, int Cin, int KS, int KinP, int NoutP, int transpose,
+int aesr_launch_pack_weights(const float* w, float* p, int Cout, int Cin, int KS, int KinP, int NoutP, int TN, int transpose,
                              hipStream_t st) {
     const size_t total = (size_t)KS * KS * KinP * NoutP;
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, st, w, p, Cout, Cin, KS, KinP, NoutP, transpose);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, st, w, p, Cout, Cin, KS, KinP, NoutP, TN, transpose);
     AESR_LAUNCH_CHECK("pack_weights");
     return AESR_OK;
 }
@@ -297,7 +291,7 @@ int aesr_launch_pack_weights(const float* w, float* p, int Cout, int Cin, int KS
 template <int KS, int NB, int MBW>
 static int launch_one(const IgemmArgs& a, hipStream_t st) {
     const int PP = a.TI * (a.TH + KS - 1) * (a.TW + KS - 1);
-    const size_t shmem = (size_t)PP * IG_S * sizeof(float);
+    const size_t shmem = ((size_t)PP * IG_S + (size_t)KS * KS * 4 * 16 * NB * 4) * sizeof(float);
     if (shmem > 160 * 1024) {
         aesr_set_error("conv_igemm: tile needs %zu B of LDS", shmem);
         return AESR_ERR_ARG;
@@ -321,11 +315,11 @@ int aesr_launch_conv_igemm(const IgemmArgs& a_in, int KS, int NB, int MBW, hipSt
     a.dbg = dbg;
     const int TP = a.TI * a.TH * a.TW;
     const int nblk = (TP + 15) / 16;
-    a.nbl = (nblk + IG_NW - 1) / IG_NW;
     if (nblk > IG_NW * MBW) {
         aesr_set_error("conv_igemm: tile of %d pixels needs %d M-blocks > %d", TP, nblk, IG_NW * MBW);
         return AESR_ERR_ARG;
     }
+    MBW = (nblk + IG_NW - 1) / IG_NW;          // exact blocks per wave: the inner loop has no runtime block bound
     if (a.CoutP % (16 * NB) != 0 || a.CinP % 16 != 0 || a.Cin % 4 != 0) {
         aesr_set_error("conv_igemm: bad channel padding Cin=%d CinP=%d CoutP=%d NB=%d", a.Cin, a.CinP, a.CoutP, NB);
         return AESR_ERR_ARG;
@@ -346,8 +340,10 @@ int aesr_launch_conv_igemm(const IgemmArgs& a_in, int KS, int NB, int MBW, hipSt
     }
 #define IG_CASE(ks, nb, mbw) \
     if (KS == ks && NB == nb && MBW == mbw) return launch_one<ks, nb, mbw>(a, st);
-    IG_CASE(3, 1, 4) IG_CASE(3, 2, 4) IG_CASE(3, 4, 2)
-    IG_CASE(1, 1, 4) IG_CASE(1, 2, 4) IG_CASE(1, 4, 2)
+    IG_CASE(3, 1, 1) IG_CASE(3, 1, 2) IG_CASE(3, 1, 3) IG_CASE(3, 1, 4) IG_CASE(3, 2, 1) IG_CASE(3, 2, 2) IG_CASE(3, 2, 3) IG_CASE(3, 2, 4)
+    IG_CASE(3, 4, 1) IG_CASE(3, 4, 2)
+    IG_CASE(1, 1, 1) IG_CASE(1, 1, 2) IG_CASE(1, 1, 3) IG_CASE(1, 1, 4) IG_CASE(1, 2, 1) IG_CASE(1, 2, 2) IG_CASE(1, 2, 3) IG_CASE(1, 2, 4)
+    IG_CASE(1, 4, 1) IG_CASE(1, 4, 2)
 #undef IG_CASE
     aesr_set_error("conv_igemm: no instantiation for KS=%d NB=%d MBW=%d", KS, NB, MBW);
     return AESR_ERR_UNSUPPORTED;
