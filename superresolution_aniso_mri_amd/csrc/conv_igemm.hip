@@ -133,6 +133,50 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
         }                                                                                                   \
     }
 
+// epilogue of one finished item: D layout of 16x16x4: column (pixel) = lane&15, row (cout) = 4*(lane>>4)+j
+#define IG_EPILOGUE(en0, ey0, ex0, eco0)  \
+    {  \
+        const bool vec = (a.Cout & 3) == 0;  \
+_Pragma("unroll")  \
+        for (int i = 0; i < MBW; ++i) {  \
+            if (pix[i] >= 0 && !(a.dbg & 4)) {  \
+                const int n = en0 + (pix[i] >> 20), y = ey0 + ((pix[i] >> 10) & 1023), x = ex0 + (pix[i] & 1023);  \
+                if (n < a.N && y < a.Ho && x < a.Wo) {  \
+                    const int ob = ((n * a.Ho + y) * a.Wo + x) * a.Cout;  \
+_Pragma("unroll")  \
+                    for (int nb = 0; nb < NB; ++nb) {  \
+                        const int co = eco0 + nb * 16 + 4 * g;  \
+                        f32x4 v = acc[i][nb];  \
+                        if (vec) {  \
+                            if (co < a.Cout) {  \
+                                if (a.bias) v += *(const f32x4*)(a.bias + co);  \
+_Pragma("unroll")  \
+                                for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act, a.slope);  \
+                                if (a.ysave) {  \
+                                    const f32x4 ys = *(const f32x4*)(a.ysave + ob + co);  \
+_Pragma("unroll")  \
+                                    for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_output(ys[e], a.mask_act, a.slope);  \
+                                }  \
+                                *(f32x4*)(a.out + ob + co) = v;  \
+                            }  \
+                        } else {  \
+_Pragma("unroll")  \
+                            for (int e = 0; e < 4; ++e) {  \
+                                if (co + e < a.Cout) {  \
+                                    float s = v[e];  \
+                                    if (a.bias) s += a.bias[co + e];  \
+                                    s = act_apply(s, a.act, a.slope);  \
+                                    if (a.ysave) s *= act_grad_from_output(a.ysave[ob + co + e], a.mask_act, a.slope);  \
+                                    a.out[ob + co + e] = s;  \
+                                }  \
+                            }  \
+                        }  \
+                    }  \
+                }  \
+            }  \
+        }  \
+    }
+
     IG_COMPUTE_GOFF(l_item)
     IG_ISSUE_LOADS(l_item, 0)
 
@@ -147,7 +191,8 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
         for (int nb = 0; nb < NB; ++nb) acc[i][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* wfrag = ldsW + (g * TN + l15) * 4;              // + tap * 4*TN*4 + nb*64
 
-    bool first = true;
+    bool first = true, ep_pending = false;
+    int en0_ = 0, ey0_ = 0, ex0_ = 0, eco0_ = 0;
     while (true) {
         if (!first) __syncthreads();           // every wave has finished reading the previous chunk from LDS
         first = false;
@@ -167,25 +212,47 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
             if (l_item < nitems) IG_COMPUTE_GOFF(l_item)
         }
         if (l_item < nitems) IG_ISSUE_LOADS(l_item, l_cc)
+        if (ep_pending) {
+            IG_EPILOGUE(en0_, ey0_, ex0_, eco0_)
+            ep_pending = false;
+#pragma unroll
+            for (int i = 0; i < MBW; ++i)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[i][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 
         const bool last_chunk = (cc + 1 == nchunks);
+        // explicit software pipeline, pinned with sched_barrier: the LDS reads of block i+1 (and of the next tap's
+        // weight fragments) are issued BEFORE the 4*NB MFMAs of block i, so their latency hides under 128*NB cycles of
+        // matrix work (left alone, the scheduler sinks the reads to just before their first use)
+        f32x4 bnxt[NB], anxt;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bnxt[nb] = *(const f32x4*)(wfrag + nb * 64);
+        anxt = *(const f32x4*)(lds + a_off[0]);
 #pragma unroll
         for (int tap = 0; tap < KS * KS; ++tap) {
             f32x4 bcur[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bcur[nb] = *(const f32x4*)(wfrag + tap * (4 * TN * 4) + nb * 64);
+            for (int nb = 0; nb < NB; ++nb) bcur[nb] = bnxt[nb];
             const int tap_off = ((tap / KS) * PW + (tap % KS)) * IG_S;
-            f32x4 acur = *(const f32x4*)(lds + a_off[0] + tap_off);
 #pragma unroll
             for (int i = 0; i < MBW; ++i) {
-                f32x4 anxt = acur;
-                if (i + 1 < MBW) anxt = *(const f32x4*)(lds + a_off[i + 1 < MBW ? i + 1 : i] + tap_off);
+                const f32x4 acur = anxt;
+                if (i + 1 < MBW) {
+                    anxt = *(const f32x4*)(lds + a_off[i + 1 < MBW ? i + 1 : i] + tap_off);
+                } else if (tap + 1 < KS * KS) {
+                    const int noff = (((tap + 1) / KS) * PW + ((tap + 1) % KS)) * IG_S;
+                    anxt = *(const f32x4*)(lds + a_off[0] + noff);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) bnxt[nb] = *(const f32x4*)(wfrag + (tap + 1) * (4 * TN * 4) + nb * 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
                         acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[nb][r], acur[r], acc[i][nb], 0, 0, 0);
-                acur = anxt;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 
@@ -193,55 +260,17 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
             ++cc;
             continue;
         }
-        // ---- epilogue of c_item: D layout of 16x16x4: column (pixel) = lane&15, row (cout) = 4*(lane>>4)+j ----
-        const bool vec = (a.Cout & 3) == 0;
-#pragma unroll
-        for (int i = 0; i < MBW; ++i) {
-            if (pix[i] >= 0 && !(a.dbg & 4)) {
-                const int n = cn0 + (pix[i] >> 20), y = cy0 + ((pix[i] >> 10) & 1023), x = cx0 + (pix[i] & 1023);
-                if (n < a.N && y < a.Ho && x < a.Wo) {
-                    const int ob = ((n * a.Ho + y) * a.Wo + x) * a.Cout;
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const int co = co0 + nb * 16 + 4 * g;
-                        f32x4 v = acc[i][nb];
-                        if (vec) {
-                            if (co < a.Cout) {
-                                if (a.bias) v += *(const f32x4*)(a.bias + co);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act, a.slope);
-                                if (a.ysave) {
-                                    const f32x4 ys = *(const f32x4*)(a.ysave + ob + co);
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_output(ys[e], a.mask_act, a.slope);
-                                }
-                                *(f32x4*)(a.out + ob + co) = v;
-                            }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                if (co + e < a.Cout) {
-                                    float s = v[e];
-                                    if (a.bias) s += a.bias[co + e];
-                                    s = act_apply(s, a.act, a.slope);
-                                    if (a.ysave) s *= act_grad_from_output(a.ysave[ob + co + e], a.mask_act, a.slope);
-                                    a.out[ob + co + e] = s;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        // the finished item's epilogue is DEFERRED to the next iteration (after the LDS write + load issue): its stores
+        // would otherwise sit in the in-order vmcnt queue in front of the wait that guards the prefetched registers
+        ep_pending = true;
+        en0_ = cn0; ey0_ = cy0; ex0_ = cx0; eco0_ = co0;
         c_item += G;
         if (c_item >= nitems) break;
         cc = 0;
         IG_TILE_ORIGIN(c_item, cn0, cy0, cx0, co0)
-#pragma unroll
-        for (int i = 0; i < MBW; ++i)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[i][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    if (ep_pending) IG_EPILOGUE(en0_, ey0_, ex0_, eco0_)
+#undef IG_EPILOGUE
 #undef IG_TILE_ORIGIN
 #undef IG_COMPUTE_GOFF
 #undef IG_ISSUE_LOADS
