@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--config", choices=["c2", "c3"], default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured step")
     opt = ap.parse_args()
 
     from superresolution_aniso_mri_amd import engine
@@ -83,6 +84,9 @@ def main():
     if dp.active:
         dp.attach(trainer)
         dp.set_batch(B)
+    use_graph = not opt.no_graph and not dp.active
+    if use_graph:
+        trainer.enable_step_graph(eager_steps=2)
     # a small pool of distinct batches, sharded by triplet and resident in HBM before the timed region
     pool = []
     for i in range(4):
@@ -110,6 +114,7 @@ def main():
     roofline = None
     if not opt.no_roofline:
         # same steps again with one HIP-event pair around every MFMA convolution launch (on the launching stream)
+        trainer._graph_enabled = False          # event pairs need host-side launches
         engine.PROFILER = engine.KernelProfiler()
         run(min(opt.steps, 5), 0)
         summ = engine.PROFILER.summary()
@@ -139,7 +144,8 @@ def main():
                                + ("MSE synthesis loss (BASELINE configs[1])" if opt.config == "c2"
                                   else "LPIPS-VGG synthesis loss lambda=0.05, synthetic backbone weights (BASELINE configs[2])"),
                    "global_batch_triplets": B, "slices_per_step": 3 * B, "parallelism": "dp%d" % opt.gpus,
-                   "init": "reference Initializer, seed 892372, random weights"},
+                   "init": "reference Initializer, seed 892372, random weights",
+                   "launch": "captured HIP graph replay" if use_graph else "host launches"},
         "step_algorithmic_gflop": STEP_GFLOP[opt.config],
         "step_tflops": round(STEP_GFLOP[opt.config] / ms_per_step, 2),
         "step_frac_of_f32_mfma_peak": round(STEP_GFLOP[opt.config] / ms_per_step / PEAK_F32_MFMA_TFLOPS, 4),

@@ -88,10 +88,10 @@ int aesr_conv2d_cout1_wgrad(const float* x, const float* dy, float* dw, float* d
 /* sums[G][2][C] (double): per group and channel sum(y), sum(y^2).  partial: G*AESR_BN_NWG*2*C floats. */
 int aesr_bn_stats(const float* y, float* partial, double* sums, int HW, int C, int G, const int* nstart_host,
                   void* stream);
-/* mean/invstd/scale/shift [G][C].  train: from sums and counts_dev[G] (double, elements per channel, global under
- * data parallel); running_mean/var/num_batches_tracked updated group after group when update_running.
+/* mean/invstd/scale/shift [G][C].  train: from sums and counts_host[G] (HOST doubles: elements per channel and group,
+ * the GLOBAL count under data parallel); running_mean/var/num_batches_tracked updated group after group when update_running.
  * eval (train == 0): from the running buffers; sums/counts ignored. */
-int aesr_bn_finalize(const double* sums, const double* counts_dev, const float* gamma, const float* beta,
+int aesr_bn_finalize(const double* sums, const double* counts_host, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
                      float* scale, float* shift, int C, int G, float momentum, float eps, int train, int update_running,
                      void* stream);
@@ -105,7 +105,7 @@ int aesr_bn_bwd_reduce(const float* gout, const float* y, const float* mean, con
 /* step 2: dpre = scale*(g - s1/M - xhat*s2/M) * act'(y);  dgamma = sum_g s2, dbeta = sum_g s1.
  * coef: G*2*C floats of scratch. */
 int aesr_bn_bwd_apply(const float* gout, const float* y, const float* mean, const float* invstd, const float* scale,
-                      const double* sums, const double* counts_dev, float* coef, float* dgamma, float* dbeta,
+                      const double* sums, const double* counts_host, float* coef, float* dgamma, float* dbeta,
                       float* dpre, int N, int H, int W, int C, int mode, int act, float slope, int G,
                       const int* nstart_host, void* stream);
 

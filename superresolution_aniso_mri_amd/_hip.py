@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libaesr_hip.so")
 P = c_void_p          # device pointer
 IP = ctypes.POINTER(c_int)
 FP = ctypes.POINTER(c_float)
+DP = ctypes.POINTER(c_double)     # host array of doubles
 
 # name -> (restype, argtypes); must list every symbol include/aesr_hip.h declares (checked by tests)
 SIGNATURES = {
@@ -34,10 +35,10 @@ SIGNATURES = {
     "aesr_conv2d_cout1_fwd": (c_int, [P, P, P, P] + [c_int] * 5 + [c_float, P]),
     "aesr_conv2d_cout1_wgrad": (c_int, [P, P, P, P, P] + [c_int] * 4 + [P]),
     "aesr_bn_stats": (c_int, [P, P, P, c_int, c_int, c_int, IP, P]),
-    "aesr_bn_finalize": (c_int, [P] * 11 + [c_int, c_int, c_float, c_float, c_int, c_int, P]),
+    "aesr_bn_finalize": (c_int, [P, DP] + [P] * 9 + [c_int, c_int, c_float, c_float, c_int, c_int, P]),
     "aesr_bn_apply": (c_int, [P, P, P, P] + [c_int] * 6 + [IP, P]),
     "aesr_bn_bwd_reduce": (c_int, [P] * 6 + [c_int] * 6 + [IP, P]),
-    "aesr_bn_bwd_apply": (c_int, [P] * 11 + [c_int] * 6 + [c_float, c_int, IP, P]),
+    "aesr_bn_bwd_apply": (c_int, [P] * 6 + [DP] + [P] * 4 + [c_int] * 6 + [c_float, c_int, IP, P]),
     "aesr_maxpool2_fwd": (c_int, [P, P] + [c_int] * 4 + [P]),
     "aesr_maxpool2_bwd": (c_int, [P, P, P, P] + [c_int] * 5 + [P]),
     "aesr_lpips_tap_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P]),
@@ -97,6 +98,10 @@ def stream():
 
 def int_array(vals):
     return (c_int * len(vals))(*[int(v) for v in vals])
+
+
+def double_array(vals):
+    return (c_double * len(vals))(*[float(v) for v in vals])
 
 
 def float_array(vals):

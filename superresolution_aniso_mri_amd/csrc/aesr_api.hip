@@ -273,13 +273,13 @@ int aesr_bn_stats(const float* y, float* partial, double* sums, int HW, int C, i
     return aesr_launch_bn_reduce(partial, sums, AESR_BN_NWG, C, G, (hipStream_t)stream);
 }
 
-int aesr_bn_finalize(const double* sums, const double* counts_dev, const float* gamma, const float* beta, float* running_mean,
+int aesr_bn_finalize(const double* sums, const double* counts_host, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
                      int C, int G, float momentum, float eps, int train, int update_running, void* stream) {
     AESR_CHECK_ARG(gamma && beta && mean && invstd && scale && shift && G >= 1 && G <= 4, "aesr_bn_finalize: bad arguments");
-    AESR_CHECK_ARG(!train || (sums && counts_dev), "aesr_bn_finalize: train mode needs sums and counts");
+    AESR_CHECK_ARG(!train || (sums && counts_host), "aesr_bn_finalize: train mode needs sums and counts");
     AESR_CHECK_ARG(train || (running_mean && running_var), "aesr_bn_finalize: eval mode needs running stats");
-    return aesr_launch_bn_finalize(sums, counts_dev, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, mean,
+    return aesr_launch_bn_finalize(sums, counts_host, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, mean,
                                    invstd, scale, shift, C, G, momentum, eps, train, update_running && running_mean && running_var,
                                    (hipStream_t)stream);
 }
@@ -313,13 +313,13 @@ int aesr_bn_bwd_reduce(const float* gout, const float* y, const float* mean, con
 }
 
 int aesr_bn_bwd_apply(const float* gout, const float* y, const float* mean, const float* invstd, const float* scale,
-                      const double* sums, const double* counts_dev, float* coef, float* dgamma, float* dbeta, float* dpre, int N,
+                      const double* sums, const double* counts_host, float* coef, float* dgamma, float* dbeta, float* dpre, int N,
                       int H, int W, int C, int mode, int act, float slope, int G, const int* nstart_host, void* stream) {
     BnBwdArgs a;
     memset(&a, 0, sizeof(a));
-    AESR_CHECK_ARG(gout && y && mean && invstd && scale && sums && counts_dev && coef && dgamma && dbeta && dpre &&
+    AESR_CHECK_ARG(gout && y && mean && invstd && scale && sums && counts_host && coef && dgamma && dbeta && dpre &&
                        fill_groups(&a.gr, G, nstart_host), "aesr_bn_bwd_apply: bad arguments");
-    if (int e = aesr_launch_bn_bwd_finalize(sums, counts_dev, coef, dgamma, dbeta, C, G, (hipStream_t)stream)) return e;
+    if (int e = aesr_launch_bn_bwd_finalize(sums, counts_host, coef, dgamma, dbeta, C, G, (hipStream_t)stream)) return e;
     a.gout = gout; a.y = y; a.mean = mean; a.invstd = invstd; a.scale = scale; a.coef = coef; a.dpre = dpre;
     a.N = N; a.H = H; a.W = W; a.C = C; a.mode = mode; a.act = act; a.slope = slope;
     bn_out_dims(H, W, mode, &a.Ho, &a.Wo);

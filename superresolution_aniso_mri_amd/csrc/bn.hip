@@ -53,9 +53,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 
 // sums[g][2][C] (double) = sum_wg partial[g][wg][2][C]
 // block = 64 columns x 4 row-lanes: coalesced across columns, fixed summation order (bitwise reproducible)
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ partial, double* __restrict__ sums, int nwg,
-                                                        int C, int G) {
-    __shared__ double red[4][64];
+__global__ __launch_bounds__(1024) void bn_reduce_kernel(const float* __restrict__ partial, double* __restrict__ sums, int nwg,
+                                                         int C, int G) {
+    __shared__ double red[16][64];
     const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int o = blockIdx.x * 64 + col;
     const int n = G * 2 * C;
@@ -63,15 +63,22 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     if (o < n) {
         const int g = o / (2 * C), r = o - g * 2 * C;
         const float* base = partial + (size_t)g * nwg * 2 * C + r;
-        for (int k = rl; k < nwg; k += 4) s += (double)base[(size_t)k * 2 * C];
+        for (int k = rl; k < nwg; k += 16) s += (double)base[(size_t)k * 2 * C];
     }
     red[rl][col] = s;
     __syncthreads();
-    if (rl == 0 && o < n) sums[o] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    if (rl == 0 && o < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][col];
+        sums[o] = t;
+    }
 }
 
 // train: stats from sums/counts (+ running update, group after group); eval: stats from the running buffers
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ counts,
+struct BnCounts { double c[4]; };
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, BnCounts counts,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    long long* __restrict__ nbt, float* __restrict__ mean, float* __restrict__ invstd,
@@ -83,7 +90,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, const double
     for (int g = 0; g < G; ++g) {
         float m, iv;
         if (train) {
-            const double M = counts[g];
+            const double M = counts.c[g];
             const double mu = sums[(g * 2 + 0) * C + c] / M;
             double var = sums[(g * 2 + 1) * C + c] / M - mu * mu;
             if (var < 0.0) var = 0.0;
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
 }
 
 // coef[g][2][C] = sums/M ; dgamma[c] = sum_g s2 ; dbeta[c] = sum_g s1
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ counts,
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, BnCounts counts,
                                        float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        int C, int G) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -193,8 +200,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, const do
     double dg = 0.0, db = 0.0;
     for (int g = 0; g < G; ++g) {
         const double s1 = sums[(g * 2 + 0) * C + c], s2 = sums[(g * 2 + 1) * C + c];
-        coef[(g * 2 + 0) * C + c] = (float)(s1 / counts[g]);
-        coef[(g * 2 + 1) * C + c] = (float)(s2 / counts[g]);
+        coef[(g * 2 + 0) * C + c] = (float)(s1 / counts.c[g]);
+        coef[(g * 2 + 1) * C + c] = (float)(s2 / counts.c[g]);
         db += s1;
         dg += s2;
     }
@@ -246,7 +253,7 @@ int aesr_launch_bn_stats(const float* y, float* partial, int HW, int C, const Bn
 }
 
 int aesr_launch_bn_reduce(const float* partial, double* sums, int nwg, int C, int G, hipStream_t st) {
-    hipLaunchKernelGGL(bn_reduce_kernel, dim3(ceil_div(G * 2 * C, 64)), dim3(256), 0, st, partial, sums, nwg, C, G);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3(ceil_div(G * 2 * C, 64)), dim3(1024), 0, st, partial, sums, nwg, C, G);
     AESR_LAUNCH_CHECK("bn_reduce");
     return AESR_OK;
 }
@@ -255,7 +262,9 @@ int aesr_launch_bn_finalize(const double* sums, const double* counts, const floa
                             float* running_mean, float* running_var, long long* nbt, float* mean, float* invstd,
                             float* scale, float* shift, int C, int G, float momentum, float eps, int train,
                             int update_running, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, sums, counts, gamma, beta, running_mean,
+    BnCounts cnt;
+    for (int g = 0; g < 4; ++g) cnt.c[g] = (counts && g < G) ? counts[g] : 1.0;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, sums, cnt, gamma, beta, running_mean,
                        running_var, nbt, mean, invstd, scale, shift, C, G, momentum, eps, train, update_running);
     AESR_LAUNCH_CHECK("bn_finalize");
     return AESR_OK;
@@ -281,7 +290,9 @@ int aesr_launch_bn_bwd_reduce(const BnBwdArgs& a, int nwg, hipStream_t st) {
 
 int aesr_launch_bn_bwd_finalize(const double* sums, const double* counts, float* coef, float* dgamma, float* dbeta, int C,
                                 int G, hipStream_t st) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, sums, counts, coef, dgamma, dbeta, C, G);
+    BnCounts cnt;
+    for (int g = 0; g < 4; ++g) cnt.c[g] = (counts && g < G) ? counts[g] : 1.0;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, sums, cnt, coef, dgamma, dbeta, C, G);
     AESR_LAUNCH_CHECK("bn_bwd_finalize");
     return AESR_OK;
 }

@@ -221,7 +221,8 @@ class SequentialRunner:
                 cur, H, W = out, Ho, Wo
         return cur, saved
 
-    sync_bn = None   # optional callable(sums[G,2,C] double, counts[G] double) -> all-reduced in place (data parallel)
+    sync_bn = None      # optional callable(sums[G,2,C] double) -> all-reduced in place across ranks (data parallel SyncBN)
+    count_scale = 1.0   # data parallel: global / local sub-batch size (B_global / B_local of this rank)
 
     def _bn_forward_stats(self, bn, y, N, H, W, C, nstart, train):
         G = len(nstart) - 1
@@ -234,20 +235,31 @@ class SequentialRunner:
             sums = torch.empty((G, 2, C), device=dev, dtype=torch.float64)
             check(lib.aesr_bn_stats(ptr(y), ptr(partial), ptr(sums), H * W, C, G, _hip.int_array(nstart), stream()),
                   "aesr_bn_stats")
-            counts = torch.tensor([float((nstart[g + 1] - nstart[g]) * H * W) for g in range(G)], dtype=torch.float64,
-                                  device=dev)
+            counts = [float((nstart[g + 1] - nstart[g]) * H * W) * self.count_scale for g in range(G)]   # host values
             if self.sync_bn is not None:
-                self.sync_bn(sums, counts)
+                self.sync_bn(sums)
         st["counts"] = counts
         momentum = 0.1 if bn.momentum is None else float(bn.momentum)
         update = bool(train and bn.track_running_stats and bn.running_mean is not None)
-        check(lib.aesr_bn_finalize(ptr(sums), ptr(counts), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+        check(lib.aesr_bn_finalize(ptr(sums), _hip.double_array(counts) if counts else None, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
                                    ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(st["mean"]), ptr(st["invstd"]),
                                    ptr(st["scale"]), ptr(st["shift"]), C, G, momentum, float(bn.eps), int(use_batch),
                                    int(update), stream()), "aesr_bn_finalize")
         return st
 
     # ---- backward --------------------------------------------------------------------------------------------
+    @staticmethod
+    def _grad_dst(p, grads):
+        """Where a parameter gradient is written: straight into ``p.grad`` when that buffer is known to be freshly zeroed
+        (HipAdam.zero_grad marks it) -- autograd then gets ``None`` and no accumulation kernel runs -- else a temporary."""
+        if p.grad is not None and getattr(p, "_aesr_grad_fresh", False) and p.grad.is_contiguous():
+            p._aesr_grad_fresh = False
+            grads[p] = None
+            return p.grad
+        t = torch.empty_like(p)
+        grads[p] = t
+        return t
+
     def backward(self, gout, saved, nstart, ngrad, need_input_grad):
         """gout: NHWC gradient of the pass output (all N images; only the first ``ngrad`` are used).
         Returns (dx or None, {param: grad})."""
@@ -274,8 +286,8 @@ class SequentialRunner:
                     check(lib.aesr_act_bwd(ptr(g), ptr(yout), ptr(dpre), g.numel(), s.act, s.slope, stream()), "aesr_act_bwd")
                     g = dpre
                 # -- weight / bias gradient
-                dw = torch.empty_like(s.mod.weight)
-                db = torch.empty_like(s.mod.bias) if s.mod.bias is not None else None
+                dw = self._grad_dst(s.mod.weight, grads)
+                db = self._grad_dst(s.mod.bias, grads) if s.mod.bias is not None else None
                 if s.cin % 4 == 0 and s.cout % 4 == 0:
                     nws = lib.aesr_conv2d_wgrad_workspace_floats(N, H, W, s.cin, s.cout, s.ks, s.pad)
                     ws = _empty((nws,), g)
@@ -293,9 +305,6 @@ class SequentialRunner:
                           "aesr_conv2d_cout1_wgrad")
                 else:
                     raise NotImplementedError("no wgrad kernel for conv %d->%d k%d" % (s.cin, s.cout, s.ks))
-                grads[s.mod.weight] = dw
-                if db is not None:
-                    grads[s.mod.bias] = db
                 # -- data gradient (fused with the derivative of the activation that produced our input)
                 if k == 0 and not need_input_grad:
                     g = None
@@ -334,14 +343,13 @@ class SequentialRunner:
                 check(lib.aesr_bn_bwd_reduce(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(partial), ptr(sums), N, H,
                                              W, C, s.mode, G, nsa, stream()), "aesr_bn_bwd_reduce")
                 if self.sync_bn is not None:
-                    self.sync_bn(sums, None)
+                    self.sync_bn(sums)
                 coef = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
-                dgamma, dbeta = torch.empty_like(s.mod.weight), torch.empty_like(s.mod.bias)
+                dgamma, dbeta = self._grad_dst(s.mod.weight, grads), self._grad_dst(s.mod.bias, grads)
                 dpre = _empty((N, H, W, C), y)
                 check(lib.aesr_bn_bwd_apply(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(sums),
-                                            ptr(st["counts"]), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dpre), N, H, W, C,
+                                            _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dpre), N, H, W, C,
                                             s.mode, prev.act, prev.slope, G, nsa, stream()), "aesr_bn_bwd_apply")
-                grads[s.mod.weight], grads[s.mod.bias] = dgamma, dbeta
                 g = dpre
         return g, grads
 

@@ -87,7 +87,12 @@ class BaseTrainer(object):
     def iters(self):
         return self._iters
 
+    _capture_sink = None      # dict while a step is being captured into a HIP graph (see AEBaseTrainer._train_graphed)
+
     def _log(self, key, value, is_test=False):
+        if self._capture_sink is not None and not is_test:
+            self._capture_sink[key] = value
+            return
         (self.losses_test if is_test else self.losses)[key].append(_scalar(value))
 
     def reset_losses(self):

@@ -38,15 +38,6 @@ class CombinedStepMixin(object):
 
     _mask_inputs = True      # cardiac multiplies the images by the mask; brain multiplies the distances
 
-    def get_extra_loss(self, slice_between, s_between_mix, z_mix, z=None, mask=None, is_test=False):
-        loss_img = self._extra_weight() * self.get_extra_image_loss(slice_between, s_between_mix, mask=mask, is_test=is_test)
-        if self.args.get("use_extra_latent_loss"):
-            raise NotImplementedError("use_extra_latent_loss is not part of the README ae_combined recipes")
-        if self._log_extra_total:
-            self._log("loss_ae_extra", loss_img, is_test)
-        self._log("loss_ae_dist_extra", loss_img, is_test)
-        return loss_img
-
     _log_extra_total = True
 
     def synthesize_batch_images(self, **kwargs):
@@ -67,11 +58,30 @@ class CombinedStepMixin(object):
             lat = ops.mse_loss(z_mix.detach(), z_ref.detach())
         return {"s_between_mix": s_mix, "z_mix": z_mix, "loss_latent": lat}
 
-    def train(self, batch_item, keep_predictions=True, eval_mode=False):
-        x = self._to_device(batch_item["image"])
-        between = self._to_device(batch_item["slice_between"])
-        self.model.train(not eval_mode)
-        self._iters += 1
+    def _lambda_tensor(self):
+        """Synthesis-loss weight as a device scalar (so an annealed weight can change under a captured step graph)."""
+        w = float(self._extra_weight())
+        t = self.__dict__.get("_lam_t")
+        if t is None:
+            t = self._lam_t = torch.empty((), dtype=torch.float32, device=self.args["device"])
+            self._lam_host = None
+        if self._lam_host != w:
+            t.fill_(w)
+            self._lam_host = w
+        return t
+
+    def get_extra_loss(self, slice_between, s_between_mix, z_mix, z=None, mask=None, is_test=False):
+        loss_img = self._lambda_tensor() * self.get_extra_image_loss(slice_between, s_between_mix, mask=mask, is_test=is_test)
+        if self.args.get("use_extra_latent_loss"):
+            raise NotImplementedError("use_extra_latent_loss is not part of the README ae_combined recipes")
+        if self._log_extra_total:
+            self._log("loss_ae_extra", loss_img, is_test)
+        self._log("loss_ae_dist_extra", loss_img, is_test)
+        return loss_img
+
+    def _step_core(self, batch_item, eval_mode):
+        """The ae_combined step on device-resident inputs; logs through ``_log`` and returns the tensors callers keep."""
+        x, between = batch_item["image"], batch_item["slice_between"]
         B = x.shape[0] // 2
         # enc(x[2B]) and the logging-only enc(slice_between[B]): one batched pass, two BatchNorm statistic groups
         z, z_ref = self.model.encode_multi([x, between], needs_grad=[True, False])
@@ -86,10 +96,22 @@ class CombinedStepMixin(object):
         self._backward_and_step(loss, eval_mode)
         self._log("loss_ae", loss)
         self._log("loss_latent_1", loss_latent)
+        return {"z_mix": z_mix, "s_mix": s_mix, "out": out}
+
+    def train(self, batch_item, keep_predictions=True, eval_mode=False):
+        dev_batch = {k: (self._to_device(v) if k in ("image", "slice_between", "alpha_from", "alpha_to") else v)
+                     for k, v in batch_item.items()}
+        self.model.train(not eval_mode)
+        self._iters += 1
+        self._lambda_tensor()
+        if self._graph_ok(keep_predictions, eval_mode):
+            self._train_graphed(dev_batch)
+            return
+        r = self._step_core(dev_batch, eval_mode)
         if keep_predictions:
-            s = s_mix.detach().cpu()
-            self.train_predictions = {"z_mix": z_mix.detach().cpu(), "pred_alphas": self._pred_alphas(batch_item),
-                                      "slice_inbetween_mix": s, "slice_inbetween_05": s, "reconstruction": out.detach().cpu()}
+            s = r["s_mix"].detach().cpu()
+            self.train_predictions = {"z_mix": r["z_mix"].detach().cpu(), "pred_alphas": self._pred_alphas(batch_item),
+                                      "slice_inbetween_mix": s, "slice_inbetween_05": s, "reconstruction": r["out"].detach().cpu()}
 
     def _pred_alphas(self, batch_item):
         return torch.tensor([0.5])

@@ -39,7 +39,7 @@ class AEBaseTrainer(BaseTrainer):
         if self.args.get("use_ssim_loss"):
             raise NotImplementedError("ERROR - SSIM as loss is disabled (as in the reference)")
         self.dp = None                                # set by parallel.DataParallelContext.attach()
-        self._step_graph = None
+        self._graph_enabled = False
         if model_file is not None:
             self.model_file = model_file
             self.load(model_file)
@@ -68,6 +68,47 @@ class AEBaseTrainer(BaseTrainer):
             self.opt_ae.step()
         if self.opt_sched_ae is not None:
             self.opt_sched_ae.step()
+
+    # ---- HIP-graph capture of the whole step (forward, backward, Adam) ---------------------------------------------
+    def enable_step_graph(self, eager_steps=3):
+        """Replay the training step from ONE captured HIP graph (no per-kernel host launches).  The first ``eager_steps``
+        calls still run eagerly (allocator / plan caches warm up), then the step is captured once per input signature."""
+        self._graph_enabled = True
+        self._graph_eager_left = int(eager_steps)
+        self._graphs = {}
+
+    def _graph_ok(self, keep_predictions, eval_mode):
+        if not getattr(self, "_graph_enabled", False) or keep_predictions or eval_mode:
+            return False
+        if self.opt_sched_ae is not None or (self.dp is not None and self.dp.active) or self.args.get("get_masks"):
+            return False                       # per-step learning rates / collectives / masks are not captured
+        if self._graph_eager_left > 0:
+            self._graph_eager_left -= 1
+            return False
+        return True
+
+    def _train_graphed(self, dev_batch):
+        keys = [k for k in ("image", "slice_between", "alpha_from", "alpha_to") if k in dev_batch]
+        sig = tuple((k, tuple(dev_batch[k].shape)) for k in keys)
+        g = self._graphs.get(sig)
+        if g is None:
+            static = {k: dev_batch[k].clone() for k in keys}
+            graph = torch.cuda.CUDAGraph()
+            sink = {}
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                self._capture_sink = sink
+                try:
+                    self._step_core(static, False)
+                finally:
+                    self._capture_sink = None
+            g = self._graphs[sig] = (graph, static, sink)
+        graph, static, sink = g
+        for k in keys:
+            static[k].copy_(dev_batch[k])
+        graph.replay()
+        for k, v in sink.items():
+            self.losses[k].append(v.detach().clone())
 
     def train(self, batch_item, keep_predictions=True, eval_mode=False):
         """Plain ``ae`` step (reference :71-109): reconstruction loss only; latent loss and the 0.5-mix are logged."""

@@ -147,8 +147,10 @@ class PNetLin(nn.Module):
         return pk
 
     def _affine(self, mul, add):
-        sh = self.scaling_layer.shift.reshape(-1).tolist()
-        sc = self.scaling_layer.scale.reshape(-1).tolist()
+        hc = self.__dict__.get("_scaling_host")
+        if hc is None:          # one device read, cached: no host sync per call (and legal under HIP-graph capture)
+            hc = self._scaling_host = (self.scaling_layer.shift.reshape(-1).tolist(), self.scaling_layer.scale.reshape(-1).tolist())
+        sh, sc = hc
         return [mul / s for s in sc], [(add - h) / s for h, s in zip(sh, sc)]
 
     def _forward_hip(self, x0, x1, mul, add, save):

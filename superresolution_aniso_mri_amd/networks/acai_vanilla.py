@@ -103,10 +103,12 @@ class HipAE(nn.Module):
         for r in self.__dict__.get("_runners", {}).values():
             r.mark_weights_dirty()
 
-    def set_sync_bn(self, fn):
-        """Data parallel: ``fn(sums, counts)`` all-reduces BatchNorm partial sums across ranks (SyncBN)."""
+    def set_sync_bn(self, fn, count_scale=1.0):
+        """Data parallel: ``fn(sums)`` all-reduces BatchNorm partial sums across ranks (SyncBN); ``count_scale`` =
+        B_global / B_local turns local element counts into global ones."""
         for name in ("enc", "dec"):
-            self._runner(name).sync_bn = fn
+            r = self._runner(name)
+            r.sync_bn, r.count_scale = fn, float(count_scale)
 
     # -- multi-group passes (one launch sequence, independent BatchNorm statistics per sub-batch) ---------
     def _pass(self, name, tensors, needs_grad=None):

@@ -49,6 +49,8 @@ def lerp_mix(z, alpha_from, alpha_to):
         raise ValueError("latent size per image must be a multiple of 4")
 
     def coef(a):
+        if isinstance(a, (int, float)):
+            return torch.full((B,), float(a), dtype=torch.float32, device=z.device)     # fill kernel: graph-capture safe
         a = torch.as_tensor(a, dtype=torch.float32, device=z.device).reshape(-1)
         if a.numel() == 1:
             a = a.expand(B)
@@ -129,6 +131,7 @@ class HipAdam(torch.optim.Adam):
             k = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
                 g_old = p.grad
+                p._aesr_grad_fresh = False
                 p.grad = self.flat_g[off:off + k].view_as(p.data)
                 if g_old is not None:
                     p.grad.copy_(g_old)
@@ -139,6 +142,8 @@ class HipAdam(torch.optim.Adam):
     def zero_grad(self, set_to_none=False):
         self._check_views()
         self.flat_g.zero_()
+        for p in self._plist:
+            p._aesr_grad_fresh = True      # engine may overwrite p.grad directly instead of going through autograd's +=
 
     @torch.no_grad()
     def step(self, closure=None):

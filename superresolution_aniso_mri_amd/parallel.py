@@ -41,16 +41,21 @@ class DataParallelContext(object):
         lo, hi = self.shard_range(B_global)
         self.global_B = B_global
         self.weight = float(hi - lo) / float(B_global)
+        self._update_model()
         return lo, hi
 
+    def _update_model(self):
+        tr = getattr(self, "trainer", None)
+        if tr is not None and hasattr(tr.model, "set_sync_bn"):
+            tr.model.set_sync_bn(self.sync_bn, 1.0 / self.weight if self.weight > 0 else 1.0)
+
     # ---- hooks -----------------------------------------------------------------------------------------------
-    def sync_bn(self, sums, counts):
-        """All-reduce BatchNorm partial sums (and element counts) across ranks, in place."""
+    def sync_bn(self, sums):
+        """All-reduce BatchNorm partial sums across ranks, in place (element counts are known on the host: every
+        sub-batch of a step scales by the same B_global / B_local, see ``count_scale``)."""
         if not self.active:
             return
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        if counts is not None:
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
 
     def allreduce_gradients(self, opt):
         if not self.active:
@@ -78,8 +83,8 @@ class DataParallelContext(object):
     def attach(self, trainer):
         """Make ``trainer`` data parallel: SyncBN hooks, gradient all-reduce, identical initial parameters."""
         trainer.dp = self
-        if hasattr(trainer.model, "set_sync_bn"):
-            trainer.model.set_sync_bn(self.sync_bn)
+        self.trainer = trainer
+        self._update_model()
         self.broadcast_parameters(trainer.model)
         return trainer
 

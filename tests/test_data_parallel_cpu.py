@@ -55,9 +55,9 @@ def _worker(rank, world, port, B, out):
     gl = dp.reduce_scalar(float(loss), weighted=True)
     # SyncBN hook on fake partial sums
     sums = torch.full((1, 2, 4), float(rank + 1), dtype=torch.float64)
-    counts = torch.tensor([float(hi - lo)], dtype=torch.float64)
-    dp.sync_bn(sums, counts)
-    assert float(sums[0, 0, 0]) == sum(range(1, world + 1)) and float(counts[0]) == B
+    dp.sync_bn(sums)
+    assert float(sums[0, 0, 0]) == sum(range(1, world + 1))
+    assert abs((hi - lo) / dp.weight - B) < 1e-9          # local count * count_scale == global count
     assert dp.max_over_ranks(rank) == world - 1
     if rank == 0:
         torch.save({"grads": [p.grad.clone() for p in ae.parameters()], "loss": gl,

@@ -250,9 +250,9 @@ def test_bn_groups_fwd_bwd(hip, mode, shape):
     sums = torch.empty((G, 2, C), dtype=torch.float64, device="cuda")
     ns = hip.int_array(nstart)
     hip.check(L.aesr_bn_stats(hip.ptr(yd), hip.ptr(partial), hip.ptr(sums), H * W, C, G, ns, hip.stream()), "stats")
-    counts = torch.tensor([n0 * H * W, (N - n0) * H * W], dtype=torch.float64, device="cuda")
+    counts = hip.double_array([n0 * H * W, (N - n0) * H * W])
     st = [torch.empty((G, C), device="cuda") for _ in range(4)]
-    hip.check(L.aesr_bn_finalize(hip.ptr(sums), hip.ptr(counts), hip.ptr(gam), hip.ptr(bet), hip.ptr(rm), hip.ptr(rv), hip.ptr(nbt),
+    hip.check(L.aesr_bn_finalize(hip.ptr(sums), counts, hip.ptr(gam), hip.ptr(bet), hip.ptr(rm), hip.ptr(rv), hip.ptr(nbt),
                                  *[hip.ptr(t) for t in st], C, G, 0.1, 1e-5, 1, 1, hip.stream()), "finalize")
     Ho, Wo = ref.shape[2:]
     out = torch.empty((N, Ho, Wo, C), device="cuda")
@@ -268,7 +268,7 @@ def test_bn_groups_fwd_bwd(hip, mode, shape):
     coef = torch.empty((1, 2, C), device="cuda")
     dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
     dpre = torch.empty((n0, H, W, C), device="cuda")
-    hip.check(L.aesr_bn_bwd_apply(hip.ptr(god), hip.ptr(yd), hip.ptr(st[0]), hip.ptr(st[1]), hip.ptr(st[2]), hip.ptr(sums1), hip.ptr(counts),
+    hip.check(L.aesr_bn_bwd_apply(hip.ptr(god), hip.ptr(yd), hip.ptr(st[0]), hip.ptr(st[1]), hip.ptr(st[2]), hip.ptr(sums1), counts,
                                   hip.ptr(coef), hip.ptr(dgam), hip.ptr(dbet), hip.ptr(dpre), n0, H, W, C, mode, 1, 0.01, 1, ns1,
                                   hip.stream()), "bwd_apply")
     mask = torch.where(y.detach()[:n0] > 0, 1.0, 0.01)

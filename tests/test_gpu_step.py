@@ -89,3 +89,22 @@ def test_checkpoint_roundtrip(tmp_path):
     t2.train(batch1)
     for (k, a), (_, b) in zip(t1.model.state_dict().items(), t2.model.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_step_graph_replay_equals_eager():
+    """The captured HIP graph replays exactly the kernels of the eager step: identical parameters after 6 steps."""
+    rec = dict(np.load(os.path.join(GOLDEN, "step_k3_brain_lpips.npz")))
+    eager, graphed = make_trainer("brain_lpips", rec), make_trainer("brain_lpips", rec)
+    graphed.enable_step_graph(eager_steps=2)
+    for step in range(6):
+        k = step % 3
+        batch = {"image": torch.from_numpy(rec["image_%d" % k]), "slice_between": torch.from_numpy(rec["between_%d" % k]),
+                 "alpha_from": torch.from_numpy(rec["alpha_from"]), "alpha_to": torch.from_numpy(rec["alpha_to"])}
+        eager.train(batch, keep_predictions=False)
+        graphed.train(batch, keep_predictions=False)
+    assert len(graphed._graphs) == 1 and graphed.iters == eager.iters == 7
+    for key in ("loss_ae", "loss_ae_dist", "loss_ae_dist_extra", "loss_latent_1"):
+        assert graphed.losses[key].floats() == eager.losses[key].floats(), key
+    for (k, a), (_, b) in zip(eager.model.state_dict().items(), graphed.model.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert float(graphed.opt_ae.dev_state[0]) == 6.0
