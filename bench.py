@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--config", choices=["c2", "c3"], default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--triplets", type=int, default=12, help="global batch in triplets (12 = the BASELINE workload; other values are for experiments only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured step")
     opt = ap.parse_args()
 
@@ -78,7 +79,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     dp = DataParallelContext(device=device)
-    B, H = 12, 160
+    B, H = opt.triplets, 160
     torch.manual_seed(892372)
     trainer = get_trainer_dynamic(build_args(opt.config, device))
     if dp.active:

@@ -1,6 +1,7 @@
 // extern "C" entry points of libaesr_hip.so (declared in include/aesr_hip.h) + the host-side tile planners.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -65,6 +66,14 @@ static ConvPlan plan_conv(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
     }
     for (int TH = 1; TH <= Ho && TH <= 64; ++TH)
         for (int TW = 1; TW <= Wo && TW <= 64; ++TW) consider(1, TH, TW);
+    if (const char* e = getenv("AESR_IGEMM_TILE")) {          // experiments: force "TI,TH,TW"
+        int ti, th, tw;
+        if (sscanf(e, "%d,%d,%d", &ti, &th, &tw) == 3) { p.TI = ti; p.TH = th < Ho ? th : Ho; p.TW = tw < Wo ? tw : Wo; }
+    }
+    if (getenv("AESR_PLAN_DEBUG"))
+        fprintf(stderr, "[aesr plan] conv N=%d %dx%d Cin=%d Cout=%d KS=%d -> TI=%d TH=%d TW=%d NB=%d nblk=%d items=%ld\n", N, Ho, Wo, Cin,
+                Cout, KS, p.TI, p.TH, p.TW, p.NB, ceil_div(p.TI * p.TH * p.TW, 16),
+                (long)ceil_div(N, p.TI) * ceil_div(Ho, p.TH) * ceil_div(Wo, p.TW) * ncout);
     g_conv_plans[key] = p;
     return p;
 }
@@ -154,7 +163,7 @@ static int run_igemm(const float* in, const float* packed, const float* bias, co
     a.in = in; a.wpk = packed; a.bias = bias; a.ysave = ysave; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = p.CinP; a.Cout = Cout; a.CoutP = p.CoutP; a.Ho = Ho; a.Wo = Wo; a.pad = pad;
     a.TI = p.TI; a.TH = p.TH; a.TW = p.TW; a.tiles_y = ceil_div(Ho, p.TH); a.tiles_x = ceil_div(Wo, p.TW);
-    a.act = act; a.mask_act = mask_act; a.slope = slope;
+    a.act = act; a.mask_act = mask_act; a.slope = slope; a.dbgbuf = nullptr;
     return aesr_launch_conv_igemm(a, KS, p.NB, p.MBW, st);
 }
 

@@ -7,6 +7,7 @@ struct IgemmArgs {
     const float* in; const float* wpk; const float* bias; const float* ysave; float* out;
     int N, H, W, Cin, CinP, Cout, CoutP, Ho, Wo, pad;
     int TI, TH, TW, tiles_y, tiles_x, nitems, dbg;
+    float* dbgbuf;   // debug stamps (nullptr in normal operation)
     int act, mask_act;
     float slope;
 };

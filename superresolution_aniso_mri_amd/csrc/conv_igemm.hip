@@ -22,6 +22,7 @@
 //
 // Replaces the ATen/cuDNN conv2d calls behind networks/acai_vanilla.py:55-56,68,70,87-88,96,98 and
 // lpips/pretrained_networks.py:107-116.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "aesr_kernels.h"
@@ -41,9 +42,11 @@ constexpr int IG_MAXP = 6;   // staging pieces (16 B) per thread: patch pixels *
 template <int KS, int NB, int MBW>
 __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
+    if ((a.dbg & 16) && wave >= 4) __builtin_amdgcn_s_setprio(1);      // experiment: static priority for the younger half
     const int G = gridDim.x;
     const int nitems = a.nitems, ncot = a.CoutP / (16 * NB);
 
@@ -55,6 +58,8 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
     constexpr int NWP = KS * KS * 4 * TN;                 // 16-byte weight pieces per (chunk, cout tile)
     constexpr int WP = (NWP + IG_NT - 1) / IG_NT;         // ... per thread
     float* ldsW = lds + PP * IG_S;                        // [tap][ci/4][TN][4]
+    float* ldsBias = ldsW + NWP * 4;                       // [CoutP] (zeros when there is no bias)
+    for (int c = tid; c < a.CoutP; c += IG_NT) ldsBias[c] = (a.bias && c < a.Cout) ? a.bias[c] : 0.f;
 
     // ---- position-independent maps (computed once) ------------------------------------------------------------
     int a_off[MBW], pix[MBW];                 // pix = img<<20 | r<<10 | c of this lane's pixel of block i, or -1
@@ -136,7 +141,6 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
 // epilogue of one finished item: D layout of 16x16x4: column (pixel) = lane&15, row (cout) = 4*(lane>>4)+j
 #define IG_EPILOGUE(en0, ey0, ex0, eco0)  \
     {  \
-        const bool vec = (a.Cout & 3) == 0;  \
 _Pragma("unroll")  \
         for (int i = 0; i < MBW; ++i) {  \
             if (pix[i] >= 0 && !(a.dbg & 4)) {  \
@@ -149,7 +153,7 @@ _Pragma("unroll")  \
                         f32x4 v = acc[i][nb];  \
                         if (vec) {  \
                             if (co < a.Cout) {  \
-                                if (a.bias) v += *(const f32x4*)(a.bias + co);  \
+                                v += *(const f32x4*)(ldsBias + co);  \
 _Pragma("unroll")  \
                                 for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act, a.slope);  \
                                 if (a.ysave) {  \
@@ -164,7 +168,7 @@ _Pragma("unroll")  \
                             for (int e = 0; e < 4; ++e) {  \
                                 if (co + e < a.Cout) {  \
                                     float s = v[e];  \
-                                    if (a.bias) s += a.bias[co + e];  \
+                                    s += ldsBias[co + e];  \
                                     s = act_apply(s, a.act, a.slope);  \
                                     if (a.ysave) s *= act_grad_from_output(a.ysave[ob + co + e], a.mask_act, a.slope);  \
                                     a.out[ob + co + e] = s;  \
@@ -190,19 +194,43 @@ _Pragma("unroll")  \
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[i][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* wfrag = ldsW + (g * TN + l15) * 4;              // + tap * 4*TN*4 + nb*64
+    // finished-item output waiting to be stored: the stores are TRICKLED through the next chunk's tap loop (one 16-byte
+    // store per tap slot) so that the 8 waves never stall on the CU's ~10 B/clk store path all at once
+    constexpr int NPIECE = MBW * NB;
+    constexpr int LPT = (IG_MAXP + WP + KS * KS - 1) / (KS * KS) < 2 ? 2 : (IG_MAXP + WP + KS * KS - 1) / (KS * KS);   // loads per tap
+    constexpr int PPS = (NPIECE + KS * KS * MBW - 1) / (KS * KS * MBW);       // pieces per (tap, block) slot
+    f32x4 pend[MBW][NB], pmask[MBW][NB];
+    int pend_ob[MBW];
+    int pend_co0 = 0;
+    bool pend_valid = false;
+    const bool vec = (a.Cout & 3) == 0;
 
-    bool first = true, ep_pending = false;
-    int en0_ = 0, ey0_ = 0, ex0_ = 0, eco0_ = 0;
+    unsigned long long tphase[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    const bool stamp = (a.dbg & 8) && a.dbgbuf;
+#define IG_STAMP(k)                                                        \
+    if (stamp) {                                                           \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();        \
+        tphase[k] += t_ - tlast;                                           \
+        tlast = t_;                                                        \
+    }
+    if (stamp) {
+        tlast = __builtin_amdgcn_s_memtime();
+        tphase[5] = tlast - t_entry;
+    }
+    bool first = true;
     while (true) {
         if (!first) __syncthreads();           // every wave has finished reading the previous chunk from LDS
         first = false;
+        IG_STAMP(0)
 #pragma unroll
         for (int j = 0; j < IG_MAXP; ++j)
             if (piece[j] >= 0) *(f32x4*)(lds + ((tid + IG_NT * j) >> 2) * IG_S + part4) = R[j];
 #pragma unroll
         for (int j = 0; j < WP; ++j)
             if (tid + IG_NT * j < NWP) *(f32x4*)(ldsW + (tid + IG_NT * j) * 4) = RW[j];
+        IG_STAMP(1)
         __syncthreads();
+        IG_STAMP(2)
         // advance the load state and put the next patch chunk in flight
         if (l_cc + 1 < nchunks) {
             ++l_cc;
@@ -211,17 +239,26 @@ _Pragma("unroll")  \
             l_cc = 0;
             if (l_item < nitems) IG_COMPUTE_GOFF(l_item)
         }
-        if (l_item < nitems) IG_ISSUE_LOADS(l_item, l_cc)
-        if (ep_pending) {
-            IG_EPILOGUE(en0_, ey0_, ex0_, eco0_)
-            ep_pending = false;
+        // the pending item's mask values (data-gradient use) go in flight BEFORE the patch prefetch: vmcnt retires in
+        // order, so they must not queue behind HBM loads
+        if (pend_valid && a.ysave) {
 #pragma unroll
             for (int i = 0; i < MBW; ++i)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[i][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int co = pend_co0 + nb * 16 + 4 * g;
+                    pmask[i][nb] = (f32x4){1.f, 1.f, 1.f, 1.f};
+                    if (pend_ob[i] >= 0 && co < a.Cout) pmask[i][nb] = *(const f32x4*)(a.ysave + pend_ob[i] + co);
+                }
         }
+        // the prefetch of the next chunk is TRICKLED through the first taps (IG_LOADS_PER_TAP pieces per tap): issued
+        // as one burst right after the barrier, the 8 waves would queue on the CU's address path for ~2.5k cycles
+        const bool do_load = l_item < nitems;
+        const float* wsrc = a.wpk + ((size_t)l_cc * ncot + (l_item % ncot)) * (NWP * 4);
+        const bool chan_ok = l_cc * 16 + part4 < a.Cin;
 
         const bool last_chunk = (cc + 1 == nchunks);
+        IG_STAMP(3)
         // explicit software pipeline, pinned with sched_barrier: the LDS reads of block i+1 (and of the next tap's
         // weight fragments) are issued BEFORE the 4*NB MFMAs of block i, so their latency hides under 128*NB cycles of
         // matrix work (left alone, the scheduler sinks the reads to just before their first use)
@@ -237,6 +274,23 @@ _Pragma("unroll")  \
             const int tap_off = ((tap / KS) * PW + (tap % KS)) * IG_S;
 #pragma unroll
             for (int i = 0; i < MBW; ++i) {
+                if (i == 0 && do_load) {
+#pragma unroll
+                    for (int u = 0; u < LPT; ++u) {
+                        constexpr int zero = 0;
+                        const int pj = tap * LPT + u + zero;
+                        if (pj < IG_MAXP) {
+                            R[pj < IG_MAXP ? pj : 0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            if (goff[pj < IG_MAXP ? pj : 0] >= 0 && chan_ok && !(a.dbg & 1))
+                                R[pj < IG_MAXP ? pj : 0] = *(const f32x4*)(a.in + goff[pj < IG_MAXP ? pj : 0] + l_cc * 16);
+                        } else if (pj - IG_MAXP < WP) {
+                            const int wj = pj - IG_MAXP < WP ? pj - IG_MAXP : 0;
+                            const int w_ = tid + IG_NT * wj;
+                            RW[wj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            if (w_ < NWP && !(a.dbg & 2)) RW[wj] = *(const f32x4*)(wsrc + w_ * 4);
+                        }
+                    }
+                }
                 const f32x4 acur = anxt;
                 if (i + 1 < MBW) {
                     anxt = *(const f32x4*)(lds + a_off[i + 1 < MBW ? i + 1 : i] + tap_off);
@@ -253,23 +307,88 @@ _Pragma("unroll")  \
                     for (int nb = 0; nb < NB; ++nb)
                         acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[nb][r], acur[r], acc[i][nb], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (pend_valid) {
+#pragma unroll
+                    for (int pp = 0; pp < PPS; ++pp) {
+                        constexpr int dummy = 0;
+                        const int k = (tap * MBW + i) * PPS + pp + dummy;
+                        if (k < NPIECE) {
+                            const int pi = k / NB, pnb = k % NB;
+                            const int co = pend_co0 + pnb * 16 + 4 * g;
+                            if (pend_ob[pi] >= 0 && co < a.Cout && !(a.dbg & 4)) {
+                                f32x4 v = pend[pi][pnb];
+                                if (a.ysave) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_output(pmask[pi][pnb][e], a.mask_act, a.slope);
+                                }
+                                *(f32x4*)(a.out + pend_ob[pi] + co) = v;
+                            }
+                        }
+                    }
+                }
             }
         }
+        pend_valid = false;
 
+        IG_STAMP(4)
         if (!last_chunk) {
             ++cc;
             continue;
         }
-        // the finished item's epilogue is DEFERRED to the next iteration (after the LDS write + load issue): its stores
-        // would otherwise sit in the in-order vmcnt queue in front of the wait that guards the prefetched registers
-        ep_pending = true;
-        en0_ = cn0; ey0_ = cy0; ex0_ = cx0; eco0_ = co0;
+        // item finished: bias + activation now, stores later (trickled through the next chunk / flushed after the loop)
+        if (vec) {
+#pragma unroll
+            for (int i = 0; i < MBW; ++i) {
+                pend_ob[i] = -1;
+                if (pix[i] >= 0) {
+                    const int n = cn0 + (pix[i] >> 20), y = cy0 + ((pix[i] >> 10) & 1023), x = cx0 + (pix[i] & 1023);
+                    if (n < a.N && y < a.Ho && x < a.Wo) pend_ob[i] = ((n * a.Ho + y) * a.Wo + x) * a.Cout;
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    f32x4 v = acc[i][nb] + *(const f32x4*)(ldsBias + co0 + nb * 16 + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act, a.slope);
+                    pend[i][nb] = v;
+                    acc[i][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            pend_co0 = co0;
+            pend_valid = true;
+        } else {
+            IG_EPILOGUE(cn0, cy0, cx0, co0)
+#pragma unroll
+            for (int i = 0; i < MBW; ++i)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[i][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         c_item += G;
         if (c_item >= nitems) break;
         cc = 0;
         IG_TILE_ORIGIN(c_item, cn0, cy0, cx0, co0)
     }
-    if (ep_pending) IG_EPILOGUE(en0_, ey0_, ex0_, eco0_)
+    if (pend_valid && !(a.dbg & 4)) {            // last item of this workgroup: flush
+#pragma unroll
+        for (int i = 0; i < MBW; ++i)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int co = pend_co0 + nb * 16 + 4 * g;
+                if (pend_ob[i] >= 0 && co < a.Cout) {
+                    f32x4 v = pend[i][nb];
+                    if (a.ysave) {
+                        const f32x4 ys = *(const f32x4*)(a.ysave + pend_ob[i] + co);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_output(ys[e], a.mask_act, a.slope);
+                    }
+                    *(f32x4*)(a.out + pend_ob[i] + co) = v;
+                }
+            }
+    }
+    if (stamp && tid == 0) {
+        tphase[6] = __builtin_amdgcn_s_memtime() - tlast;
+        for (int k = 0; k < 7; ++k) a.dbgbuf[blockIdx.x * 7 + k] = (float)tphase[k];
+    }
+#undef IG_STAMP
 #undef IG_EPILOGUE
 #undef IG_TILE_ORIGIN
 #undef IG_COMPUTE_GOFF
@@ -320,7 +439,7 @@ int aesr_launch_pack_weights(const float* w, float* p, int Cout, int Cin, int KS
 template <int KS, int NB, int MBW>
 static int launch_one(const IgemmArgs& a, hipStream_t st) {
     const int PP = a.TI * (a.TH + KS - 1) * (a.TW + KS - 1);
-    const size_t shmem = ((size_t)PP * IG_S + (size_t)KS * KS * 4 * 16 * NB * 4) * sizeof(float);
+    const size_t shmem = ((size_t)PP * IG_S + (size_t)KS * KS * 4 * 16 * NB * 4 + a.CoutP) * sizeof(float);
     if (shmem > 160 * 1024) {
         aesr_set_error("conv_igemm: tile needs %zu B of LDS", shmem);
         return AESR_ERR_ARG;
@@ -330,8 +449,25 @@ static int launch_one(const IgemmArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_f32<KS, NB, MBW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    int grid = 2 * 256;                       // persistent: up to two 8-wave workgroups per CU
+    int grid = 256;                           // persistent: one 8-wave workgroup per CU (register budget allows one)
+    if (const char* e = getenv("AESR_IGEMM_GRID")) grid = atoi(e);
     if (grid > a.nitems) grid = a.nitems;
+    if (a.dbg & 8) {                          // debug: per-phase cycle stamps, printed after a host sync
+        static float* dbuf = nullptr;
+        if (!dbuf) (void)hipMalloc(&dbuf, 1024 * 7 * sizeof(float));
+        IgemmArgs b = a;
+        b.dbgbuf = dbuf;
+        hipLaunchKernelGGL((conv_igemm_f32<KS, NB, MBW>), dim3(grid), dim3(IG_NT), shmem, st, b);
+        (void)hipStreamSynchronize(st);
+        static float host[1024 * 7];
+        (void)hipMemcpy(host, dbuf, grid * 7 * sizeof(float), hipMemcpyDeviceToHost);
+        double s5[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < grid; ++i) for (int k = 0; k < 7; ++k) s5[k] += host[i * 7 + k];
+        fprintf(stderr, "[igemm stamps] grid=%d items=%d per-WG kcycles: barrier1 %.1f | lds-write %.1f | barrier2 %.1f | loads+epilogue %.1f | mfma %.1f | setup %.1f | flush %.1f\n",
+                grid, a.nitems, s5[0] / grid / 1e3, s5[1] / grid / 1e3, s5[2] / grid / 1e3, s5[3] / grid / 1e3, s5[4] / grid / 1e3,
+                s5[5] / grid / 1e3, s5[6] / grid / 1e3);
+        return AESR_OK;
+    }
     hipLaunchKernelGGL((conv_igemm_f32<KS, NB, MBW>), dim3(grid), dim3(IG_NT), shmem, st, a);
     AESR_LAUNCH_CHECK("conv_igemm_f32");
     return AESR_OK;
