@@ -110,6 +110,11 @@ int aesr_bn_bwd_apply(const float* gout, const float* y, const float* mean, cons
                       const int* nstart_host, void* stream);
 
 /* ---- LPIPS-VGG (lpips/networks_basic.py:63-91, lpips/common.py:12-14, lpips/pretrained_networks.py:107-116) ---- */
+/* ScalingLayer (lpips/networks_basic.py:93-100, with the 2x-1 of lpips/perceptual.py:29-31 folded in) of a 1-channel image,
+ * materialised as 4 channels (c, c, c, 0) so VGG conv1_1 runs on the MFMA kernel: out4[p][c] = ca[c]*x[p] + cb[c];
+ * backward: dx[p] = sum_c ca[c]*d4[p][c].  n = number of pixels. */
+int aesr_scale_expand_fwd(const float* x, float* out4, size_t n, const float* ca_host, const float* cb_host, void* stream);
+int aesr_scale_expand_bwd(const float* d4, float* dx, size_t n, const float* ca_host, void* stream);
 /* nn.MaxPool2d(2): out [N,H/2,W/2,C]. */
 int aesr_maxpool2_fwd(const float* x, float* out, int N, int H, int W, int C, void* stream);
 /* dx = (scatter of gout to the FIRST maximum of each window + gadd) * (relu_mask ? x > 0 : 1); gadd may be NULL. */

@@ -39,6 +39,8 @@ SIGNATURES = {
     "aesr_bn_apply": (c_int, [P, P, P, P] + [c_int] * 6 + [IP, P]),
     "aesr_bn_bwd_reduce": (c_int, [P] * 6 + [c_int] * 6 + [IP, P]),
     "aesr_bn_bwd_apply": (c_int, [P] * 6 + [DP] + [P] * 4 + [c_int] * 6 + [c_float, c_int, IP, P]),
+    "aesr_scale_expand_fwd": (c_int, [P, P, c_size_t, FP, FP, P]),
+    "aesr_scale_expand_bwd": (c_int, [P, P, c_size_t, FP, P]),
     "aesr_maxpool2_fwd": (c_int, [P, P] + [c_int] * 4 + [P]),
     "aesr_maxpool2_bwd": (c_int, [P, P, P, P] + [c_int] * 5 + [P]),
     "aesr_lpips_tap_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P]),

@@ -44,7 +44,6 @@ static ConvPlan plan_conv(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
     p.MBW = (p.NB == 4) ? 2 : 4;                     // M-blocks per wave; 8 waves per workgroup
     const int maxpix = 128 * p.MBW, maxpatch = 760;  // 760 px * 80 B = 61 KB -> two workgroups per CU
     const int ncout = p.CoutP / (16 * p.NB);
-    const double kmf = (double)KS * KS * (p.CinP / 16) * 4 * 32;   // MFMA cycles per (M-block, N-block)
     double best = 1e300;
     p.TI = 1; p.TH = 1; p.TW = 1;
     auto consider = [&](int TI, int TH, int TW) {
@@ -53,7 +52,10 @@ static ConvPlan plan_conv(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
         if (TP > maxpix || PP > maxpatch) return;
         const int nblk = ceil_div(TP, 16);
         const long nwg = (long)ceil_div(N, TI) * ceil_div(Ho, TH) * ceil_div(Wo, TW) * ncout;
-        const double per = ceil_div(nblk, 8) * 2 * p.NB * kmf + (double)PP * (p.CinP / 16) * 3.0 + 1500.0;
+        // per work item: per 16-channel chunk the MFMA time of a SIMD (2 waves x blocks x NB x taps x 4 k-steps x 32 cycles)
+        // plus ~4.5k cycles of staging / barrier phases in which the matrix pipe idles (measured with the phase stamps)
+        const double nch = p.CinP / 16;
+        const double per = nch * (ceil_div(nblk, 8) * 2.0 * p.NB * KS * KS * 4 * 32 + 4500.0) + 3000.0;
         const double rounds = nwg <= 2048 ? (double)ceil_div((int)nwg, 256) : (double)nwg / 256.0;
         const double t = per * rounds;
         if (t < best * 0.999 || (t < best * 1.001 && TP > p.TI * p.TH * p.TW)) {
@@ -344,6 +346,16 @@ int aesr_maxpool2_bwd(const float* gout, const float* x, const float* gadd, floa
                       void* stream) {
     AESR_CHECK_ARG(gout && x && dx && N > 0 && H >= 2 && W >= 2 && C % 4 == 0, "aesr_maxpool2_bwd: bad arguments");
     return aesr_launch_maxpool2_bwd(gout, x, gadd, dx, N, H, W, C, relu_mask, (hipStream_t)stream);
+}
+
+int aesr_scale_expand_fwd(const float* x, float* out4, size_t n, const float* ca_host, const float* cb_host, void* stream) {
+    AESR_CHECK_ARG(x && out4 && ca_host && cb_host && n > 0 && n < ((size_t)1 << 29), "aesr_scale_expand_fwd: bad arguments");
+    return aesr_launch_scale_expand(x, out4, (int)n, ca_host, cb_host, 0, (hipStream_t)stream);
+}
+
+int aesr_scale_expand_bwd(const float* d4, float* dx, size_t n, const float* ca_host, void* stream) {
+    AESR_CHECK_ARG(d4 && dx && ca_host && n > 0 && n < ((size_t)1 << 29), "aesr_scale_expand_bwd: bad arguments");
+    return aesr_launch_scale_expand(d4, dx, (int)n, ca_host, nullptr, 1, (hipStream_t)stream);
 }
 
 int aesr_lpips_tap_fwd(const float* f, const float* lin_w, float* partial, int B, int HW, int C, void* stream) {

@@ -183,6 +183,35 @@ __global__ __launch_bounds__(256) void lpips_tap_bwd_kernel(const float* __restr
     }
 }
 
+// ScalingLayer (+ optional 2x-1) materialised as a 4-channel image so that VGG conv1_1 runs on the MFMA kernel:
+// out[p] = (ca0*x+cb0, ca1*x+cb1, ca2*x+cb2, 0);  backward: dx[p] = sum_c ca_c * d4[p][c]
+struct ScaleArgs { float ca[3], cb[3]; };
+
+__global__ __launch_bounds__(256) void scale_expand_fwd_kernel(const float* __restrict__ x, float* __restrict__ out4, int n, ScaleArgs a) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float v = x[i];
+        *(f32x4*)(out4 + (size_t)i * 4) = (f32x4){a.ca[0] * v + a.cb[0], a.ca[1] * v + a.cb[1], a.ca[2] * v + a.cb[2], 0.f};
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_expand_bwd_kernel(const float* __restrict__ d4, float* __restrict__ dx, int n, ScaleArgs a) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const f32x4 d = *(const f32x4*)(d4 + (size_t)i * 4);
+        dx[i] = a.ca[0] * d[0] + a.ca[1] * d[1] + a.ca[2] * d[2];
+    }
+}
+
+int aesr_launch_scale_expand(const float* x, float* out4, int n, const float* ca, const float* cb, int backward, hipStream_t st) {
+    ScaleArgs a;
+    for (int c = 0; c < 3; ++c) { a.ca[c] = ca[c]; a.cb[c] = cb ? cb[c] : 0.f; }
+    int grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (backward) hipLaunchKernelGGL(scale_expand_bwd_kernel, dim3(grid), dim3(256), 0, st, x, out4, n, a);
+    else hipLaunchKernelGGL(scale_expand_fwd_kernel, dim3(grid), dim3(256), 0, st, x, out4, n, a);
+    AESR_LAUNCH_CHECK("scale_expand");
+    return AESR_OK;
+}
+
 struct LpFinalArgs {
     const float* partial[8];
     float scale[8];

@@ -130,13 +130,20 @@ class PNetLin(nn.Module):
         if self._packed is not None and self._packed["key"] == key:
             return self._packed
         pk = {"key": key, "fwd": [], "bwd": [], "lin": []}
-        for c in convs[1:]:
-            w = c.weight
+        # conv1_1: 3 input channels padded to 4 (zero filter plane) so the MFMA kernel's 16-byte channel pieces apply
+        w0 = convs[0].weight
+        _hip.require_gpu_tensor(w0, "vgg weight")
+        w4 = torch.zeros((w0.shape[0], 4, 3, 3), device=w0.device, dtype=torch.float32)
+        w4[:, :3] = w0.detach()
+        pk["w4"] = w4
+        for c, w in [(None, w4)] + [(c, c.weight) for c in convs[1:]]:
+            cin = w.shape[1]
+            cout = w.shape[0]
             _hip.require_gpu_tensor(w, "vgg weight")
-            pf = torch.empty(lib.aesr_conv2d_packed_floats(c.out_channels, c.in_channels, 3, 0), device=w.device)
-            pb = torch.empty(lib.aesr_conv2d_packed_floats(c.out_channels, c.in_channels, 3, 1), device=w.device)
-            check(lib.aesr_conv2d_pack(ptr(w), ptr(pf), c.out_channels, c.in_channels, 3, 0, stream()), "aesr_conv2d_pack")
-            check(lib.aesr_conv2d_pack(ptr(w), ptr(pb), c.out_channels, c.in_channels, 3, 1, stream()), "aesr_conv2d_pack")
+            pf = torch.empty(lib.aesr_conv2d_packed_floats(cout, cin, 3, 0), device=w.device)
+            pb = torch.empty(lib.aesr_conv2d_packed_floats(cout, cin, 3, 1), device=w.device)
+            check(lib.aesr_conv2d_pack(ptr(w), ptr(pf), cout, cin, 3, 0, stream()), "aesr_conv2d_pack")
+            check(lib.aesr_conv2d_pack(ptr(w), ptr(pb), cout, cin, 3, 1, stream()), "aesr_conv2d_pack")
             pk["fwd"].append(pf)
             pk["bwd"].append(pb)
         for k, l in enumerate(self.lins):
@@ -163,10 +170,12 @@ class PNetLin(nn.Module):
         ca, cb = self._affine(mul, add)
         acts, pool_in, taps = [], {}, []
         c0 = convs[0]
+        x4 = torch.empty((N, H, W, 4), device=x.device)
+        check(lib.aesr_scale_expand_fwd(ptr(x), ptr(x4), N * H * W, _hip.float_array(ca), _hip.float_array(cb), stream()),
+              "aesr_scale_expand_fwd")
         cur = torch.empty((N, H, W, 64), device=x.device)
-        check(lib.aesr_conv2d_smallcin_fwd(ptr(x), ptr(c0.weight), ptr(c0.bias), None, ptr(cur), N, H, W, 3, 64, 3, 1,
-                                           _hip.ACT_RELU, 0, 0.0, 0, 1, _hip.float_array(ca), _hip.float_array(cb), stream()),
-              "aesr_conv2d_smallcin_fwd(vgg conv1_1)")
+        check(lib.aesr_conv2d_fwd(ptr(x4), ptr(pk["fwd"][0]), ptr(c0.bias), ptr(cur), N, H, W, 4, 64, 3, 1, _hip.ACT_RELU, 0.0,
+                                  stream()), "aesr_conv2d_fwd(vgg conv1_1)")
         acts.append(cur)
         nconv, h, w, cin = 1, H, W, 64
         partials, hws = [], []
@@ -181,7 +190,7 @@ class PNetLin(nn.Module):
                 continue
             c = convs[nconv]
             out = torch.empty((N, h, w, v), device=x.device)
-            check(lib.aesr_conv2d_fwd(ptr(cur), ptr(pk["fwd"][nconv - 1]), ptr(c.bias), ptr(out), N, h, w, cin, v, 3, 1,
+            check(lib.aesr_conv2d_fwd(ptr(cur), ptr(pk["fwd"][nconv]), ptr(c.bias), ptr(out), N, h, w, cin, v, 3, 1,
                                       _hip.ACT_RELU, 0.0, stream()), "aesr_conv2d_fwd(vgg)")
             cur, cin = out, v
             nconv += 1
@@ -227,16 +236,18 @@ class PNetLin(nn.Module):
             # now g = d/d(pre-activation of conv n); push it through conv n to its input
             if n == 1:
                 ca, _ = self._affine(mul, 0.0)
+                d4 = torch.empty((B, H, W, 4), device=dev)
+                check(lib.aesr_conv2d_dgrad(ptr(g), ptr(pk["bwd"][0]), None, ptr(d4), B, H, W, 4, 64, 3, 1, 0, 0.0, stream()),
+                      "aesr_conv2d_dgrad(vgg conv1_1)")
                 dx = torch.empty((B, H, W, 1), device=dev)
-                check(lib.aesr_conv2d_smallcin_dgrad(ptr(g), ptr(convs[0].weight), ptr(dx), B, H, W, 3, 64, 3, 1, 1,
-                                                     _hip.float_array(ca), stream()), "aesr_conv2d_smallcin_dgrad(vgg conv1_1)")
+                check(lib.aesr_scale_expand_bwd(ptr(d4), ptr(dx), B * H * W, _hip.float_array(ca), stream()), "aesr_scale_expand_bwd")
                 return dx
             cv = convs[n - 1]
             prev = acts[n - 2]
             producer_is_pool = (n - 1) in tap_of           # conv n reads pool(tap layer n-1)
             mask = None if producer_is_pool else prev
             dxs = torch.empty((B, h, w, cv.in_channels), device=dev)
-            check(lib.aesr_conv2d_dgrad(ptr(g), ptr(pk["bwd"][n - 2]), ptr(mask), ptr(dxs), B, h, w, cv.in_channels,
+            check(lib.aesr_conv2d_dgrad(ptr(g), ptr(pk["bwd"][n - 1]), ptr(mask), ptr(dxs), B, h, w, cv.in_channels,
                                         cv.out_channels, 3, 1, _hip.ACT_RELU if mask is not None else 0, 0.0, stream()),
                   "aesr_conv2d_dgrad(vgg)")
             g = dxs
