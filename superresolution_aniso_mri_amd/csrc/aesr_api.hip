@@ -243,7 +243,8 @@ size_t aesr_small_wgrad_workspace_floats(int nout) { return (size_t)SMALL_WGRAD_
 int aesr_conv2d_smallcin_wgrad(const float* in, const float* dout, float* dw, float* db, float* workspace, int N, int H,
                                int W, int Cin, int Cout, int pad, void* stream) {
     AESR_CHECK_ARG(in && dout && dw && db && workspace && Cin >= 1 && Cin <= 4, "aesr_conv2d_smallcin_wgrad: need 1 <= Cin <= 4");
-    AESR_CHECK_ARG(Cout > 0 && Cout <= 256 && 256 % Cout == 0, "aesr_conv2d_smallcin_wgrad: Cout=%d must divide 256", Cout);
+    AESR_CHECK_ARG(Cout >= 4 && Cout % 4 == 0 && 256 % (Cout / 4) == 0 && Cout <= 256,
+                   "aesr_conv2d_smallcin_wgrad: Cout=%d must be a multiple of 4 with Cout/4 dividing 256", Cout);
     SmallWgradArgs a;
     a.in = in; a.dout = dout; a.partial = workspace; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.pad = pad;
     a.Ho = H + 2 * pad; a.Wo = W + 2 * pad;
@@ -266,7 +267,7 @@ int aesr_conv2d_cout1_fwd(const float* x, const float* w, const float* bias, flo
 int aesr_conv2d_cout1_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W,
                             int Cin, void* stream) {
     AESR_CHECK_ARG(x && dy && dw && db && workspace, "aesr_conv2d_cout1_wgrad: null pointer");
-    AESR_CHECK_ARG(Cin > 0 && Cin <= 128 && 256 % Cin == 0, "aesr_conv2d_cout1_wgrad: Cin=%d must divide 256", Cin);
+    AESR_CHECK_ARG(Cin >= 4 && Cin <= 128 && 256 % Cin == 0, "aesr_conv2d_cout1_wgrad: Cin=%d must divide 256 (and be >= 4)", Cin);
     Cout1WgradArgs a;
     a.x = x; a.dy = dy; a.partial = workspace; a.N = N; a.H = H; a.W = W; a.Cin = Cin;
     a.TH = H < 16 ? H : 16; a.TW = W < 16 ? W : 16;

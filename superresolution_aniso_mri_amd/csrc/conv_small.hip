@@ -43,19 +43,35 @@ __global__ __launch_bounds__(256) void conv_smallcin_fwd_kernel(SmallArgs a) {
     }
 }
 
-// Same op, one thread = one output pixel x 4 consecutive couts (Cout % 4 == 0): 16-byte stores, 32-bit index math.
+// Same op, one workgroup per output row (n, y); a thread owns one cout quad (256 % (Cout/4) == 0) and walks the row:
+// no per-element integer division, 16-byte stores, the quad's filter taps cached in registers when Cin*KS*KS <= 9.
 __global__ __launch_bounds__(256) void conv_smallcin_fwd4_kernel(SmallArgs a) {
     const int C4 = a.Cout >> 2;
-    const int total = a.N * a.Ho * a.Wo * C4;
+    const int row = blockIdx.x;
+    const int n = row / a.Ho, y = row - n * a.Ho;
+    const int c4 = threadIdx.x % C4, xl = threadIdx.x / C4, XL = 256 / C4;
     const int cmem = a.bcast ? 1 : a.Cin;
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
-        const int c4 = idx % C4;
-        int pix = idx / C4;
-        const int x = pix % a.Wo;
-        pix /= a.Wo;
-        const int y = pix % a.Ho;
-        const int n = pix / a.Ho;
-        f32x4 s = a.bias ? *(const f32x4*)(a.bias + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int K = a.Cin * a.KS * a.KS;
+    f32x4 wreg[9];
+    const bool cached = K <= 9;
+    if (cached) {
+        for (int k = 0; k < 9; ++k) {
+            wreg[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (k < K) {
+                const int ci = k / (a.KS * a.KS), tap = k - ci * a.KS * a.KS;
+                const int ky = tap / a.KS, kx = tap - ky * a.KS;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = c4 * 4 + e;
+                    wreg[k][e] = a.transpose ? a.w[((ci * a.Cout + co) * a.KS + (a.KS - 1 - ky)) * a.KS + (a.KS - 1 - kx)]
+                                             : a.w[((co * a.Cin + ci) * a.KS + ky) * a.KS + kx];
+                }
+            }
+        }
+    }
+    const f32x4 bias = a.bias ? *(const f32x4*)(a.bias + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int x = xl; x < a.Wo; x += XL) {
+        f32x4 s = bias;
         for (int ky = 0; ky < a.KS; ++ky) {
             const int gy = y + ky - a.pad;
             if (gy < 0 || gy >= a.H) continue;
@@ -65,25 +81,36 @@ __global__ __launch_bounds__(256) void conv_smallcin_fwd4_kernel(SmallArgs a) {
                 const float* ip = a.in + ((size_t)(n * a.H + gy) * a.W + gx) * cmem;
                 for (int ci = 0; ci < a.Cin; ++ci) {
                     const float v = a.bcast ? a.ca[ci] * ip[0] + a.cb[ci] : ip[ci];
+                    if (cached) {
+                        // static register indexing: K <= 9 slots, select by comparison (wave-uniform)
+                        const int k = ci * a.KS * a.KS + ky * a.KS + kx;
+                        f32x4 wv = wreg[0];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int co = c4 * 4 + e;
-                        const float wv = a.transpose
-                                             ? a.w[((ci * a.Cout + co) * a.KS + (a.KS - 1 - ky)) * a.KS + (a.KS - 1 - kx)]
-                                             : a.w[((co * a.Cin + ci) * a.KS + ky) * a.KS + kx];
-                        s[e] = fmaf(v, wv, s[e]);
+                        for (int q = 1; q < 9; ++q)
+                            if (k == q) wv = wreg[q];
+                        s += wv * v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int co = c4 * 4 + e;
+                            const float wv = a.transpose
+                                                 ? a.w[((ci * a.Cout + co) * a.KS + (a.KS - 1 - ky)) * a.KS + (a.KS - 1 - kx)]
+                                                 : a.w[((co * a.Cin + ci) * a.KS + ky) * a.KS + kx];
+                            s[e] = fmaf(v, wv, s[e]);
+                        }
                     }
                 }
             }
         }
+        const size_t o = ((size_t)(n * a.Ho + y) * a.Wo + x) * a.Cout + c4 * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[e] = act_apply(s[e], a.act, a.slope);
         if (a.ysave) {
-            const f32x4 ys = *(const f32x4*)(a.ysave + (size_t)idx * 4);
+            const f32x4 ys = *(const f32x4*)(a.ysave + o);
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[e] *= act_grad_from_output(ys[e], a.mask_act, a.slope);
         }
-        *(f32x4*)(a.out + (size_t)idx * 4) = s;
+        *(f32x4*)(a.out + o) = s;
     }
 }
 
@@ -186,32 +213,42 @@ __global__ __launch_bounds__(256) void conv_smallcin_dgrad_kernel(SmallDgradArgs
 // stem wgrad (KS == 1): partial[wg][co*Cin + k] = sum dout[.,co]*in[.,k];  partial[wg][Cout*Cin + co] = sum dout
 
 __global__ __launch_bounds__(256) void conv_smallcin_wgrad_kernel(SmallWgradArgs a) {
-    extern __shared__ float red[];   // [PL][Cout*(Cin+1)]
-    const int co = threadIdx.x % a.Cout, pl = threadIdx.x / a.Cout, PL = 256 / a.Cout;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb = 0.f;
-    const size_t npix = (size_t)a.N * a.Ho * a.Wo;
-    for (size_t pix = (size_t)blockIdx.x * PL + pl; pix < npix; pix += (size_t)gridDim.x * PL) {
-        const int x = pix % a.Wo;
-        const int y = (pix / a.Wo) % a.Ho;
-        const int n = pix / ((size_t)a.Wo * a.Ho);
-        const float d = a.dout[pix * a.Cout + co];
-        accb += d;
-        const int gy = y - a.pad, gx = x - a.pad;
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-            const float* ip = a.in + (((size_t)n * a.H + gy) * a.W + gx) * a.Cin;
+    // thread = (cout quad, pixel lane); workgroups stride over output rows; no per-pixel integer division
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [XL][Cout*(Cin+1)]
+    const int C4 = a.Cout >> 2, c4 = threadIdx.x % C4, xl = threadIdx.x / C4, XL = 256 / C4;
+    f32x4 acc[4], accb = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < a.Cin) acc[k] = fmaf(d, ip[k], acc[k]);
+    for (int k = 0; k < 4; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nrows = a.N * a.Ho;
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int n = row / a.Ho, y = row - n * a.Ho;
+        const int gy = y - a.pad;
+        const bool yin = gy >= 0 && gy < a.H;
+        const float* drow = a.dout + (size_t)row * a.Wo * a.Cout + c4 * 4;
+        const float* irow = a.in + (size_t)(n * a.H + (yin ? gy : 0)) * a.W * a.Cin;
+        for (int x = xl; x < a.Wo; x += XL) {
+            const f32x4 d = *(const f32x4*)(drow + (size_t)x * a.Cout);
+            accb += d;
+            const int gx = x - a.pad;
+            if (yin && gx >= 0 && gx < a.W) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < a.Cin) acc[k] += d * irow[gx * a.Cin + k];
+            }
         }
     }
     const int nout = a.Cout * (a.Cin + 1);
-    for (int k = 0; k < a.Cin; ++k) red[pl * nout + co * a.Cin + k] = acc[k];
-    red[pl * nout + a.Cout * a.Cin + co] = accb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int co = c4 * 4 + e;
+        for (int k = 0; k < a.Cin; ++k) red[xl * nout + co * a.Cin + k] = acc[k][e];
+        red[xl * nout + a.Cout * a.Cin + co] = accb[e];
+    }
     __syncthreads();
     for (int o = threadIdx.x; o < nout; o += 256) {
-        float s = 0.f;
-        for (int p = 0; p < PL; ++p) s += red[p * nout + o];
-        a.partial[(size_t)blockIdx.x * nout + o] = s;
+        float t = 0.f;
+        for (int p = 0; p < XL; ++p) t += red[p * nout + o];
+        a.partial[(size_t)blockIdx.x * nout + o] = t;
     }
 }
 
@@ -232,12 +269,18 @@ __global__ __launch_bounds__(256) void conv_cout1_wgrad_kernel(Cout1WgradArgs a)
         const int n = tile / tpi;
         const int trem = tile - n * tpi;
         const int y0 = (trem / a.tiles_x) * a.TH, x0 = (trem % a.tiles_x) * a.TW;
-        for (int q = threadIdx.x; q < PP * a.Cin; q += 256) {
-            const int p = q / a.Cin, c = q - p * a.Cin;
+        const int C4 = a.Cin >> 2;
+        for (int q = threadIdx.x; q < PP * C4; q += 256) {
+            const int p = q / C4, part = q - p * C4;
             const int gy = y0 + p / PW - 1, gx = x0 + p % PW - 1;
-            float v = 0.f;
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = a.x[(((size_t)n * a.H + gy) * a.W + gx) * a.Cin + c];
-            ldsP[p * CS + c] = v;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = *(const f32x4*)(a.x + (((size_t)n * a.H + gy) * a.W + gx) * a.Cin + part * 4);
+            float* d = ldsP + p * CS + part * 4;
+            d[0] = v[0];
+            d[1] = v[1];
+            d[2] = v[2];
+            d[3] = v[3];
         }
         for (int p = threadIdx.x; p < TP; p += 256) {
             const int gy = y0 + p / a.TW, gx = x0 + p % a.TW;
@@ -295,10 +338,8 @@ int aesr_launch_cout1_fwd(const Cout1FwdArgs& a, hipStream_t st) {
 
 int aesr_launch_smallcin_fwd(const SmallArgs& a, hipStream_t st) {
     const size_t total = (size_t)a.N * a.Ho * a.Wo * a.Cout;
-    if (a.Cout % 4 == 0 && total < (size_t)1 << 31) {
-        int grid4 = (int)((total / 4 + 255) / 256);
-        if (grid4 > 16384) grid4 = 16384;
-        hipLaunchKernelGGL(conv_smallcin_fwd4_kernel, dim3(grid4), dim3(256), 0, st, a);
+    if (a.Cout % 4 == 0 && 256 % (a.Cout / 4) == 0 && total < (size_t)1 << 31) {
+        hipLaunchKernelGGL(conv_smallcin_fwd4_kernel, dim3(a.N * a.Ho), dim3(256), 0, st, a);
         AESR_LAUNCH_CHECK("conv_smallcin_fwd4");
         return AESR_OK;
     }
@@ -325,8 +366,8 @@ int aesr_launch_sum_partials(const float* partial, int np, int n, float* out0, i
 }
 
 int aesr_launch_smallcin_wgrad(const SmallWgradArgs& a, int nwg, hipStream_t st) {
-    const int PL = 256 / a.Cout;
-    const size_t shmem = (size_t)PL * a.Cout * (a.Cin + 1) * sizeof(float);
+    const int XL = 256 / (a.Cout / 4);
+    const size_t shmem = (size_t)XL * a.Cout * (a.Cin + 1) * sizeof(float);
     hipLaunchKernelGGL(conv_smallcin_wgrad_kernel, dim3(nwg), dim3(256), shmem, st, a);
     AESR_LAUNCH_CHECK("conv_smallcin_wgrad");
     return AESR_OK;
