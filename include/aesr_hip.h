@@ -79,6 +79,12 @@ int aesr_conv2d_cout1_fwd(const float* x, const float* w, const float* bias, flo
 int aesr_conv2d_cout1_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W,
                             int Cin, void* stream);
 
+/* Stride-2 2x2 convolution (networks/acai_vanilla_strided.py:19) = space-to-depth + 1x1 MFMA conv:
+ * out[n,y,x,(ky*2+kx)*C+c] = x[n,2y+ky,2x+kx,c], out is [N,H/2,W/2,4C]; the inverse scatters a [N,H/2,W/2,4C] gradient
+ * back to [N,H,W,C] (zero in a dropped odd last row / column).  H, W are the FULL-resolution sizes in both calls. */
+int aesr_space_to_depth2(const float* x, float* out, int N, int H, int W, int C, void* stream);
+int aesr_depth_to_space2(const float* g, float* dx, int N, int H, int W, int C, void* stream);
+
 /* ---- BatchNorm2d (+AvgPool2d(2) / nearest Upsample x2) (networks/acai_vanilla.py:58-59,90-92) ------------ */
 #define AESR_BN_NONE 0
 #define AESR_BN_POOL 1

@@ -34,6 +34,8 @@ SIGNATURES = {
     "aesr_conv2d_smallcin_wgrad": (c_int, [P, P, P, P, P] + [c_int] * 6 + [P]),
     "aesr_conv2d_cout1_fwd": (c_int, [P, P, P, P] + [c_int] * 5 + [c_float, P]),
     "aesr_conv2d_cout1_wgrad": (c_int, [P, P, P, P, P] + [c_int] * 4 + [P]),
+    "aesr_space_to_depth2": (c_int, [P, P] + [c_int] * 4 + [P]),
+    "aesr_depth_to_space2": (c_int, [P, P] + [c_int] * 4 + [P]),
     "aesr_bn_stats": (c_int, [P, P, P, c_int, c_int, c_int, IP, P]),
     "aesr_bn_finalize": (c_int, [P, DP] + [P] * 9 + [c_int, c_int, c_float, c_float, c_int, c_int, P]),
     "aesr_bn_apply": (c_int, [P, P, P, P] + [c_int] * 6 + [IP, P]),

@@ -374,6 +374,16 @@ int aesr_lpips_finalize(const float* const* partials_host, const int* hw_host, i
     return aesr_launch_lpips_finalize(partials_host, hw_host, ntaps, d, B, (hipStream_t)stream);
 }
 
+int aesr_space_to_depth2(const float* x, float* out, int N, int H, int W, int C, void* stream) {
+    AESR_CHECK_ARG(x && out && N > 0 && H >= 2 && W >= 2 && C % 4 == 0, "aesr_space_to_depth2: bad arguments (C %% 4 == 0, H,W >= 2)");
+    return aesr_launch_s2d(x, out, N, H, W, C, 0, (hipStream_t)stream);
+}
+
+int aesr_depth_to_space2(const float* g, float* dx, int N, int H, int W, int C, void* stream) {
+    AESR_CHECK_ARG(g && dx && N > 0 && H >= 2 && W >= 2 && C % 4 == 0, "aesr_depth_to_space2: bad arguments (C %% 4 == 0, H,W >= 2)");
+    return aesr_launch_s2d(g, dx, N, H, W, C, 1, (hipStream_t)stream);
+}
+
 int aesr_lerp_fwd(const float* z, const float* a_from, const float* a_to, float* zmix, int B, size_t per, void* stream) {
     AESR_CHECK_ARG(z && a_from && a_to && zmix && B > 0 && per % 4 == 0, "aesr_lerp_fwd: bad arguments (per %% 4 == 0)");
     return aesr_launch_lerp_fwd(z, a_from, a_to, zmix, B, per, (hipStream_t)stream);

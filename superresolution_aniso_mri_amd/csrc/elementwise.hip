@@ -99,6 +99,44 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
     }
 }
 
+// ---- space-to-depth (2x2): the stride-2 2x2 convolution of networks/acai_vanilla_strided.py:19 as a 1x1 conv -------------
+// out[n,yo,xo,(ky*2+kx)*C + c] = x[n,2yo+ky,2xo+kx,c]   (Ho = H/2, Wo = W/2; an odd last row / column is dropped)
+__global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int H, int W, int C,
+                                                  int inverse) {
+    const int Ho = H >> 1, Wo = W >> 1, C4 = C >> 2;
+    if (!inverse) {
+        const int total = N * Ho * Wo * 4 * C4;
+        for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+            const int c4 = idx % C4;
+            int r = idx / C4;
+            const int q = r & 3;
+            r >>= 2;
+            const int xo = r % Wo;
+            r /= Wo;
+            const int yo = r % Ho;
+            const int n = r / Ho;
+            *(f32x4*)(out + (size_t)idx * 4) =
+                *(const f32x4*)(x + ((size_t)(n * H + 2 * yo + (q >> 1)) * W + 2 * xo + (q & 1)) * C + c4 * 4);
+        }
+    } else {
+        // x is the [N,Ho,Wo,4C] gradient, out the [N,H,W,C] gradient (zero in a dropped odd row / column)
+        const int total = N * H * W * C4;
+        for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+            const int c4 = idx % C4;
+            int r = idx / C4;
+            const int xx = r % W;
+            r /= W;
+            const int yy = r % H;
+            const int n = r / H;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int yo = yy >> 1, xo = xx >> 1;
+            if (yo < Ho && xo < Wo)
+                v = *(const f32x4*)(x + (((size_t)(n * Ho + yo) * Wo + xo) * 4 + (yy & 1) * 2 + (xx & 1)) * C + c4 * 4);
+            *(f32x4*)(out + (size_t)idx * 4) = v;
+        }
+    }
+}
+
 static inline int grid_for(size_t n, int cap) {
     size_t g = (n + 255) / 256;
     if (g < 1) g = 1;
@@ -143,5 +181,12 @@ int aesr_launch_adam(float* p, const float* g, float* m, float* v, float* state,
     AESR_LAUNCH_CHECK("adam_prep");
     hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, st, p, g, m, v, state, n, lr, beta1, beta2, eps, wd);
     AESR_LAUNCH_CHECK("adam_step");
+    return AESR_OK;
+}
+
+int aesr_launch_s2d(const float* x, float* out, int N, int H, int W, int C, int inverse, hipStream_t st) {
+    const size_t total = inverse ? (size_t)N * H * W * (C / 4) : (size_t)N * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(s2d_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, st, x, out, N, H, W, C, inverse);
+    AESR_LAUNCH_CHECK("s2d");
     return AESR_OK;
 }

@@ -79,10 +79,19 @@ class ConvStep:
 
     def __init__(self, mod, act, slope):
         ks, st, pd = mod.kernel_size, mod.stride, mod.padding
-        if ks[0] != ks[1] or st != (1, 1) or pd[0] != pd[1] or ks[0] not in (1, 3) or mod.dilation != (1, 1) or mod.groups != 1:
-            raise NotImplementedError("HIP conv path supports square 1x1/3x3 stride-1 convolutions, got %r" % (mod,))
+        self.s2d = (ks == (2, 2) and st == (2, 2) and pd == (0, 0) and mod.dilation == (1, 1) and mod.groups == 1
+                    and mod.in_channels % 4 == 0)
+        if not self.s2d and (ks[0] != ks[1] or st != (1, 1) or pd[0] != pd[1] or ks[0] not in (1, 3) or mod.dilation != (1, 1)
+                             or mod.groups != 1):
+            raise NotImplementedError("HIP conv path supports square 1x1/3x3 stride-1 and 2x2 stride-2 convolutions, got %r" % (mod,))
         self.mod, self.act, self.slope = mod, act, slope
         self.cin, self.cout, self.ks, self.pad = mod.in_channels, mod.out_channels, ks[0], pd[0]
+        if self.s2d:
+            # stride-2 2x2 conv == space-to-depth followed by a 1x1 conv over 4*Cin channels (networks/acai_vanilla_strided.py:19)
+            if act != _hip.ACT_NONE:
+                raise NotImplementedError("activation fused behind a stride-2 convolution")
+            self.cin_full, self.cin, self.ks, self.pad = mod.in_channels, 4 * mod.in_channels, 1, 0
+        self.w1 = None          # s2d: the equivalent [Cout, 4Cin, 1, 1] filter
         self.packed = None      # forward operand
         self.packed_t = None    # data-gradient operand
         self.packed_epoch = -1
@@ -92,7 +101,16 @@ class ConvStep:
         return self.cin % 4 == 0
 
     def out_hw(self, h, w):
+        if self.s2d:
+            return h // 2, w // 2
         return h + 2 * self.pad - self.ks + 1, w + 2 * self.pad - self.ks + 1
+
+    def weight_for_kernels(self):
+        """[Cout,Cin,K,K] filter the kernels see (s2d: channels ordered (ky, kx, c) like aesr_space_to_depth2)."""
+        if not self.s2d:
+            return self.mod.weight
+        self.w1 = self.mod.weight.detach().permute(0, 2, 3, 1).reshape(self.cout, self.cin, 1, 1).contiguous()
+        return self.w1
 
 
 class BnStep:
@@ -164,16 +182,17 @@ class SequentialRunner:
         if s.packed_epoch == epoch:
             return
         _hip.require_gpu_tensor(w, "conv weight")
+        wk = s.weight_for_kernels()
         if s.cin % 4 == 0:
             n = lib.aesr_conv2d_packed_floats(s.cout, s.cin, s.ks, 0)
             if s.packed is None or s.packed.numel() != n:
                 s.packed = _empty((n,), w)
-            check(lib.aesr_conv2d_pack(ptr(w), ptr(s.packed), s.cout, s.cin, s.ks, 0, stream()), "aesr_conv2d_pack")
+            check(lib.aesr_conv2d_pack(ptr(wk), ptr(s.packed), s.cout, s.cin, s.ks, 0, stream()), "aesr_conv2d_pack")
         if s.cout % 4 == 0:
             n = lib.aesr_conv2d_packed_floats(s.cout, s.cin, s.ks, 1)
             if s.packed_t is None or s.packed_t.numel() != n:
                 s.packed_t = _empty((n,), w)
-            check(lib.aesr_conv2d_pack(ptr(w), ptr(s.packed_t), s.cout, s.cin, s.ks, 1, stream()), "aesr_conv2d_pack")
+            check(lib.aesr_conv2d_pack(ptr(wk), ptr(s.packed_t), s.cout, s.cin, s.ks, 1, stream()), "aesr_conv2d_pack")
         s.packed_epoch = epoch
 
     # ---- forward ---------------------------------------------------------------------------------------------
@@ -186,10 +205,17 @@ class SequentialRunner:
         cur = x
         for s in self.steps:
             if s.kind == "conv":
+                if s.s2d:
+                    if C != s.cin_full:
+                        raise RuntimeError("channel mismatch: tensor has %d channels, conv expects %d" % (C, s.cin_full))
+                    xs = _empty((N, H // 2, W // 2, 4 * C), x)
+                    check(lib.aesr_space_to_depth2(ptr(cur), ptr(xs), N, H, W, C, stream()), "aesr_space_to_depth2")
+                    full_hw = (H, W)
+                    cur, H, W, C = xs, H // 2, W // 2, 4 * C
                 if C != s.cin:
                     raise RuntimeError("channel mismatch: tensor has %d channels, conv expects %d" % (C, s.cin))
                 self._ensure_packed(s)
-                Ho, Wo = s.out_hw(H, W)
+                Ho, Wo = (H, W) if s.s2d else s.out_hw(H, W)
                 out = _empty((N, Ho, Wo, s.cout), x)
                 bias = s.mod.bias
                 if s.cout == 1 and s.ks == 3 and s.pad == 1 and s.cin % 4 == 0:
@@ -207,7 +233,7 @@ class SequentialRunner:
                 else:
                     raise NotImplementedError("conv with Cin=%d (neither <=4 nor a multiple of 4)" % s.cin)
                 if save:
-                    saved.append((cur, out))
+                    saved.append((cur, out, full_hw) if s.s2d else (cur, out))
                 cur, H, W, C = out, Ho, Wo, s.cout
             else:
                 bn = s.mod
@@ -277,16 +303,17 @@ class SequentialRunner:
         for k in range(len(steps) - 1, -1, -1):
             s = steps[k]
             if s.kind == "conv":
-                xin, yout = saved[k]
+                xin, yout = saved[k][0], saved[k][1]
                 N, H, W, _ = xin.shape
                 N = ngrad
-                Ho, Wo = s.out_hw(H, W)
+                Ho, Wo = (H, W) if s.s2d else s.out_hw(H, W)
                 if k == len(steps) - 1 and s.act != _hip.ACT_NONE:
                     dpre = torch.empty_like(g)
                     check(lib.aesr_act_bwd(ptr(g), ptr(yout), ptr(dpre), g.numel(), s.act, s.slope, stream()), "aesr_act_bwd")
                     g = dpre
                 # -- weight / bias gradient
-                dw = self._grad_dst(s.mod.weight, grads)
+                dw_final = self._grad_dst(s.mod.weight, grads)
+                dw = torch.empty((s.cout, s.cin, 1, 1), device=g.device) if s.s2d else dw_final
                 db = self._grad_dst(s.mod.bias, grads) if s.mod.bias is not None else None
                 if s.cin % 4 == 0 and s.cout % 4 == 0:
                     nws = lib.aesr_conv2d_wgrad_workspace_floats(N, H, W, s.cin, s.cout, s.ks, s.pad)
@@ -305,6 +332,8 @@ class SequentialRunner:
                           "aesr_conv2d_cout1_wgrad")
                 else:
                     raise NotImplementedError("no wgrad kernel for conv %d->%d k%d" % (s.cin, s.cout, s.ks))
+                if s.s2d:       # [Cout, (ky,kx,c)] -> [Cout, c, ky, kx]
+                    dw_final.copy_(dw.reshape(s.cout, 2, 2, s.cin_full).permute(0, 3, 1, 2))
                 # -- data gradient (fused with the derivative of the activation that produced our input)
                 if k == 0 and not need_input_grad:
                     g = None
@@ -330,6 +359,13 @@ class SequentialRunner:
                                                        None, None, stream()), "aesr_conv2d_smallcin_fwd(dgrad)")
                 else:
                     raise NotImplementedError("no dgrad kernel for conv %d->%d" % (s.cin, s.cout))
+                if s.s2d:
+                    if mask is not None:
+                        raise NotImplementedError("activation mask in front of a stride-2 convolution")
+                    fh, fw = saved[k][2]
+                    dfull = _empty((N, fh, fw, s.cin_full), g)
+                    check(lib.aesr_depth_to_space2(ptr(dx), ptr(dfull), N, fh, fw, s.cin_full, stream()), "aesr_depth_to_space2")
+                    dx = dfull
                 g = dx
             else:
                 y, st = saved[k]

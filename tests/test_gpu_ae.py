@@ -20,13 +20,15 @@ def rel_l2(a, b):
 
 
 def _model(cname, args):
-    from superresolution_aniso_mri_amd.networks import acai_vanilla, acai_vanilla_modified
-    cls = {"VanillaACAI": acai_vanilla.VanillaACAI, "LargerAE": acai_vanilla_modified.LargerAE}[cname]
+    from superresolution_aniso_mri_amd.networks import acai_vanilla, acai_vanilla_modified, acai_vanilla_strided
+    cls = {"VanillaACAI": acai_vanilla.VanillaACAI, "LargerAE": acai_vanilla_modified.LargerAE,
+           "VanillaACAIStrided": acai_vanilla_strided.VanillaACAIStrided}[cname]
     return cls(dict(args))
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "ae_small_VanillaACAI_*.npz")) +
-                                        glob.glob(os.path.join(GOLDEN, "ae_small_LargerAE_*.npz"))))
+                                        glob.glob(os.path.join(GOLDEN, "ae_small_LargerAE_*.npz")) +
+                                        glob.glob(os.path.join(GOLDEN, "ae_small_VanillaACAIStrided_*.npz"))))
 def test_ae_small_vs_reference_vectors(path):
     rec = dict(np.load(path))
     cname = os.path.basename(path).split("_")[2]
