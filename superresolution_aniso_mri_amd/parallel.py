@@ -34,6 +34,17 @@ class DataParallelContext(object):
     def active(self):
         return self.world > 1
 
+    def _all_reduce(self, t, op=None):
+        """In-place all-reduce; with the gloo backend (CPU tests, single-GPU rehearsals) device tensors are staged through
+        the host, with nccl (= RCCL over xGMI) they are reduced in place on the device."""
+        op = op or dist.ReduceOp.SUM
+        if t.is_cuda and dist.get_backend() == "gloo":
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+
     def shard_range(self, B):
         return (B * self.rank) // self.world, (B * (self.rank + 1)) // self.world
 
@@ -55,18 +66,18 @@ class DataParallelContext(object):
         sub-batch of a step scales by the same B_global / B_local, see ``count_scale``)."""
         if not self.active:
             return
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        self._all_reduce(sums)
 
     def allreduce_gradients(self, opt):
         if not self.active:
             return
         flat = getattr(opt, "flat_g", None)
         if flat is not None:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            self._all_reduce(flat)
             return
         grads = [p.grad for g in opt.param_groups for p in g["params"] if p.grad is not None]
         buf = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        self._all_reduce(buf)
         off = 0
         for g in grads:
             g.copy_(buf[off:off + g.numel()].view_as(g))
@@ -76,7 +87,12 @@ class DataParallelContext(object):
         if not self.active:
             return
         for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, src=0)
+            if t.is_cuda and dist.get_backend() == "gloo":
+                h = t.data.cpu()
+                dist.broadcast(h, src=0)
+                t.data.copy_(h)
+            else:
+                dist.broadcast(t.data, src=0)
         if hasattr(model, "mark_weights_dirty"):
             model.mark_weights_dirty()
 
@@ -94,7 +110,7 @@ class DataParallelContext(object):
         t = torch.as_tensor(v, dtype=torch.float64, device=self.device).clone().reshape(1)
         if weighted:
             t *= self.weight
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        self._all_reduce(t)
         return float(t)
 
     def barrier(self):
@@ -105,5 +121,5 @@ class DataParallelContext(object):
         if not self.active:
             return v
         t = torch.tensor([float(v)], dtype=torch.float64, device=self.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self._all_reduce(t, dist.ReduceOp.MAX)
         return float(t)
