@@ -74,10 +74,34 @@ int aesr_conv2d_smallcin_wgrad(const float* in, const float* dout, float* dw, fl
 /* 3x3 pad-1 Cout==1 forward (output conv networks/acai_vanilla.py:98 + Sigmoid): out[N,H,W,1] = act(conv(x, w[1][Cin][3][3]) + bias). */
 int aesr_conv2d_cout1_fwd(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int Cin, int act,
                           float slope, void* stream);
-/* 3x3 pad-1 Cout==1 weight/bias gradient (output conv networks/acai_vanilla.py:98).  Same workspace helper
- * with nout = Cin*9+1. */
+/* 3x3 pad-1 Cout==1 weight/bias gradient (output conv networks/acai_vanilla.py:98).  Cin = 4 * 2^k <= 256 (else a slower generic kernel when Cin divides 256);
+ * workspace: aesr_conv2d_cout1_workspace_floats(Cin) floats. */
+size_t aesr_conv2d_cout1_workspace_floats(int Cin);
 int aesr_conv2d_cout1_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W,
                             int Cin, void* stream);
+/* 3x3 pad-1 Cout==1 data gradient: dx[N,H,W,Cin] = conv^T(dy[N,H,W,1], w) * act'(y_saved) (y_saved = output of the
+ * activation that produced the conv's input, or NULL).  Cin = 4 * 2^k <= 256.  workspace: >= 9*Cin floats (the flipped filter). */
+int aesr_conv2d_cout1_dgrad(const float* dy, const float* w, const float* y_saved, float* dx, float* workspace, int N, int H,
+                            int W, int Cin, int mask_act, float slope, void* stream);
+
+/* ---- encoder stem folded into the first 3x3 convolution (networks/acai_vanilla.py:51,55) ------------------------
+ * Conv2d(1, Cs, 1, padding=stem_pad) followed directly (no non-linearity) by Conv2d(Cs, C1, 3, padding=1) + activation,
+ * computed as ONE 1 -> C1 3x3 convolution of the single-channel image with the folded filter
+ * weff[t][co] = sum_c w1[co,c,t]*w_stem[c] and the per-tap bias beff[t][co] = sum_c w1[co,c,t]*b_stem[c] (counted only for
+ * taps inside the stem's (H+2*stem_pad)^2 output grid).  The Cs-channel stem tensor is never materialised.
+ * C1 = 4 * 2^k <= 256.  folded: aesr_stemconv_folded_floats(C1) floats, refreshed by aesr_stemconv_fold whenever
+ * the parameters change.  out: [N, H+2*stem_pad, W+2*stem_pad, C1]. */
+size_t aesr_stemconv_folded_floats(int C1);
+int aesr_stemconv_fold(const float* w_stem, const float* b_stem, const float* w1, float* folded, int Cs, int C1, void* stream);
+int aesr_stemconv_fwd(const float* x, const float* folded, const float* b1, float* out, int N, int H, int W, int C1,
+                      int stem_pad, int act, float slope, void* stream);
+/* Gradients of all four parameter tensors from g = dL/d(pre-activation output) [N,H+2p,W+2p,C1]:
+ * dw_stem[Cs], db_stem[Cs] (may be NULL with b_stem), dw1[C1][Cs][3][3], db1[C1] (may be NULL).
+ * workspace: aesr_stemconv_workspace_floats(C1) floats. */
+size_t aesr_stemconv_workspace_floats(int C1);
+int aesr_stemconv_wgrad(const float* x, const float* g, const float* w_stem, const float* b_stem, const float* w1,
+                        float* dw_stem, float* db_stem, float* dw1, float* db1, float* workspace, int N, int H, int W, int Cs,
+                        int C1, int stem_pad, void* stream);
 
 /* Stride-2 2x2 convolution (networks/acai_vanilla_strided.py:19) = space-to-depth + 1x1 MFMA conv:
  * out[n,y,x,(ky*2+kx)*C+c] = x[n,2y+ky,2x+kx,c], out is [N,H/2,W/2,4C]; the inverse scatters a [N,H/2,W/2,4C] gradient
@@ -89,7 +113,7 @@ int aesr_depth_to_space2(const float* g, float* dx, int N, int H, int W, int C, 
 #define AESR_BN_NONE 0
 #define AESR_BN_POOL 1
 #define AESR_BN_UP 2
-#define AESR_BN_NWG 256   /* partial rows per group of the stats / backward-reduce passes */
+#define AESR_BN_NWG 512   /* partial rows per group of the stats / backward-reduce passes */
 
 /* sums[G][2][C] (double): per group and channel sum(y), sum(y^2).  partial: G*AESR_BN_NWG*2*C floats. */
 int aesr_bn_stats(const float* y, float* partial, double* sums, int HW, int C, int G, const int* nstart_host,
@@ -101,6 +125,12 @@ int aesr_bn_finalize(const double* sums, const double* counts_host, const float*
                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
                      float* scale, float* shift, int C, int G, float momentum, float eps, int train, int update_running,
                      void* stream);
+/* aesr_bn_stats + aesr_bn_finalize(train) without the sums round trip (two launches): the single-process path, where no
+ * SyncBN exchange sits between the two.  Same arithmetic, same outputs. */
+int aesr_bn_stats_finalize(const float* y, float* partial, const double* counts_host, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
+                           float* scale, float* shift, int HW, int C, int G, const int* nstart_host, float momentum, float eps,
+                           int update_running, void* stream);
 /* out = scale[g]*f(y) + shift[g], f = identity / 2x2 mean (floor) / nearest x2. */
 int aesr_bn_apply(const float* y, const float* scale, const float* shift, float* out, int N, int H, int W, int C, int mode,
                   int G, const int* nstart_host, void* stream);
@@ -114,6 +144,10 @@ int aesr_bn_bwd_apply(const float* gout, const float* y, const float* mean, cons
                       const double* sums, const double* counts_host, float* coef, float* dgamma, float* dbeta,
                       float* dpre, int N, int H, int W, int C, int mode, int act, float slope, int G,
                       const int* nstart_host, void* stream);
+/* aesr_bn_bwd_reduce + aesr_bn_bwd_apply without the sums round trip (three launches), for the single-process path. */
+int aesr_bn_bwd(const float* gout, const float* y, const float* mean, const float* invstd, const float* scale, float* partial,
+                const double* counts_host, float* coef, float* dgamma, float* dbeta, float* dpre, int N, int H, int W, int C,
+                int mode, int act, float slope, int G, const int* nstart_host, void* stream);
 
 /* ---- LPIPS-VGG (lpips/networks_basic.py:63-91, lpips/common.py:12-14, lpips/pretrained_networks.py:107-116) ---- */
 /* ScalingLayer (lpips/networks_basic.py:93-100, with the 2x-1 of lpips/perceptual.py:29-31 folded in) of a 1-channel image,

@@ -33,11 +33,20 @@ SIGNATURES = {
     "aesr_small_wgrad_workspace_floats": (c_size_t, [c_int]),
     "aesr_conv2d_smallcin_wgrad": (c_int, [P, P, P, P, P] + [c_int] * 6 + [P]),
     "aesr_conv2d_cout1_fwd": (c_int, [P, P, P, P] + [c_int] * 5 + [c_float, P]),
+    "aesr_conv2d_cout1_workspace_floats": (c_size_t, [c_int]),
     "aesr_conv2d_cout1_wgrad": (c_int, [P, P, P, P, P] + [c_int] * 4 + [P]),
+    "aesr_conv2d_cout1_dgrad": (c_int, [P, P, P, P, P] + [c_int] * 5 + [c_float, P]),
+    "aesr_stemconv_folded_floats": (c_size_t, [c_int]),
+    "aesr_stemconv_fold": (c_int, [P, P, P, P, c_int, c_int, P]),
+    "aesr_stemconv_fwd": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),
+    "aesr_stemconv_workspace_floats": (c_size_t, [c_int]),
+    "aesr_stemconv_wgrad": (c_int, [P] * 10 + [c_int] * 6 + [P]),
     "aesr_space_to_depth2": (c_int, [P, P] + [c_int] * 4 + [P]),
     "aesr_depth_to_space2": (c_int, [P, P] + [c_int] * 4 + [P]),
     "aesr_bn_stats": (c_int, [P, P, P, c_int, c_int, c_int, IP, P]),
     "aesr_bn_finalize": (c_int, [P, DP] + [P] * 9 + [c_int, c_int, c_float, c_float, c_int, c_int, P]),
+    "aesr_bn_stats_finalize": (c_int, [P, P, DP] + [P] * 9 + [c_int, c_int, c_int, IP, c_float, c_float, c_int, P]),
+    "aesr_bn_bwd": (c_int, [P] * 6 + [DP] + [P] * 4 + [c_int] * 6 + [c_float, c_int, IP, P]),
     "aesr_bn_apply": (c_int, [P, P, P, P] + [c_int] * 6 + [IP, P]),
     "aesr_bn_bwd_reduce": (c_int, [P] * 6 + [c_int] * 6 + [IP, P]),
     "aesr_bn_bwd_apply": (c_int, [P] * 6 + [DP] + [P] * 4 + [c_int] * 6 + [c_float, c_int, IP, P]),
@@ -58,7 +67,7 @@ SIGNATURES = {
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 BN_NONE, BN_POOL, BN_UP = 0, 1, 2
-BN_NWG = 256
+BN_NWG = 512
 MSE_NPART = 512
 LPIPS_NCH = 64
 

@@ -264,9 +264,30 @@ int aesr_conv2d_cout1_fwd(const float* x, const float* w, const float* bias, flo
     return aesr_launch_cout1_fwd(a, (hipStream_t)stream);
 }
 
+#define THIN_NWG 512
+static bool thin_channels_ok(int C) { return C >= 4 && C <= 256 && C % 4 == 0 && ((C / 4) & (C / 4 - 1)) == 0; }
+
+size_t aesr_conv2d_cout1_workspace_floats(int Cin) {
+    const size_t legacy = (size_t)SMALL_WGRAD_NWG * (Cin * 9 + 1);
+    const size_t thin = (size_t)(THIN_NWG + 1) * 10 * Cin;
+    return legacy > thin ? legacy : thin;
+}
+
 int aesr_conv2d_cout1_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W,
                             int Cin, void* stream) {
     AESR_CHECK_ARG(x && dy && dw && db && workspace, "aesr_conv2d_cout1_wgrad: null pointer");
+    AESR_CHECK_ARG(N > 0 && H > 0 && W > 0, "aesr_conv2d_cout1_wgrad: empty shape");
+    if (thin_channels_ok(Cin)) {
+        // dW[0,ci,ky,kx] = sum_u X[u,ci] * dy[u - (ky-1, kx-1)]  ->  thin reduce of X against dy, taps flipped
+        ThinArgs a;
+        memset(&a, 0, sizeof(a));
+        a.s = dy; a.t = x; a.partial = workspace;
+        a.N = N; a.Hs = H; a.Ws = W; a.Ho = H; a.Wo = W; a.C = Cin; a.ps = 0; a.with_be = 0;
+        float* R = workspace + (size_t)THIN_NWG * 10 * Cin;
+        if (int e = aesr_launch_thin_reduce(a, THIN_NWG, (hipStream_t)stream)) return e;
+        if (int e = aesr_launch_sum_partials(workspace, THIN_NWG, 10 * Cin, R, 10 * Cin, nullptr, (hipStream_t)stream)) return e;
+        return aesr_launch_thin_cout1_finish(R, dw, db, Cin, (hipStream_t)stream);
+    }
     AESR_CHECK_ARG(Cin >= 4 && Cin <= 128 && 256 % Cin == 0, "aesr_conv2d_cout1_wgrad: Cin=%d must divide 256 (and be >= 4)", Cin);
     Cout1WgradArgs a;
     a.x = x; a.dy = dy; a.partial = workspace; a.N = N; a.H = H; a.W = W; a.Cin = Cin;
@@ -276,6 +297,57 @@ int aesr_conv2d_cout1_wgrad(const float* x, const float* dy, float* dw, float* d
     int nwg = a.ntiles < SMALL_WGRAD_NWG ? a.ntiles : SMALL_WGRAD_NWG;
     if (int e = aesr_launch_cout1_wgrad(a, nwg, (hipStream_t)stream)) return e;
     return aesr_launch_sum_partials(workspace, nwg, Cin * 9 + 1, dw, Cin * 9, db, (hipStream_t)stream);
+}
+
+int aesr_conv2d_cout1_dgrad(const float* dy, const float* w, const float* y_saved, float* dx, float* workspace, int N, int H,
+                            int W, int Cin, int mask_act, float slope, void* stream) {
+    AESR_CHECK_ARG(dy && w && dx && workspace && N > 0 && H > 0 && W > 0, "aesr_conv2d_cout1_dgrad: null pointer or empty shape");
+    AESR_CHECK_ARG(thin_channels_ok(Cin), "aesr_conv2d_cout1_dgrad: Cin=%d must be 4 times a power of two (4..256)", Cin);
+    if (int e = aesr_launch_thin_cout1_flip(w, workspace, Cin, (hipStream_t)stream)) return e;
+    ThinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.s = dy; a.w = workspace; a.ysave = y_saved; a.out = dx;
+    a.N = N; a.Hs = H; a.Ws = W; a.Ho = H; a.Wo = W; a.C = Cin; a.ps = 0;
+    a.act = ACT_NONE; a.mask_act = y_saved ? mask_act : ACT_NONE; a.slope = slope;
+    return aesr_launch_thin_expand(a, (hipStream_t)stream);
+}
+
+size_t aesr_stemconv_folded_floats(int C1) { return (size_t)2 * 9 * C1; }
+
+int aesr_stemconv_fold(const float* w_stem, const float* b_stem, const float* w1, float* folded, int Cs, int C1, void* stream) {
+    AESR_CHECK_ARG(w_stem && w1 && folded && Cs > 0 && C1 > 0, "aesr_stemconv_fold: bad arguments");
+    return aesr_launch_thin_stem_fold(w_stem, b_stem, w1, folded, Cs, C1, (hipStream_t)stream);
+}
+
+int aesr_stemconv_fwd(const float* x, const float* folded, const float* b1, float* out, int N, int H, int W, int C1,
+                      int stem_pad, int act, float slope, void* stream) {
+    AESR_CHECK_ARG(x && folded && out && N > 0 && H > 0 && W > 0 && stem_pad >= 0, "aesr_stemconv_fwd: bad arguments");
+    AESR_CHECK_ARG(thin_channels_ok(C1), "aesr_stemconv_fwd: C1=%d must be 4 times a power of two (4..256)", C1);
+    ThinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.s = x; a.w = folded; a.be = folded + (size_t)9 * C1; a.b = b1; a.out = out;
+    a.N = N; a.Hs = H; a.Ws = W; a.Ho = H + 2 * stem_pad; a.Wo = W + 2 * stem_pad; a.C = C1; a.ps = stem_pad;
+    a.act = act; a.mask_act = ACT_NONE; a.slope = slope;
+    return aesr_launch_thin_expand(a, (hipStream_t)stream);
+}
+
+size_t aesr_stemconv_workspace_floats(int C1) { return (size_t)(THIN_NWG + 1) * 19 * C1; }
+
+int aesr_stemconv_wgrad(const float* x, const float* g, const float* w_stem, const float* b_stem, const float* w1,
+                        float* dw_stem, float* db_stem, float* dw1, float* db1, float* workspace, int N, int H, int W, int Cs,
+                        int C1, int stem_pad, void* stream) {
+    AESR_CHECK_ARG(x && g && w_stem && w1 && dw_stem && dw1 && workspace, "aesr_stemconv_wgrad: null pointer");
+    AESR_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cs > 0 && stem_pad >= 0, "aesr_stemconv_wgrad: bad shape");
+    AESR_CHECK_ARG(thin_channels_ok(C1), "aesr_stemconv_wgrad: C1=%d must be 4 times a power of two (4..256)", C1);
+    AESR_CHECK_ARG(!db_stem || b_stem, "aesr_stemconv_wgrad: db_stem needs b_stem");
+    ThinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.s = x; a.t = g; a.partial = workspace;
+    a.N = N; a.Hs = H; a.Ws = W; a.Ho = H + 2 * stem_pad; a.Wo = W + 2 * stem_pad; a.C = C1; a.ps = stem_pad; a.with_be = 1;
+    float* R = workspace + (size_t)THIN_NWG * 19 * C1;
+    if (int e = aesr_launch_thin_reduce(a, THIN_NWG, (hipStream_t)stream)) return e;
+    if (int e = aesr_launch_sum_partials(workspace, THIN_NWG, 19 * C1, R, 19 * C1, nullptr, (hipStream_t)stream)) return e;
+    return aesr_launch_thin_stem_finish(R, w_stem, b_stem, w1, dw_stem, db_stem, dw1, db1, Cs, C1, (hipStream_t)stream);
 }
 
 int aesr_bn_stats(const float* y, float* partial, double* sums, int HW, int C, int G, const int* nstart_host, void* stream) {
@@ -294,6 +366,19 @@ int aesr_bn_finalize(const double* sums, const double* counts_host, const float*
     return aesr_launch_bn_finalize(sums, counts_host, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, mean,
                                    invstd, scale, shift, C, G, momentum, eps, train, update_running && running_mean && running_var,
                                    (hipStream_t)stream);
+}
+
+int aesr_bn_stats_finalize(const float* y, float* partial, const double* counts_host, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
+                           float* scale, float* shift, int HW, int C, int G, const int* nstart_host, float momentum, float eps,
+                           int update_running, void* stream) {
+    BnGroups gr;
+    AESR_CHECK_ARG(y && partial && counts_host && fill_groups(&gr, G, nstart_host), "aesr_bn_stats_finalize: bad arguments");
+    AESR_CHECK_ARG(gamma && beta && mean && invstd && scale && shift, "aesr_bn_stats_finalize: null pointer");
+    if (int e = aesr_launch_bn_stats(y, partial, HW, C, gr, AESR_BN_NWG, (hipStream_t)stream)) return e;
+    return aesr_launch_bn_reduce_finalize(partial, AESR_BN_NWG, counts_host, gamma, beta, running_mean, running_var,
+                                          (long long*)num_batches_tracked, mean, invstd, scale, shift, C, G, momentum, eps,
+                                          update_running && running_mean && running_var, (hipStream_t)stream);
 }
 
 static void bn_out_dims(int H, int W, int mode, int* Ho, int* Wo) {
@@ -319,6 +404,7 @@ int aesr_bn_bwd_reduce(const float* gout, const float* y, const float* mean, con
     AESR_CHECK_ARG(gout && y && mean && invstd && partial && sums && fill_groups(&a.gr, G, nstart_host), "aesr_bn_bwd_reduce: bad arguments");
     a.gout = gout; a.y = y; a.mean = mean; a.invstd = invstd; a.partial = partial;
     a.N = N; a.H = H; a.W = W; a.C = C; a.mode = mode;
+    AESR_CHECK_ARG((double)N * H * W < 2147483648.0, "aesr_bn_bwd_reduce: more than 2^31 pixels");
     bn_out_dims(H, W, mode, &a.Ho, &a.Wo);
     if (int e = aesr_launch_bn_bwd_reduce(a, AESR_BN_NWG, (hipStream_t)stream)) return e;
     return aesr_launch_bn_reduce(partial, sums, AESR_BN_NWG, C, G, (hipStream_t)stream);
@@ -335,6 +421,23 @@ int aesr_bn_bwd_apply(const float* gout, const float* y, const float* mean, cons
     a.gout = gout; a.y = y; a.mean = mean; a.invstd = invstd; a.scale = scale; a.coef = coef; a.dpre = dpre;
     a.N = N; a.H = H; a.W = W; a.C = C; a.mode = mode; a.act = act; a.slope = slope;
     bn_out_dims(H, W, mode, &a.Ho, &a.Wo);
+    return aesr_launch_bn_bwd_apply(a, (hipStream_t)stream);
+}
+
+int aesr_bn_bwd(const float* gout, const float* y, const float* mean, const float* invstd, const float* scale, float* partial,
+                const double* counts_host, float* coef, float* dgamma, float* dbeta, float* dpre, int N, int H, int W, int C,
+                int mode, int act, float slope, int G, const int* nstart_host, void* stream) {
+    BnBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    AESR_CHECK_ARG(gout && y && mean && invstd && scale && partial && counts_host && coef && dgamma && dbeta && dpre &&
+                       fill_groups(&a.gr, G, nstart_host), "aesr_bn_bwd: bad arguments");
+    AESR_CHECK_ARG((double)N * H * W < 2147483648.0, "aesr_bn_bwd: more than 2^31 pixels");
+    a.gout = gout; a.y = y; a.mean = mean; a.invstd = invstd; a.scale = scale; a.coef = coef; a.dpre = dpre; a.partial = partial;
+    a.N = N; a.H = H; a.W = W; a.C = C; a.mode = mode; a.act = act; a.slope = slope;
+    bn_out_dims(H, W, mode, &a.Ho, &a.Wo);
+    if (int e = aesr_launch_bn_bwd_reduce(a, AESR_BN_NWG, (hipStream_t)stream)) return e;
+    if (int e = aesr_launch_bn_bwd_reduce_finalize(partial, AESR_BN_NWG, counts_host, coef, dgamma, dbeta, C, G, (hipStream_t)stream))
+        return e;
     return aesr_launch_bn_bwd_apply(a, (hipStream_t)stream);
 }
 

@@ -57,6 +57,30 @@ int aesr_launch_sum_partials(const float* partial, int np, int n, float* out0, i
 int aesr_launch_smallcin_wgrad(const SmallWgradArgs& a, int nwg, hipStream_t st);
 int aesr_launch_cout1_wgrad(const Cout1WgradArgs& a, int nwg, hipStream_t st);
 
+// "thin" 3x3 convolutions (one side single-channel): conv_thin.hip
+struct ThinArgs {
+    const float* s;        // single-channel image [N,Hs,Ws]
+    const float* w;        // expand: [9][C] tap-major filter
+    const float* be;       // expand: [9][C] per-tap bias counted for taps inside the grid, or nullptr
+    const float* b;        // expand: [C] bias or nullptr
+    const float* ysave;    // expand: saved activation output [N,Ho,Wo,C] for the derivative mask, or nullptr
+    float* out;            // expand: [N,Ho,Wo,C]
+    const float* t;        // reduce: [N,Ho,Wo,C]
+    float* partial;        // reduce: [nwg][nrow][C]
+    int N, Hs, Ws, Ho, Wo, C, ps;
+    int act, mask_act;
+    float slope;
+    int with_be;
+    int tiles_y, tiles_x, ntiles;
+};
+int aesr_launch_thin_expand(ThinArgs a, hipStream_t st);
+int aesr_launch_thin_reduce(ThinArgs a, int nwg, hipStream_t st);
+int aesr_launch_thin_stem_fold(const float* ws, const float* bs, const float* w1, float* folded, int Cs, int C1, hipStream_t st);
+int aesr_launch_thin_stem_finish(const float* R, const float* ws, const float* bs, const float* w1, float* dws, float* dbs,
+                                 float* dw1, float* db1, int Cs, int C1, hipStream_t st);
+int aesr_launch_thin_cout1_flip(const float* w, float* wexp, int Cin, hipStream_t st);
+int aesr_launch_thin_cout1_finish(const float* R, float* dw, float* db, int Cin, hipStream_t st);
+
 struct BnGroups { int G; int nstart[5]; };
 struct BnApplyArgs {
     const float* y; const float* scale; const float* shift; float* out;
@@ -75,6 +99,12 @@ int aesr_launch_bn_reduce(const float* partial, double* sums, int nwg, int C, in
 int aesr_launch_bn_finalize(const double* sums, const double* counts, const float* gamma, const float* beta, float* rm, float* rv,
                             long long* nbt, float* mean, float* invstd, float* scale, float* shift, int C, int G, float momentum,
                             float eps, int train, int update_running, hipStream_t st);
+int aesr_launch_bn_reduce_finalize(const float* partial, int nwg, const double* counts, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, long long* nbt, float* mean, float* invstd,
+                                   float* scale, float* shift, int C, int G, float momentum, float eps, int update_running,
+                                   hipStream_t st);
+int aesr_launch_bn_bwd_reduce_finalize(const float* partial, int nwg, const double* counts, float* coef, float* dgamma,
+                                       float* dbeta, int C, int G, hipStream_t st);
 int aesr_launch_bn_apply(const BnApplyArgs& a, hipStream_t st);
 int aesr_launch_bn_bwd_reduce(const BnBwdArgs& a, int nwg, hipStream_t st);
 int aesr_launch_bn_bwd_finalize(const double* sums, const double* counts, float* coef, float* dgamma, float* dbeta, int C, int G, hipStream_t st);

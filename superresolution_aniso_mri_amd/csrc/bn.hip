@@ -78,38 +78,89 @@ __global__ __launch_bounds__(1024) void bn_reduce_kernel(const float* __restrict
 // train: stats from sums/counts (+ running update, group after group); eval: stats from the running buffers
 struct BnCounts { double c[4]; };
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, BnCounts counts,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   long long* __restrict__ nbt, float* __restrict__ mean, float* __restrict__ invstd,
-                                   float* __restrict__ scale, float* __restrict__ shift, int C, int G, float momentum,
-                                   float eps, int train, int update_running) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && train && update_running && nbt) *nbt += G;
-    if (c >= C) return;
-    for (int g = 0; g < G; ++g) {
-        float m, iv;
-        if (train) {
-            const double M = counts.c[g];
-            const double mu = sums[(g * 2 + 0) * C + c] / M;
-            double var = sums[(g * 2 + 1) * C + c] / M - mu * mu;
-            if (var < 0.0) var = 0.0;
-            m = (float)mu;
-            iv = (float)(1.0 / sqrt(var + (double)eps));
-            if (update_running) {
-                const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
-                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
-            }
-        } else {
-            m = running_mean[c];
-            iv = 1.f / sqrtf(running_var[c] + eps);
+struct BnFinArgs {
+    const float* gamma; const float* beta; float* running_mean; float* running_var; long long* nbt;
+    float* mean; float* invstd; float* scale; float* shift;
+    int C, G;
+    float momentum, eps;
+    int train, update_running;
+    BnCounts counts;
+};
+
+// one channel, one group: (sum, sum of squares) -> mean / invstd / scale / shift (+ running statistics)
+__device__ __forceinline__ void bn_finalize_one(const BnFinArgs& f, int c, int g, double s0, double s1) {
+    float m, iv;
+    if (f.train) {
+        const double M = f.counts.c[g];
+        const double mu = s0 / M;
+        double var = s1 / M - mu * mu;
+        if (var < 0.0) var = 0.0;
+        m = (float)mu;
+        iv = (float)(1.0 / sqrt(var + (double)f.eps));
+        if (f.update_running) {
+            const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
+            f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * m;
+            f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unb;
         }
-        mean[g * C + c] = m;
-        invstd[g * C + c] = iv;
-        const float sc = gamma[c] * iv;
-        scale[g * C + c] = sc;
-        shift[g * C + c] = beta[c] - m * sc;
+    } else {
+        m = f.running_mean[c];
+        iv = 1.f / sqrtf(f.running_var[c] + f.eps);
+    }
+    f.mean[g * f.C + c] = m;
+    f.invstd[g * f.C + c] = iv;
+    const float sc = f.gamma[c] * iv;
+    f.scale[g * f.C + c] = sc;
+    f.shift[g * f.C + c] = f.beta[c] - m * sc;
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, BnFinArgs f) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && f.train && f.update_running && f.nbt) *f.nbt += f.G;
+    if (c >= f.C) return;
+    for (int g = 0; g < f.G; ++g)
+        bn_finalize_one(f, c, g, f.train ? sums[(g * 2 + 0) * f.C + c] : 0.0, f.train ? sums[(g * 2 + 1) * f.C + c] : 0.0);
+}
+
+// column sums of partial[g][wg][2][C] for one channel column: 16 row-lanes x 4 independent accumulators, fixed order.
+// Returns the total in the rl == 0 threads.  red: [16][64] doubles.
+__device__ __forceinline__ double bn_column_total(const float* __restrict__ base, int nwg, int rowstride, bool live,
+                                                  double (*red)[64], int col, int rl) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (live) {
+        int k = rl;
+        for (; k + 48 < nwg; k += 64) {
+            const float v0 = base[(size_t)k * rowstride], v1 = base[(size_t)(k + 16) * rowstride];
+            const float v2 = base[(size_t)(k + 32) * rowstride], v3 = base[(size_t)(k + 48) * rowstride];
+            s0 += (double)v0;
+            s1 += (double)v1;
+            s2 += (double)v2;
+            s3 += (double)v3;
+        }
+        for (; k < nwg; k += 16) s0 += (double)base[(size_t)k * rowstride];
+    }
+    __syncthreads();
+    red[rl][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    double t = 0.0;
+    if (rl == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][col];
+    }
+    return t;
+}
+
+// Statistics partials -> finalize in ONE launch (no SyncBN exchange in between).  block = 64 channels x 16 row-lanes.
+__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ partial, int nwg, BnFinArgs f) {
+    __shared__ double red[16][64];
+    const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + col;
+    const bool live = c < f.C;
+    if (c == 0 && rl == 0 && f.update_running && f.nbt) *f.nbt += f.G;
+    for (int g = 0; g < f.G; ++g) {
+        const float* base = partial + (size_t)g * nwg * 2 * f.C + c;
+        const double s0 = bn_column_total(base, nwg, 2 * f.C, live, red, col, rl);
+        const double s1 = bn_column_total(base + f.C, nwg, 2 * f.C, live, red, col, rl);
+        if (rl == 0 && live) bn_finalize_one(f, c, g, s0, s1);
     }
 }
 
@@ -165,18 +216,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
     const int C4 = a.C >> 2, PL = 256 / C4;
     const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
     const int g = blockIdx.y;
-    const int HW = a.H * a.W;
-    const size_t p0 = (size_t)a.gr.nstart[g] * HW, p1 = (size_t)a.gr.nstart[g + 1] * HW;
+    const unsigned HW = a.H * a.W;
+    const unsigned p0 = a.gr.nstart[g] * HW, p1 = a.gr.nstart[g + 1] * HW;       // host checks N*H*W < 2^31
     const f32x4 mu = *(const f32x4*)(a.mean + g * a.C + c4 * 4);
     const f32x4 iv = *(const f32x4*)(a.invstd + g * a.C + c4 * 4);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     if (pl < PL) {
-        for (size_t p = p0 + (size_t)blockIdx.x * PL + pl; p < p1; p += (size_t)gridDim.x * PL) {
-            const int n = p / HW;
-            const int rem = p - (size_t)n * HW;
-            const int yy = rem / a.W, x = rem - yy * a.W;
+        for (unsigned p = p0 + blockIdx.x * PL + pl; p < p1; p += gridDim.x * PL) {
+            const unsigned n = p / HW;
+            const unsigned rem = p - n * HW;
+            const unsigned yy = rem / (unsigned)a.W, x = rem - yy * a.W;
             const f32x4 gg = bn_gather_g(a, n, yy, x, c4);
-            const f32x4 xh = (*(const f32x4*)(a.y + p * a.C + c4 * 4) - mu) * iv;
+            const f32x4 xh = (*(const f32x4*)(a.y + (size_t)p * a.C + c4 * 4) - mu) * iv;
             s1 += gg;
             s2 += gg * xh;
         }
@@ -207,6 +258,32 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, BnCounts
     }
     dgamma[c] = (float)dg;
     dbeta[c] = (float)db;
+}
+
+// backward-reduce partials -> coef / dgamma / dbeta in ONE launch (same math as bn_reduce + bn_bwd_finalize)
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_finalize_kernel(const float* __restrict__ partial, int nwg, BnCounts counts,
+                                                                      float* __restrict__ coef, float* __restrict__ dgamma,
+                                                                      float* __restrict__ dbeta, int C, int G) {
+    __shared__ double red[16][64];
+    const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + col;
+    const bool live = c < C;
+    double dg = 0.0, db = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const float* base = partial + (size_t)g * nwg * 2 * C + c;
+        const double s1 = bn_column_total(base, nwg, 2 * C, live, red, col, rl);
+        const double s2 = bn_column_total(base + C, nwg, 2 * C, live, red, col, rl);
+        if (rl == 0 && live) {
+            coef[(g * 2 + 0) * C + c] = (float)(s1 / counts.c[g]);
+            coef[(g * 2 + 1) * C + c] = (float)(s2 / counts.c[g]);
+            db += s1;
+            dg += s2;
+        }
+    }
+    if (rl == 0 && live) {
+        dgamma[c] = (float)dg;
+        dbeta[c] = (float)db;
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
@@ -258,15 +335,46 @@ int aesr_launch_bn_reduce(const float* partial, double* sums, int nwg, int C, in
     return AESR_OK;
 }
 
+static BnFinArgs bn_fin_args(const double* counts, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             long long* nbt, float* mean, float* invstd, float* scale, float* shift, int C, int G, float momentum,
+                             float eps, int train, int update_running) {
+    BnFinArgs f;
+    f.gamma = gamma; f.beta = beta; f.running_mean = running_mean; f.running_var = running_var; f.nbt = nbt;
+    f.mean = mean; f.invstd = invstd; f.scale = scale; f.shift = shift; f.C = C; f.G = G; f.momentum = momentum; f.eps = eps;
+    f.train = train; f.update_running = update_running;
+    for (int g = 0; g < 4; ++g) f.counts.c[g] = (counts && g < G) ? counts[g] : 1.0;
+    return f;
+}
+
 int aesr_launch_bn_finalize(const double* sums, const double* counts, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, long long* nbt, float* mean, float* invstd,
                             float* scale, float* shift, int C, int G, float momentum, float eps, int train,
                             int update_running, hipStream_t st) {
+    const BnFinArgs f = bn_fin_args(counts, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift, C, G, momentum,
+                                    eps, train, update_running);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, sums, f);
+    AESR_LAUNCH_CHECK("bn_finalize");
+    return AESR_OK;
+}
+
+int aesr_launch_bn_reduce_finalize(const float* partial, int nwg, const double* counts, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, long long* nbt, float* mean, float* invstd,
+                                   float* scale, float* shift, int C, int G, float momentum, float eps, int update_running,
+                                   hipStream_t st) {
+    const BnFinArgs f = bn_fin_args(counts, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift, C, G, momentum,
+                                    eps, 1, update_running);
+    hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, st, partial, nwg, f);
+    AESR_LAUNCH_CHECK("bn_reduce_finalize");
+    return AESR_OK;
+}
+
+int aesr_launch_bn_bwd_reduce_finalize(const float* partial, int nwg, const double* counts, float* coef, float* dgamma,
+                                       float* dbeta, int C, int G, hipStream_t st) {
     BnCounts cnt;
     for (int g = 0; g < 4; ++g) cnt.c[g] = (counts && g < G) ? counts[g] : 1.0;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, sums, cnt, gamma, beta, running_mean,
-                       running_var, nbt, mean, invstd, scale, shift, C, G, momentum, eps, train, update_running);
-    AESR_LAUNCH_CHECK("bn_finalize");
+    hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, st, partial, nwg, cnt, coef, dgamma,
+                       dbeta, C, G);
+    AESR_LAUNCH_CHECK("bn_bwd_reduce_finalize");
     return AESR_OK;
 }
 

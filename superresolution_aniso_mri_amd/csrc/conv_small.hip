@@ -311,19 +311,33 @@ __global__ __launch_bounds__(256) void conv_cout1_wgrad_kernel(Cout1WgradArgs a)
 }
 
 // out[o] = sum_p partial[p][o]  (fixed order; double accumulate), optional second output split at n0
-// block = 64 columns x 4 row-lanes
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int np, int n,
-                                                           float* __restrict__ out0, int n0, float* __restrict__ out1) {
-    __shared__ double red[4][64];
+// block = 64 columns x 16 row-lanes; every row-lane keeps 4 independent loads in flight
+__global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ partial, int np, int n,
+                                                            float* __restrict__ out0, int n0, float* __restrict__ out1) {
+    __shared__ double red[16][64];
     const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int o = blockIdx.x * 64 + col;
     double s = 0.0;
-    if (o < n)
-        for (int p = rl; p < np; p += 4) s += (double)partial[(size_t)p * n + o];
+    if (o < n) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int p = rl;
+        for (; p + 48 < np; p += 64) {
+            const float v0 = partial[(size_t)p * n + o], v1 = partial[(size_t)(p + 16) * n + o];
+            const float v2 = partial[(size_t)(p + 32) * n + o], v3 = partial[(size_t)(p + 48) * n + o];
+            s0 += (double)v0;
+            s1 += (double)v1;
+            s2 += (double)v2;
+            s3 += (double)v3;
+        }
+        for (; p < np; p += 16) s0 += (double)partial[(size_t)p * n + o];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[rl][col] = s;
     __syncthreads();
     if (rl == 0 && o < n) {
-        s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][col];
         if (o < n0) out0[o] = (float)s;
         else out1[o - n0] = (float)s;
     }
@@ -360,7 +374,7 @@ int aesr_launch_smallcin_dgrad(const SmallDgradArgs& a, hipStream_t st) {
 }
 
 int aesr_launch_sum_partials(const float* partial, int np, int n, float* out0, int n0, float* out1, hipStream_t st) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(n, 64)), dim3(256), 0, st, partial, np, n, out0, n0, out1);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(n, 64)), dim3(1024), 0, st, partial, np, n, out0, n0, out1);
     AESR_LAUNCH_CHECK("sum_partials");
     return AESR_OK;
 }

@@ -1,0 +1,333 @@
+// "Thin" 3x3 convolutions: one side of the convolution has a single channel, so the op is bandwidth-bound on the
+// multi-channel tensor and does not belong on the matrix cores.
+//
+//   expand   out[n,y,x,c] = act(b[c] + sum_t ( w[t][c] * s[n, y+dy_t-ps, x+dx_t-ps]  +  [ (y+dy_t, x+dx_t) in grid ] * be[t][c] )) * mask
+//   reduce   r[t][c]  = sum_{n,y,x} T[n,y,x,c] * s[n, y+dy_t-ps, x+dx_t-ps]
+//            rb[t][c] = sum_{n,y,x} [ (y+dy_t, x+dx_t) in grid ] * T[n,y,x,c]          ssum = sum s over the grid
+//
+// (t = 3*(dy+1)+(dx+1), dy,dx in -1..1; s is zero outside its [Hs,Ws] extent; "grid" is the [Ho,Wo] extent of the
+// multi-channel tensor.)  Users:
+//   * the encoder stem folded into the first 3x3 convolution (networks/acai_vanilla.py:51,55): a 1x1 pad-1 conv
+//     colors=1 -> Cs followed, with no non-linearity in between, by a 3x3 pad-1 conv Cs -> C1 is exactly a 1 -> C1
+//     3x3 conv with the folded filter  weff[t][co] = sum_c W1[co,c,t]*ws[c]  plus a per-tap bias
+//     beff[t][co] = sum_c W1[co,c,t]*bs[c]  that only counts for taps that land inside the stem's (H+2)x(W+2) output
+//     grid.  Forward = expand; backward = reduce (+ the chain rule back to W1, ws, bs in thin_stem_finish_kernel).
+//     The Cs-channel stem tensor never exists.
+//   * the Cout == 1 output convolution (networks/acai_vanilla.py:98): its data gradient is an expand of dy with the
+//     flipped filter (and the derivative of the LeakyReLU in front of it as the mask), its weight gradient a reduce of
+//     the saved input against dy.
+//
+// Tile = 8 rows x min(64, 256 / (C/4)) columns; a thread owns one channel quad of one column and walks the 8 rows; the
+// single-channel patch (tile + halo) sits in LDS.  16-byte accesses on the multi-channel side, 1 KiB contiguous per
+// wave.
+#include "aesr_kernels.h"
+
+#define THIN_TH 8
+#define THIN_XS 68
+
+__host__ __device__ __forceinline__ int thin_tw(int C4) { return 256 / C4 < 64 ? 256 / C4 : 64; }
+
+__device__ __forceinline__ void thin_stage(const ThinArgs& a, float (*xs)[THIN_XS], int n, int y0, int x0, int TW) {
+    const int PW = TW + 2;
+    for (int q = threadIdx.x; q < (THIN_TH + 2) * PW; q += 256) {
+        const int r = q / PW, c = q - r * PW;
+        const int sy = y0 + r - 1 - a.ps, sx = x0 + c - 1 - a.ps;
+        float v = 0.f;
+        if (sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws) v = a.s[((size_t)n * a.Hs + sy) * a.Ws + sx];
+        xs[r][c] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void thin_expand_kernel(ThinArgs a) {
+    __shared__ float xs[THIN_TH + 2][THIN_XS];
+    const int C4 = a.C >> 2, TW = thin_tw(C4);
+    const int tid = threadIdx.x, c4 = tid % C4, pl = tid / C4;
+    int tile = blockIdx.x;
+    const int tx = tile % a.tiles_x;
+    tile /= a.tiles_x;
+    const int ty = tile % a.tiles_y;
+    const int n = tile / a.tiles_y;
+    const int y0 = ty * THIN_TH, x0 = tx * TW;
+    thin_stage(a, xs, n, y0, x0, TW);
+    f32x4 w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = *(const f32x4*)(a.w + t * a.C + c4 * 4);
+    const f32x4 b0 = a.b ? *(const f32x4*)(a.b + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 bfull = b0;
+    if (a.be) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) bfull += *(const f32x4*)(a.be + t * a.C + c4 * 4);
+    }
+    __syncthreads();
+    const int ox = x0 + pl;
+    if (pl >= TW || ox >= a.Wo) return;
+    const bool xedge = a.be && (ox == 0 || ox == a.Wo - 1);
+#pragma unroll
+    for (int r = 0; r < THIN_TH; ++r) {
+        const int oy = y0 + r;
+        if (oy >= a.Ho) break;
+        f32x4 acc = bfull;
+        if (xedge || (a.be && (oy == 0 || oy == a.Ho - 1))) {       // border of the grid: only the taps that land inside count
+            acc = b0;
+            for (int t = 0; t < 9; ++t) {
+                const int yy = oy + t / 3 - 1, xx = ox + t % 3 - 1;
+                if (yy >= 0 && yy < a.Ho && xx >= 0 && xx < a.Wo) acc += *(const f32x4*)(a.be + t * a.C + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float v = xs[r + t / 3][pl + t % 3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(w[t][e], v, acc[e]);
+        }
+        const size_t o = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.C + c4 * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = act_apply(acc[e], a.act, a.slope);
+        if (a.ysave) {
+            const f32x4 ys = *(const f32x4*)(a.ysave + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] *= act_grad_from_output(ys[e], a.mask_act, a.slope);
+        }
+        *(f32x4*)(a.out + o) = acc;
+    }
+}
+
+// partial[wg][row][c]: rows 0..8 = r, (WITH_BE: rows 9..17 = rb), last row: column 0 = ssum, other columns 0
+template <bool WITH_BE>
+__global__ __launch_bounds__(256) void thin_reduce_kernel(ThinArgs a) {
+    __shared__ float xs[THIN_TH + 2][THIN_XS];
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [4 waves][NROW][C]
+    constexpr int NROW = WITH_BE ? 19 : 10;
+    const int C4 = a.C >> 2, TW = thin_tw(C4);
+    const int tid = threadIdx.x, c4 = tid % C4, pl = tid / C4;
+    const int lane = tid & 63, wave = tid >> 6;
+    f32x4 accW[9], accB[9];
+    float accs = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        accW[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        accB[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int tpi = a.tiles_y * a.tiles_x;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int n = tile / tpi;
+        const int trem = tile - n * tpi;
+        const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+        const int y0 = ty * THIN_TH, x0 = tx * TW;
+        __syncthreads();
+        thin_stage(a, xs, n, y0, x0, TW);
+        const int ox = x0 + pl;
+        const bool xin = pl < TW && ox < a.Wo;
+        const int plr = pl < TW ? pl : 0;               // idle threads (C < 16) read a valid LDS column, their g is 0
+        f32x4 g[THIN_TH];
+#pragma unroll
+        for (int r = 0; r < THIN_TH; ++r) {
+            const int oy = y0 + r;
+            g[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (xin && oy < a.Ho) g[r] = *(const f32x4*)(a.t + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.C + c4 * 4);
+        }
+        float mxf[3];
+        mxf[0] = (ox - 1 >= 0) ? 1.f : 0.f;
+        mxf[1] = 1.f;
+        mxf[2] = (ox + 1 < a.Wo) ? 1.f : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < THIN_TH; ++r) {
+            const int oy = y0 + r;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float v = xs[r + t / 3][plr + t % 3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) accW[t][e] = fmaf(g[r][e], v, accW[t][e]);
+            }
+            if (WITH_BE) {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int yy = oy + dy - 1;
+                    const float myf = (yy >= 0 && yy < a.Ho) ? 1.f : 0.f;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float m = myf * mxf[dx];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) accB[dy * 3 + dx][e] = fmaf(g[r][e], m, accB[dy * 3 + dx][e]);
+                    }
+                }
+            }
+            if (c4 == 0 && xin && oy < a.Ho) accs += xs[r + 1][plr + 1];
+        }
+    }
+    // lanes that share a channel quad (same lane % C4) -> butterfly; then the 4 waves through LDS, fixed order
+    for (int m = C4; m < 64; m <<= 1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                accW[t][e] += __shfl_xor(accW[t][e], m, 64);
+                if (WITH_BE) accB[t][e] += __shfl_xor(accB[t][e], m, 64);
+            }
+    }
+    for (int m = 1; m < 64; m <<= 1) accs += __shfl_xor(accs, m, 64);
+    __syncthreads();
+    if (lane < C4) {                              // C4 <= 64: lane == c4 here
+        float* rw = red + (size_t)wave * NROW * a.C;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            *(f32x4*)(rw + t * a.C + c4 * 4) = accW[t];
+            if (WITH_BE) *(f32x4*)(rw + (9 + t) * a.C + c4 * 4) = accB[t];
+        }
+        *(f32x4*)(rw + (NROW - 1) * a.C + c4 * 4) = (f32x4){c4 == 0 ? accs : 0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    const int nout = NROW * a.C;
+    for (int o = tid; o < nout; o += 256)
+        a.partial[(size_t)blockIdx.x * nout + o] =
+            (red[o] + red[(size_t)nout + o]) + (red[2 * (size_t)nout + o] + red[3 * (size_t)nout + o]);
+}
+
+// ---- tiny parameter-side kernels ----------------------------------------------------------------------------------
+
+// folded[0][t][co] = sum_c W1[co,c,t]*ws[c]   folded[1][t][co] = sum_c W1[co,c,t]*bs[c]   (double accumulation)
+__global__ __launch_bounds__(256) void thin_stem_fold_kernel(const float* __restrict__ ws, const float* __restrict__ bs,
+                                                             const float* __restrict__ w1, float* __restrict__ folded, int Cs,
+                                                             int C1) {
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < 9 * C1; o += gridDim.x * 256) {
+        const int t = o / C1, co = o - t * C1;
+        double sw = 0.0, sb = 0.0;
+        for (int c = 0; c < Cs; ++c) {
+            const double wv = (double)w1[((size_t)co * Cs + c) * 9 + t];
+            sw += wv * (double)ws[c];
+            if (bs) sb += wv * (double)bs[c];
+        }
+        folded[o] = (float)sw;
+        folded[9 * C1 + o] = (float)sb;
+    }
+}
+
+// R rows: [0..8] dweff[t][co], [9..17] dbeff[t][co].  Chain rule back to the four parameter tensors.
+// blocks [0, Cs): dws[c], dbs[c] (one block per stem channel, fixed-order tree over the C1*9 terms);
+// blocks [Cs, ...): dw1 / db1 element-wise.
+__global__ __launch_bounds__(256) void thin_stem_finish_kernel(const float* __restrict__ R, const float* __restrict__ ws,
+                                                               const float* __restrict__ bs, const float* __restrict__ w1,
+                                                               float* __restrict__ dws, float* __restrict__ dbs,
+                                                               float* __restrict__ dw1, float* __restrict__ db1, int Cs, int C1) {
+    __shared__ double redw[256], redb[256];
+    if ((int)blockIdx.x < Cs) {
+        const int c = blockIdx.x;
+        double sw = 0.0, sb = 0.0;
+        for (int o = threadIdx.x; o < C1 * 9; o += 256) {
+            const int co = o / 9, t = o - co * 9;
+            const double wv = (double)w1[((size_t)co * Cs + c) * 9 + t];
+            sw += wv * (double)R[t * C1 + co];
+            sb += wv * (double)R[(9 + t) * C1 + co];
+        }
+        redw[threadIdx.x] = sw;
+        redb[threadIdx.x] = sb;
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) {
+            if ((int)threadIdx.x < h) {
+                redw[threadIdx.x] += redw[threadIdx.x + h];
+                redb[threadIdx.x] += redb[threadIdx.x + h];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            dws[c] = (float)redw[0];
+            if (dbs) dbs[c] = (float)redb[0];
+        }
+        return;
+    }
+    const int tid = (blockIdx.x - Cs) * 256 + threadIdx.x, nth = (gridDim.x - Cs) * 256;
+    for (int o = tid; o < C1 * Cs * 9; o += nth) {
+        const int t = o % 9, c = (o / 9) % Cs, co = o / (9 * Cs);
+        float v = R[t * C1 + co] * ws[c];
+        if (bs) v = fmaf(R[(9 + t) * C1 + co], bs[c], v);
+        dw1[o] = v;
+    }
+    if (db1)
+        for (int co = tid; co < C1; co += nth) db1[co] = R[(9 + 4) * C1 + co];     // centre tap is always inside the grid
+}
+
+// Cout == 1 conv: wexp[t][ci] = W[0,ci,8-t] (flipped filter for the data gradient)
+__global__ __launch_bounds__(256) void thin_cout1_flip_kernel(const float* __restrict__ w, float* __restrict__ wexp, int Cin) {
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < 9 * Cin; o += gridDim.x * 256) {
+        const int t = o / Cin, ci = o - t * Cin;
+        wexp[o] = w[ci * 9 + (8 - t)];
+    }
+}
+
+// Cout == 1 conv: dw[ci*9+k] = R[8-k][ci], db = R[9][0]
+__global__ __launch_bounds__(256) void thin_cout1_finish_kernel(const float* __restrict__ R, float* __restrict__ dw,
+                                                                float* __restrict__ db, int Cin) {
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < 9 * Cin; o += gridDim.x * 256) {
+        const int ci = o / 9, k = o - ci * 9;
+        dw[o] = R[(8 - k) * Cin + ci];
+    }
+    if (db && blockIdx.x == 0 && threadIdx.x == 0) db[0] = R[9 * Cin];
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------------
+
+static bool thin_shape_ok(const ThinArgs& a) {
+    const int C4 = a.C / 4;
+    return a.C >= 4 && a.C % 4 == 0 && a.C <= 256 && (C4 & (C4 - 1)) == 0;
+}
+
+int aesr_launch_thin_expand(ThinArgs a, hipStream_t st) {
+    if (!thin_shape_ok(a)) {
+        aesr_set_error("thin conv: C=%d must be 4 times a power of two (4..256)", a.C);
+        return AESR_ERR_ARG;
+    }
+    const int TW = thin_tw(a.C / 4);
+    a.tiles_y = ceil_div(a.Ho, THIN_TH);
+    a.tiles_x = ceil_div(a.Wo, TW);
+    a.ntiles = a.N * a.tiles_y * a.tiles_x;
+    hipLaunchKernelGGL(thin_expand_kernel, dim3(a.ntiles), dim3(256), 0, st, a);
+    AESR_LAUNCH_CHECK("thin_expand");
+    return AESR_OK;
+}
+
+int aesr_launch_thin_reduce(ThinArgs a, int nwg, hipStream_t st) {
+    if (!thin_shape_ok(a)) {
+        aesr_set_error("thin conv: C=%d must be 4 times a power of two (4..256)", a.C);
+        return AESR_ERR_ARG;
+    }
+    const int TW = thin_tw(a.C / 4);
+    a.tiles_y = ceil_div(a.Ho, THIN_TH);
+    a.tiles_x = ceil_div(a.Wo, TW);
+    a.ntiles = a.N * a.tiles_y * a.tiles_x;
+    const int nrow = a.with_be ? 19 : 10;
+    const size_t shmem = (size_t)4 * nrow * a.C * sizeof(float);
+    if (a.with_be)
+        hipLaunchKernelGGL(thin_reduce_kernel<true>, dim3(nwg), dim3(256), shmem, st, a);
+    else
+        hipLaunchKernelGGL(thin_reduce_kernel<false>, dim3(nwg), dim3(256), shmem, st, a);
+    AESR_LAUNCH_CHECK("thin_reduce");
+    return AESR_OK;
+}
+
+int aesr_launch_thin_stem_fold(const float* ws, const float* bs, const float* w1, float* folded, int Cs, int C1, hipStream_t st) {
+    hipLaunchKernelGGL(thin_stem_fold_kernel, dim3(ceil_div(9 * C1, 256)), dim3(256), 0, st, ws, bs, w1, folded, Cs, C1);
+    AESR_LAUNCH_CHECK("thin_stem_fold");
+    return AESR_OK;
+}
+
+int aesr_launch_thin_stem_finish(const float* R, const float* ws, const float* bs, const float* w1, float* dws, float* dbs,
+                                 float* dw1, float* db1, int Cs, int C1, hipStream_t st) {
+    int grid = ceil_div(C1 * Cs * 9, 256);
+    if (grid > 64) grid = 64;
+    hipLaunchKernelGGL(thin_stem_finish_kernel, dim3(Cs + grid), dim3(256), 0, st, R, ws, bs, w1, dws, dbs, dw1, db1, Cs, C1);
+    AESR_LAUNCH_CHECK("thin_stem_finish");
+    return AESR_OK;
+}
+
+int aesr_launch_thin_cout1_flip(const float* w, float* wexp, int Cin, hipStream_t st) {
+    hipLaunchKernelGGL(thin_cout1_flip_kernel, dim3(ceil_div(9 * Cin, 256)), dim3(256), 0, st, w, wexp, Cin);
+    AESR_LAUNCH_CHECK("thin_cout1_flip");
+    return AESR_OK;
+}
+
+int aesr_launch_thin_cout1_finish(const float* R, float* dw, float* db, int Cin, hipStream_t st) {
+    hipLaunchKernelGGL(thin_cout1_finish_kernel, dim3(ceil_div(9 * Cin, 256)), dim3(256), 0, st, R, dw, db, Cin);
+    AESR_LAUNCH_CHECK("thin_cout1_finish");
+    return AESR_OK;
+}

@@ -13,6 +13,7 @@ MFMA split-K wgrad, BatchNorm backward fused with the LeakyReLU derivative).  Ac
 A pass may carry several *statistic groups* (sub-batches with independent BatchNorm batch statistics); only a
 leading prefix of the batch needs gradients.
 """
+import os
 from ctypes import c_float
 
 import torch
@@ -52,6 +53,7 @@ class KernelProfiler:
 
 
 PROFILER = None
+FUSE_STEM = os.environ.get("AESR_FUSE_STEM", "1") != "0"      # fold the encoder stem into the first 3x3 conv
 
 
 def _pb(kind, flops):
@@ -113,6 +115,42 @@ class ConvStep:
         return self.w1
 
 
+class StemConvStep:
+    """Encoder stem ``Conv2d(1, Cs, 1, padding=p)`` folded into the 3x3 convolution that follows it with no non-linearity
+    in between (networks/acai_vanilla.py:51,55): one 1 -> C1 3x3 "thin" convolution, the Cs-channel stem tensor is never
+    written (aesr_stemconv_*)."""
+    kind = "stemconv"
+
+    def __init__(self, stem, conv):
+        self.stem, self.mod = stem.mod, conv.mod
+        self.act, self.slope = conv.act, conv.slope
+        self.cs, self.cout, self.stem_pad = stem.cout, conv.cout, stem.pad
+        self.cin, self.ks, self.pad = 1, 3, 1
+        self.s2d = False
+        self.folded = None
+        self.folded_epoch = -1
+
+    def out_hw(self, h, w):
+        return h + 2 * self.stem_pad, w + 2 * self.stem_pad
+
+
+def _thin_channels(c):
+    """Channel counts the bandwidth-bound "thin" kernels take: 4 * 2^k <= 256."""
+    return 4 <= c <= 256 and c % 4 == 0 and ((c // 4) & (c // 4 - 1)) == 0
+
+
+def fuse_stem(steps):
+    """steps with the leading (1x1 single-channel stem, 3x3 pad-1 conv) pair replaced by one StemConvStep, or None."""
+    if len(steps) < 2 or steps[0].kind != "conv" or steps[1].kind != "conv":
+        return None
+    st, cv = steps[0], steps[1]
+    ok = (st.cin == 1 and st.ks == 1 and not st.s2d and st.act == _hip.ACT_NONE and st.mod.bias is not None
+          and cv.ks == 3 and cv.pad == 1 and not cv.s2d and cv.cin == st.cout and _thin_channels(cv.cout))
+    if not ok:
+        return None
+    return [StemConvStep(st, cv)] + list(steps[2:])
+
+
 class BnStep:
     kind = "bn"
 
@@ -169,6 +207,7 @@ class SequentialRunner:
     def __init__(self, seq):
         self.seq = seq
         self.steps = compile_steps(seq)
+        self.steps_fused = fuse_stem(self.steps) if FUSE_STEM else None
         self.weights_epoch = 0
         self.params = [p for p in seq.parameters()]
 
@@ -196,15 +235,41 @@ class SequentialRunner:
         s.packed_epoch = epoch
 
     # ---- forward ---------------------------------------------------------------------------------------------
-    def forward(self, x, nstart, train, save):
-        """x: NHWC fp32 [N,H,W,C]; nstart: group boundaries (len G+1).  Returns (out, saved)."""
+    def _ensure_folded(self, s):
+        ws, w1 = s.stem.weight, s.mod.weight
+        epoch = (self.weights_epoch, ws._version, s.stem.bias._version, w1._version, ws.data_ptr(), w1.data_ptr())
+        if s.folded_epoch == epoch:
+            return
+        _hip.require_gpu_tensor(w1, "conv weight")
+        n = lib.aesr_stemconv_folded_floats(s.cout)
+        if s.folded is None or s.folded.numel() != n:
+            s.folded = _empty((n,), w1)
+        check(lib.aesr_stemconv_fold(ptr(ws), ptr(s.stem.bias), ptr(w1), ptr(s.folded), s.cs, s.cout, stream()),
+              "aesr_stemconv_fold")
+        s.folded_epoch = epoch
+
+    def forward(self, x, nstart, train, save, fused=True):
+        """x: NHWC fp32 [N,H,W,C]; nstart: group boundaries (len G+1).  Returns (out, saved, steps): ``steps`` is the
+        compiled list that ran (the stem-folded one unless ``fused`` is False, e.g. when the input needs a gradient)."""
         _hip.require_gpu_tensor(x, "input")
         N, H, W, C = x.shape
         G = len(nstart) - 1
         saved = []
         cur = x
-        for s in self.steps:
-            if s.kind == "conv":
+        steps = self.steps_fused if (fused and self.steps_fused is not None) else self.steps
+        for s in steps:
+            if s.kind == "stemconv":
+                if C != 1:
+                    raise RuntimeError("channel mismatch: tensor has %d channels, the stem expects 1" % C)
+                self._ensure_folded(s)
+                Ho, Wo = s.out_hw(H, W)
+                out = _empty((N, Ho, Wo, s.cout), x)
+                check(lib.aesr_stemconv_fwd(ptr(cur), ptr(s.folded), ptr(s.mod.bias), ptr(out), N, H, W, s.cout, s.stem_pad,
+                                            s.act, s.slope, stream()), "aesr_stemconv_fwd")
+                if save:
+                    saved.append((cur, out))
+                cur, H, W, C = out, Ho, Wo, s.cout
+            elif s.kind == "conv":
                 if s.s2d:
                     if C != s.cin_full:
                         raise RuntimeError("channel mismatch: tensor has %d channels, conv expects %d" % (C, s.cin_full))
@@ -245,7 +310,7 @@ class SequentialRunner:
                 if save:
                     saved.append((cur, st))
                 cur, H, W = out, Ho, Wo
-        return cur, saved
+        return cur, saved, steps
 
     sync_bn = None      # optional callable(sums[G,2,C] double) -> all-reduced in place across ranks (data parallel SyncBN)
     count_scale = 1.0   # data parallel: global / local sub-batch size (B_global / B_local of this rank)
@@ -255,18 +320,25 @@ class SequentialRunner:
         dev = y.device
         st = {k: torch.empty((G, C), device=dev, dtype=torch.float32) for k in ("mean", "invstd", "scale", "shift")}
         use_batch = train or bn.running_mean is None
+        momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+        update = bool(train and bn.track_running_stats and bn.running_mean is not None)
         sums = counts = None
         if use_batch:
             partial = torch.empty((G * _hip.BN_NWG * 2 * C,), device=dev, dtype=torch.float32)
+            counts = [float((nstart[g + 1] - nstart[g]) * H * W) * self.count_scale for g in range(G)]   # host values
+            st["counts"] = counts
+            if self.sync_bn is None:        # single process: statistics -> finalize without the sums round trip
+                check(lib.aesr_bn_stats_finalize(ptr(y), ptr(partial), _hip.double_array(counts), ptr(bn.weight), ptr(bn.bias),
+                                                 ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
+                                                 ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(st["shift"]), H * W, C,
+                                                 G, _hip.int_array(nstart), momentum, float(bn.eps), int(update), stream()),
+                      "aesr_bn_stats_finalize")
+                return st
             sums = torch.empty((G, 2, C), device=dev, dtype=torch.float64)
             check(lib.aesr_bn_stats(ptr(y), ptr(partial), ptr(sums), H * W, C, G, _hip.int_array(nstart), stream()),
                   "aesr_bn_stats")
-            counts = [float((nstart[g + 1] - nstart[g]) * H * W) * self.count_scale for g in range(G)]   # host values
-            if self.sync_bn is not None:
-                self.sync_bn(sums)
+            self.sync_bn(sums)
         st["counts"] = counts
-        momentum = 0.1 if bn.momentum is None else float(bn.momentum)
-        update = bool(train and bn.track_running_stats and bn.running_mean is not None)
         check(lib.aesr_bn_finalize(ptr(sums), _hip.double_array(counts) if counts else None, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
                                    ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(st["mean"]), ptr(st["invstd"]),
                                    ptr(st["scale"]), ptr(st["shift"]), C, G, momentum, float(bn.eps), int(use_batch),
@@ -286,10 +358,10 @@ class SequentialRunner:
         grads[p] = t
         return t
 
-    def backward(self, gout, saved, nstart, ngrad, need_input_grad):
+    def backward(self, gout, saved, nstart, ngrad, need_input_grad, steps=None):
         """gout: NHWC gradient of the pass output (all N images; only the first ``ngrad`` are used).
         Returns (dx or None, {param: grad})."""
-        steps = self.steps
+        steps = self.steps if steps is None else steps
         grads = {}
         G = 0
         while G < len(nstart) - 1 and nstart[G + 1] <= ngrad:
@@ -302,6 +374,20 @@ class SequentialRunner:
             g = g.contiguous()
         for k in range(len(steps) - 1, -1, -1):
             s = steps[k]
+            if s.kind == "stemconv":
+                if need_input_grad:
+                    raise RuntimeError("the stem-folded pass has no input gradient (run the pass with fused=False)")
+                xin = saved[k][0]
+                _, H, W, _ = xin.shape
+                dws, dbs = self._grad_dst(s.stem.weight, grads), self._grad_dst(s.stem.bias, grads)
+                dw1 = self._grad_dst(s.mod.weight, grads)
+                db1 = self._grad_dst(s.mod.bias, grads) if s.mod.bias is not None else None
+                ws = _empty((lib.aesr_stemconv_workspace_floats(s.cout),), g)
+                check(lib.aesr_stemconv_wgrad(ptr(xin), ptr(g), ptr(s.stem.weight), ptr(s.stem.bias), ptr(s.mod.weight),
+                                              ptr(dws), ptr(dbs), ptr(dw1), ptr(db1), ptr(ws), ngrad, H, W, s.cs, s.cout,
+                                              s.stem_pad, stream()), "aesr_stemconv_wgrad")
+                g = None
+                break
             if s.kind == "conv":
                 xin, yout = saved[k][0], saved[k][1]
                 N, H, W, _ = xin.shape
@@ -327,7 +413,7 @@ class SequentialRunner:
                     check(lib.aesr_conv2d_smallcin_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout,
                                                          s.pad, stream()), "aesr_conv2d_smallcin_wgrad")
                 elif s.cout == 1 and s.ks == 3 and s.pad == 1 and db is not None:
-                    ws = _empty((lib.aesr_small_wgrad_workspace_floats(s.cin * 9 + 1),), g)
+                    ws = _empty((lib.aesr_conv2d_cout1_workspace_floats(s.cin),), g)
                     check(lib.aesr_conv2d_cout1_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, stream()),
                           "aesr_conv2d_cout1_wgrad")
                 else:
@@ -339,7 +425,7 @@ class SequentialRunner:
                     g = None
                     break
                 mask, mask_act, mslope = None, _hip.ACT_NONE, 0.0
-                if k > 0 and steps[k - 1].kind == "conv":
+                if k > 0 and steps[k - 1].kind in ("conv", "stemconv"):
                     mask, mask_act, mslope = saved[k - 1][1], steps[k - 1].act, steps[k - 1].slope
                     if mask_act == _hip.ACT_NONE:
                         mask = None
@@ -352,6 +438,10 @@ class SequentialRunner:
                     check(lib.aesr_conv2d_dgrad(ptr(g), ptr(s.packed_t), ptr(mask), ptr(dx), N, H, W, s.cin, s.cout, s.ks,
                                                 s.pad, mask_act, mslope, stream()), "aesr_conv2d_dgrad")
                     _pe()
+                elif s.cout == 1 and s.ks == 3 and s.pad == 1 and _thin_channels(s.cin):
+                    wsf = _empty((9 * s.cin,), g)
+                    check(lib.aesr_conv2d_cout1_dgrad(ptr(g), ptr(s.mod.weight), ptr(mask), ptr(dx), ptr(wsf), N, H, W, s.cin,
+                                                      mask_act, mslope, stream()), "aesr_conv2d_cout1_dgrad")
                 elif s.cout <= 4:
                     # data gradient of a tiny-Cout conv == small-Cin forward conv with the flipped/transposed filter
                     check(lib.aesr_conv2d_smallcin_fwd(ptr(g), ptr(s.mod.weight), None, ptr(mask), ptr(dx), N, Ho, Wo, s.cout,
@@ -374,54 +464,83 @@ class SequentialRunner:
                 N = ngrad
                 dev = y.device
                 partial = torch.empty((G * _hip.BN_NWG * 2 * C,), device=dev, dtype=torch.float32)
-                sums = torch.empty((G, 2, C), device=dev, dtype=torch.float64)
                 nsa = _hip.int_array(ns)
-                check(lib.aesr_bn_bwd_reduce(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(partial), ptr(sums), N, H,
-                                             W, C, s.mode, G, nsa, stream()), "aesr_bn_bwd_reduce")
-                if self.sync_bn is not None:
-                    self.sync_bn(sums)
                 coef = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
                 dgamma, dbeta = self._grad_dst(s.mod.weight, grads), self._grad_dst(s.mod.bias, grads)
                 dpre = _empty((N, H, W, C), y)
-                check(lib.aesr_bn_bwd_apply(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(sums),
-                                            _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dpre), N, H, W, C,
-                                            s.mode, prev.act, prev.slope, G, nsa, stream()), "aesr_bn_bwd_apply")
+                if self.sync_bn is None:
+                    check(lib.aesr_bn_bwd(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(partial),
+                                          _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dpre), N, H, W,
+                                          C, s.mode, prev.act, prev.slope, G, nsa, stream()), "aesr_bn_bwd")
+                else:
+                    sums = torch.empty((G, 2, C), device=dev, dtype=torch.float64)
+                    check(lib.aesr_bn_bwd_reduce(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(partial), ptr(sums), N,
+                                                 H, W, C, s.mode, G, nsa, stream()), "aesr_bn_bwd_reduce")
+                    self.sync_bn(sums)
+                    check(lib.aesr_bn_bwd_apply(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(sums),
+                                                _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dpre),
+                                                N, H, W, C, s.mode, prev.act, prev.slope, G, nsa, stream()), "aesr_bn_bwd_apply")
                 g = dpre
         return g, grads
 
 
 class _PassFn(torch.autograd.Function):
-    """One pass of a compiled stack as a single autograd node (NHWC in, NHWC out)."""
+    """One pass of a compiled stack as a single autograd node: NHWC batch in, one logical-NCHW view of the NHWC output
+    buffer per sub-batch out (so the caller never runs an autograd split / cat / layout copy on the activations)."""
 
     @staticmethod
-    def forward(ctx, runner, nstart, ngrad, train, x, *params):
+    def forward(ctx, runner, nstart, ngrad, train, splits, x, *params):
         need = any(ctx.needs_input_grad) and ngrad > 0       # grad mode is off inside forward(); this is the truth
-        out, saved = runner.forward(x.detach(), nstart, train, save=need)
-        ctx.runner, ctx.nstart, ctx.ngrad, ctx.saved = runner, nstart, ngrad, saved
+        out, saved, steps = runner.forward(x.detach(), nstart, train, save=need, fused=not x.requires_grad)
+        ctx.runner, ctx.nstart, ctx.ngrad, ctx.saved, ctx.steps = runner, nstart, ngrad, saved, steps
         ctx.x_needs_grad = x.requires_grad
-        ctx.nparams = len(params)
-        ctx.N = x.shape[0]
-        return out
+        ctx.N, ctx.splits, ctx.out_shape = x.shape[0], splits, tuple(out.shape)
+        outs, n0 = [], 0
+        for n in splits:
+            outs.append(out[n0:n0 + n].permute(0, 3, 1, 2))
+            n0 += n
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, *gouts):
         runner = ctx.runner
-        if not gout.is_contiguous():
-            gout = gout.contiguous()
-        dx, grads = runner.backward(gout, ctx.saved, ctx.nstart, ctx.ngrad, ctx.x_needs_grad)
+        # NHWC gradient of the leading ``ngrad`` images (the only ones the backward pass reads)
+        parts, n0 = [], 0
+        for n, g in zip(ctx.splits, gouts):
+            if n0 >= ctx.ngrad:
+                break
+            take = min(n, ctx.ngrad - n0)
+            if g is None:
+                ref = next(t for t in gouts if t is not None)
+                parts.append(torch.zeros((take,) + ctx.out_shape[1:], device=ref.device, dtype=torch.float32))
+            else:
+                parts.append(g.permute(0, 2, 3, 1)[:take])
+            n0 += n
+        gout = parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, dim=0)
+        dx, grads = runner.backward(gout, ctx.saved, ctx.nstart, ctx.ngrad, ctx.x_needs_grad, ctx.steps)
         ctx.saved = None
         if dx is not None and ctx.ngrad < ctx.N:
             full = torch.zeros((ctx.N,) + tuple(dx.shape[1:]), device=dx.device, dtype=dx.dtype)
             full[:ctx.ngrad] = dx
             dx = full
-        return (None, None, None, None, dx) + tuple(grads.get(p) for p in runner.params)
+        return (None, None, None, None, None, dx) + tuple(grads.get(p) for p in runner.params)
 
 
-def run_pass(runner, x_nhwc, nstart=None, ngrad=None, train=True):
+def run_pass_groups(runner, x_nhwc, splits, nstart=None, ngrad=None, train=True):
+    """Runs the stack over the NHWC batch and returns one logical-NCHW output view per entry of ``splits`` (image counts)."""
     n = x_nhwc.shape[0]
     nstart = tuple(nstart) if nstart is not None else (0, n)
     ngrad = n if ngrad is None else int(ngrad)
-    return _PassFn.apply(runner, nstart, ngrad, bool(train), x_nhwc, *runner.params)
+    splits = tuple(int(v) for v in splits)
+    if sum(splits) != n:
+        raise ValueError("splits %s do not add up to the batch size %d" % (splits, n))
+    return list(_PassFn.apply(runner, nstart, ngrad, bool(train), splits, x_nhwc, *runner.params))
+
+
+def run_pass(runner, x_nhwc, nstart=None, ngrad=None, train=True):
+    """Single-output form: NHWC in, NHWC out."""
+    out = run_pass_groups(runner, x_nhwc, (x_nhwc.shape[0],), nstart, ngrad, train)[0]
+    return out.permute(0, 2, 3, 1)
 
 
 # ---- layout helpers (zero-copy where the memory already is NHWC) -----------------------------------------------
@@ -431,7 +550,9 @@ def to_nhwc(t):
         raise ValueError("expected a 4-D NCHW tensor, got shape %s" % (tuple(t.shape),))
     if t.dtype != torch.float32:
         t = t.float()
-    return t.permute(0, 2, 3, 1).contiguous()       # no-op copy when t is channels_last or C == 1
+    if t.shape[1] == 1:                              # single channel: NCHW memory IS NHWC memory
+        return t.contiguous().reshape(t.shape[0], t.shape[2], t.shape[3], 1)
+    return t.permute(0, 2, 3, 1).contiguous()       # no-op when t is channels_last
 
 
 def to_nchw_view(t_nhwc):

@@ -125,11 +125,7 @@ class HipAE(nn.Module):
         if not self.training:
             nstart = [0, nstart[-1]]          # eval: running statistics, groups are irrelevant
             ngrad = nstart[-1] if ngrad > 0 else 0
-        out = engine.run_pass(self._runner(name), x, nstart, ngrad, train=self.training)
-        out = engine.to_nchw_view(out)
-        if len(xs) == 1:
-            return [out]
-        return list(torch.split(out, [t.shape[0] for t in xs], dim=0))
+        return engine.run_pass_groups(self._runner(name), x, [t.shape[0] for t in xs], nstart, ngrad, train=self.training)
 
     def encode_multi(self, images, needs_grad=None):
         return self._pass("enc", images, needs_grad)

@@ -117,6 +117,46 @@ def test_grouped_passes_equal_sequential_passes():
             assert int(sd[k]) == int(v) == 2
 
 
+@pytest.mark.parametrize("cname,args", [("VanillaACAI", SMALL), ("LargerAE", SMALL), ("VanillaACAIStrided", SMALL),
+                                        ("VanillaACAI", dict(SMALL, width=64, latent_width=16, depth=32, latent=32))])
+def test_stem_folded_pass_equals_unfolded_pass(cname, args):
+    """The encoder pass with the stem folded into the first 3x3 convolution (default) == the layer-by-layer pass
+    (outputs 1e-5, every parameter gradient 1e-4, BatchNorm running statistics 1e-5)."""
+    torch.manual_seed(11)
+    model = _model(cname, args)
+    for p in model.parameters():           # non-zero biases so the per-tap border bias matters
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    model.mark_weights_dirty()
+    runner = model._runner("enc")
+    assert runner.steps_fused is not None and runner.steps_fused[0].kind == "stemconv"
+    W = args["width"]
+    x, btw = torch.rand(4, 1, W, W).cuda(), torch.rand(2, 1, W, W).cuda()
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    res = []
+    for fused in (True, False):
+        model.load_state_dict(state0)
+        model.zero_grad(set_to_none=True)
+        model.train()
+        fused_steps = runner.steps_fused
+        if not fused:
+            runner.steps_fused = None
+        try:
+            z, zb = model.encode_multi([x, btw], needs_grad=[True, False])
+            (z ** 2).mean().backward()
+        finally:
+            runner.steps_fused = fused_steps
+        res.append((z.detach().clone(), zb.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                    {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
+    (z1, zb1, g1, r1), (z0, zb0, g0, r0) = res
+    assert rel_l2(z1, z0) < 1e-5 and rel_l2(zb1, zb0) < 1e-5
+    assert set(g1) == set(g0) and any(k.startswith("enc.0.") for k in g1)
+    for k in g0:
+        assert rel_l2(g1[k], g0[k]) < 1e-4, k
+    for k in r0:
+        assert rel_l2(r1[k], r0[k]) < 1e-5, k
+
+
 def test_cpu_tensor_is_refused_loudly():
     model = _model("VanillaACAI", SMALL)
     with pytest.raises(RuntimeError, match="no CPU fallback"):

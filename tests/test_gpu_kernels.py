@@ -184,9 +184,11 @@ def test_smallcin_bcast_matches_scaling_layer(hip):
     assert rel_l2(dx.reshape(N, 1, H, W), x.grad) < 1e-5
 
 
-def test_cout1_conv_backward(hip):
-    """Output conv 32->1: dgrad through the small-Cin forward kernel (transpose flag) + dedicated wgrad."""
-    N, H, W, cin = 2, 24, 20, 32
+@pytest.mark.parametrize("shape", [(2, 24, 20, 32), (3, 37, 70, 16), (1, 9, 130, 64), (2, 160, 160, 32), (2, 12, 12, 8)])
+def test_cout1_conv_backward(hip, shape):
+    """Output conv Cin->1 (networks/acai_vanilla.py:98): data gradient (thin expand kernel, or the small-Cin kernel with
+    the transpose flag for channel counts the thin kernels do not take) + weight/bias gradient."""
+    N, H, W, cin = shape
     g = torch.Generator().manual_seed(9)
     h = torch.randn(N, cin, H, W, generator=g).requires_grad_(True)
     w = torch.randn(1, cin, 3, 3, generator=g).requires_grad_(True)
@@ -196,15 +198,57 @@ def test_cout1_conv_backward(hip):
     dy = torch.randn(out.shape, generator=g)
     out.backward(dy)
     L = hip.lib
-    dx = torch.empty((N, H, W, cin), device="cuda")
-    hip.check(L.aesr_conv2d_smallcin_fwd(hip.ptr(D(nhwc(dy))), hip.ptr(D(w.detach())), None, hip.ptr(D(nhwc(hl.detach()))),
-                                         hip.ptr(dx), N, H, W, 1, cin, 3, 1, 0, 1, 0.01, 1, 0, None, None, hip.stream()), "dgrad")
+    dx = torch.full((N, H, W, cin), float("nan"), device="cuda")
+    if cin in (4, 8, 16, 32, 64, 128, 256):
+        wsf = torch.empty(9 * cin, device="cuda")
+        hip.check(L.aesr_conv2d_cout1_dgrad(hip.ptr(D(nhwc(dy))), hip.ptr(D(w.detach())), hip.ptr(D(nhwc(hl.detach()))), hip.ptr(dx),
+                                            hip.ptr(wsf), N, H, W, cin, 1, 0.01, hip.stream()), "cout1 dgrad")
+    else:
+        hip.check(L.aesr_conv2d_smallcin_fwd(hip.ptr(D(nhwc(dy))), hip.ptr(D(w.detach())), None, hip.ptr(D(nhwc(hl.detach()))),
+                                             hip.ptr(dx), N, H, W, 1, cin, 3, 1, 0, 1, 0.01, 1, 0, None, None, hip.stream()), "dgrad")
     assert rel_l2(nchw(dx), h.grad) < 1e-5
     dw, db = torch.empty((1, cin, 3, 3), device="cuda"), torch.empty(1, device="cuda")
-    ws = torch.empty(L.aesr_small_wgrad_workspace_floats(cin * 9 + 1), device="cuda")
+    ws = torch.empty(L.aesr_conv2d_cout1_workspace_floats(cin), device="cuda")
     hip.check(L.aesr_conv2d_cout1_wgrad(hip.ptr(D(nhwc(hl.detach()))), hip.ptr(D(nhwc(dy))), hip.ptr(dw), hip.ptr(db),
                                         hip.ptr(ws), N, H, W, cin, hip.stream()), "wgrad")
     assert rel_l2(dw, w.grad) < 1e-5 and rel_l2(db, b.grad) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(3, 21, 37, 32, 32, 1), (2, 160, 160, 32, 32, 1), (2, 8, 70, 16, 64, 1), (1, 30, 30, 48, 16, 0),
+                                   (2, 5, 3, 32, 128, 2), (2, 34, 34, 8, 8, 1), (1, 20, 150, 8, 4, 1)])
+def test_stem_folded_into_first_conv(hip, shape):
+    """Conv2d(1,Cs,1,padding=p) -> Conv2d(Cs,C1,3,padding=1) -> LeakyReLU as ONE thin 1->C1 convolution
+    (networks/acai_vanilla.py:51,55-56): forward and all four parameter gradients against the unfused PyTorch chain."""
+    N, H, W, Cs, C1, p = shape
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.rand(N, 1, H, W, generator=g)
+    ws = (torch.randn(Cs, 1, 1, 1, generator=g)).requires_grad_(True)
+    bs = (torch.randn(Cs, generator=g) * 0.3).requires_grad_(True)
+    w1 = (torch.randn(C1, Cs, 3, 3, generator=g) / np.sqrt(9 * Cs)).requires_grad_(True)
+    b1 = (torch.randn(C1, generator=g) * 0.1).requires_grad_(True)
+    pre = F.conv2d(F.conv2d(x, ws, bs, padding=p), w1, b1, padding=1)
+    ref = F.leaky_relu(pre, 0.01).detach()
+    gout = torch.randn(pre.shape, generator=g)
+    pre.backward(gout)
+    L = hip.lib
+    xd = D(x.reshape(N, H, W).contiguous())
+    folded = torch.empty(L.aesr_stemconv_folded_floats(C1), device="cuda")
+    dws, dbs, dw1, db1 = D(ws.detach()), D(bs.detach()), D(w1.detach()), D(b1.detach())
+    hip.check(L.aesr_stemconv_fold(hip.ptr(dws), hip.ptr(dbs), hip.ptr(dw1), hip.ptr(folded), Cs, C1, hip.stream()), "fold")
+    Ho, Wo = H + 2 * p, W + 2 * p
+    out = torch.full((N, Ho, Wo, C1), float("nan"), device="cuda")
+    hip.check(L.aesr_stemconv_fwd(hip.ptr(xd), hip.ptr(folded), hip.ptr(db1), hip.ptr(out), N, H, W, C1, p, 1, 0.01, hip.stream()),
+              "stemconv fwd")
+    assert rel_l2(nchw(out), ref) < 1e-5
+    assert float((nchw(out).cpu() - ref.detach()).abs().max()) < 1e-4
+    gws, gbs = torch.empty(Cs, device="cuda"), torch.empty(Cs, device="cuda")
+    gw1, gb1 = torch.empty((C1, Cs, 3, 3), device="cuda"), torch.empty(C1, device="cuda")
+    wsp = torch.empty(L.aesr_stemconv_workspace_floats(C1), device="cuda")
+    hip.check(L.aesr_stemconv_wgrad(hip.ptr(xd), hip.ptr(D(nhwc(gout))), hip.ptr(dws), hip.ptr(dbs), hip.ptr(dw1), hip.ptr(gws),
+                                    hip.ptr(gbs), hip.ptr(gw1), hip.ptr(gb1), hip.ptr(wsp), N, H, W, Cs, C1, p, hip.stream()),
+              "stemconv wgrad")
+    assert rel_l2(gws, ws.grad.reshape(-1)) < 2e-5 and rel_l2(gbs, bs.grad) < 2e-5
+    assert rel_l2(gw1, w1.grad) < 2e-5 and rel_l2(gb1, b1.grad) < 2e-5
 
 
 @pytest.mark.parametrize("shape", [(2, 24, 20, 32), (1, 160, 160, 32), (3, 9, 7, 8)])
