@@ -40,6 +40,14 @@ const char* aesr_last_error_string(void);
  * transpose = 0: forward operand; 1: data-gradient operand (flipped taps, channels swapped). */
 size_t aesr_conv2d_packed_floats(int Cout, int Cin, int KS, int transpose);
 int aesr_conv2d_pack(const float* w, float* packed, int Cout, int Cin, int KS, int transpose, void* stream);
+/* The same for many filters in one launch per 32 jobs (all the layers of a network after an optimizer step).  The job
+ * array is read on the host during the call; the pointers inside travel as kernel arguments (graph-capture safe). */
+typedef struct aesr_pack_job {
+    const float* w;
+    float* packed;
+    int Cout, Cin, KS, transpose;
+} aesr_pack_job;
+int aesr_conv2d_pack_many(const aesr_pack_job* jobs_host, int njobs, void* stream);
 
 /* out = act(conv(in, w) + bias)                         [MFMA implicit GEMM; Cin % 4 == 0]
  * `packed` from aesr_conv2d_pack(transpose=0).  bias may be NULL.  Ho = H + 2*pad - KS + 1. */

@@ -18,12 +18,18 @@ IP = ctypes.POINTER(c_int)
 FP = ctypes.POINTER(c_float)
 DP = ctypes.POINTER(c_double)     # host array of doubles
 
+class PackJob(ctypes.Structure):
+    """aesr_pack_job of include/aesr_hip.h"""
+    _fields_ = [("w", c_void_p), ("packed", c_void_p), ("Cout", c_int), ("Cin", c_int), ("KS", c_int), ("transpose", c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol include/aesr_hip.h declares (checked by tests)
 SIGNATURES = {
     "aesr_version": (c_int, []),
     "aesr_last_error_string": (c_char_p, []),
     "aesr_conv2d_packed_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "aesr_conv2d_pack": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "aesr_conv2d_pack_many": (c_int, [ctypes.POINTER(PackJob), c_int, P]),
     "aesr_conv2d_fwd": (c_int, [P, P, P, P] + [c_int] * 8 + [c_float, P]),
     "aesr_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 8 + [c_float, P]),
     "aesr_conv2d_wgrad_workspace_floats": (c_size_t, [c_int] * 7),

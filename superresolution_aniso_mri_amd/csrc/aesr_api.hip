@@ -97,32 +97,45 @@ static WgradPlan plan_wgrad(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
     p.CinP = round_up(Cin, 32);
     p.CoutP = round_up(Cout, p.COT);
     const size_t max_lds = 52 * 1024;        // three workgroups per CU
+    const int nchunks = (p.CinP / 32) * (p.CoutP / p.COT);
+    const int S0 = round_up(768 / nchunks > 0 ? 768 / nchunks : 1, 8);      // multiple of 8: XCD-aware workgroup order
     double best = 1e300;
-    p.TH = 1; p.TW = 8;
+    p.TH = 1; p.TW = 8; p.S = 1;
     for (int TW = 8; TW <= 64; TW += 8) {
         if (TW - 8 >= Wo) break;
         for (int TH = 1; TH <= 32 && TH <= Ho; ++TH) {
-            const int PH = TH + KS - 1, PWS = TW + KS - 1 + ((TW + KS - 1) & 1);
+            const int PH = TH + KS - 1, PWp = TW + KS - 1, PWS = PWp + (PWp & 1);
+            // the kernel prefetches a whole tile into registers: WG_NX / WG_ND float4 slots per thread (conv_wgrad.hip)
+            if (PH * PWp * 8 > 256 * (p.variant ? 4 : 6) || TH * TW * (p.COT / 4) > 256 * (p.variant ? 5 : 6)) break;
             const size_t ldsb = ((size_t)32 * plane_stride(PH * PWS) + (size_t)p.COT * plane_stride(TH * TW)) * 4;
             if (ldsb > max_lds) break;
-            const double tiles = (double)ceil_div(Ho, TH) * ceil_div(Wo, TW);
-            const double mf = (double)(TH * TW / 8) * (2 * KS * KS * cibw + 2) * 32.0;
-            const double stage = ((double)PH * (TW + KS - 1) * 8 + (double)TH * TW * (p.COT / 4)) / 256.0 * 40.0 + 600.0;
-            const double t = tiles * (mf + stage);
-            if (t < best) { best = t; p.TH = TH; p.TW = TW; }
+            const int ntiles = N * ceil_div(Ho, TH) * ceil_div(Wo, TW);
+            const int S = S0 < ntiles ? S0 : ntiles;
+            const double rounds = (double)ceil_div(ntiles, S);
+            // three workgroups share a SIMD's matrix pipe; per tile about 4.5k cycles of LDS-write phase, barriers and
+            // address work are not hidden (fitted to the phase stamps of AESR_WGRAD_DBG on the layers of the AE)
+            const double mf = 3.0 * (TH * TW / 8) * (2 * KS * KS * cibw) * 32.0;
+            const double t = rounds * (mf + 4500.0);
+            if (t < best) { best = t; p.TH = TH; p.TW = TW; p.S = S; }
+        }
+    }
+    if (const char* e = getenv("AESR_WGRAD_TILE")) {          // experiment knob: "TH,TW"
+        int th = 0, tw = 0;
+        if (sscanf(e, "%d,%d", &th, &tw) == 2 && th > 0 && tw > 0 && tw % 8 == 0) {
+            p.TH = th < Ho ? th : Ho; p.TW = tw;
+            const int ntiles = N * ceil_div(Ho, p.TH) * ceil_div(Wo, p.TW);
+            p.S = S0 < ntiles ? S0 : ntiles;
         }
     }
     p.PWS = p.TW + KS - 1 + ((p.TW + KS - 1) & 1);
     p.TWS = p.TW;
     p.PSX = plane_stride((p.TH + KS - 1) * p.PWS);
     p.PSD = plane_stride(p.TH * p.TW);
-    const int ntiles = N * ceil_div(Ho, p.TH) * ceil_div(Wo, p.TW);
-    const int nchunks = (p.CinP / 32) * (p.CoutP / p.COT);
-    int S = 768 / nchunks;
-    if (S < 1) S = 1;
-    if (S > ntiles) S = ntiles;
-    p.S = S;
-    p.nslab = S;
+    p.nslab = p.S;
+    if (getenv("AESR_PLAN_DEBUG"))
+        fprintf(stderr, "[plan_wgrad] N=%d %dx%d %d->%d k%d: tile %dx%d S=%d tiles=%d rounds=%d lds=%zu\n", N, Ho, Wo, Cin, Cout, KS,
+                p.TH, p.TW, p.S, N * ceil_div(Ho, p.TH) * ceil_div(Wo, p.TW), ceil_div(N * ceil_div(Ho, p.TH) * ceil_div(Wo, p.TW), p.S),
+                ((size_t)32 * p.PSX + (size_t)p.COT * p.PSD) * 4);
     p.slab_floats = (size_t)p.nslab * (KS * KS + 1) * p.CinP * p.CoutP;
     g_wgrad_plans[key] = p;
     return p;
@@ -169,6 +182,34 @@ static int run_igemm(const float* in, const float* packed, const float* bias, co
     return aesr_launch_conv_igemm(a, KS, p.NB, p.MBW, st);
 }
 
+int aesr_conv2d_pack_many(const aesr_pack_job* jobs_host, int njobs, void* stream) {
+    AESR_CHECK_ARG(jobs_host && njobs > 0, "aesr_conv2d_pack_many: no jobs");
+    for (int j0 = 0; j0 < njobs; j0 += PACK_MAX_JOBS) {
+        PackTable t;
+        memset(&t, 0, sizeof(t));
+        t.njobs = njobs - j0 < PACK_MAX_JOBS ? njobs - j0 : PACK_MAX_JOBS;
+        int nb = 0;
+        for (int k = 0; k < t.njobs; ++k) {
+            const aesr_pack_job& jb = jobs_host[j0 + k];
+            AESR_CHECK_ARG(jb.w && jb.packed && jb.Cout > 0 && jb.Cin > 0 && (jb.KS == 1 || jb.KS == 3),
+                           "aesr_conv2d_pack_many: bad job %d", j0 + k);
+            int NP, NB;
+            const int kin = jb.transpose ? jb.Cout : jb.Cin, nout = jb.transpose ? jb.Cin : jb.Cout;
+            cout_padding(nout, &NP, &NB);
+            PackJob& o = t.job[k];
+            o.w = jb.w; o.p = jb.packed; o.Cout = jb.Cout; o.Cin = jb.Cin; o.KS = jb.KS; o.KinP = round_up(kin, 16); o.NoutP = NP;
+            o.TN = 16 * NB; o.transpose = jb.transpose; o.block0 = nb;
+            const size_t total = (size_t)jb.KS * jb.KS * o.KinP * NP;
+            int blocks = (int)((total + 1023) / 1024);         // 4 elements per thread
+            if (blocks > 256) blocks = 256;
+            nb += blocks;
+        }
+        t.nblocks = nb;
+        if (int e = aesr_launch_pack_many(t, (hipStream_t)stream)) return e;
+    }
+    return AESR_OK;
+}
+
 int aesr_conv2d_fwd(const float* in, const float* packed, const float* bias, float* out, int N, int H, int W, int Cin,
                     int Cout, int KS, int pad, int act, float slope, void* stream) {
     AESR_CHECK_ARG(in && packed && out && N > 0 && H > 0 && W > 0, "aesr_conv2d_fwd: null pointer or empty shape");
@@ -205,7 +246,7 @@ int aesr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, flo
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = p.CinP; a.Cout = Cout; a.CoutP = p.CoutP; a.Ho = Ho; a.Wo = Wo; a.pad = pad;
     a.TH = p.TH; a.TW = p.TW; a.tiles_y = ceil_div(Ho, p.TH); a.tiles_x = ceil_div(Wo, p.TW);
     a.ntiles = N * a.tiles_y * a.tiles_x; a.S = p.S;
-    a.PWS = p.PWS; a.TWS = p.TWS; a.PSX = p.PSX; a.PSD = p.PSD;
+    a.PWS = p.PWS; a.TWS = p.TWS; a.PSX = p.PSX; a.PSD = p.PSD; a.dbgbuf = nullptr;
     if (int e = aesr_launch_conv_wgrad(a, KS, p.variant, (hipStream_t)stream)) return e;
     return aesr_launch_wgrad_reduce(workspace, dw, db, p.nslab, KS, Cin, p.CinP, Cout, p.CoutP, (hipStream_t)stream);
 }
@@ -256,6 +297,8 @@ int aesr_conv2d_cout1_fwd(const float* x, const float* w, const float* bias, flo
                           float slope, void* stream) {
     AESR_CHECK_ARG(x && w && out && N > 0 && H > 0 && W > 0, "aesr_conv2d_cout1_fwd: null pointer or empty shape");
     AESR_CHECK_ARG(Cin > 0 && Cin % 4 == 0 && Cin <= 256, "aesr_conv2d_cout1_fwd: Cin=%d must be a multiple of 4 (<= 256)", Cin);
+    if (((Cin / 4) & (Cin / 4 - 1)) == 0)
+        return aesr_launch_thin_collapse(x, w, bias, out, N, H, W, Cin, act, slope, (hipStream_t)stream);
     Cout1FwdArgs a;
     a.x = x; a.w = w; a.bias = bias; a.out = out; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.act = act; a.slope = slope;
     a.TH = H < 16 ? H : 16; a.TW = W < 16 ? W : 16;

@@ -14,12 +14,18 @@ struct IgemmArgs {
 int aesr_launch_conv_igemm(const IgemmArgs& a, int KS, int NB, int MBW, hipStream_t st);
 int aesr_launch_pack_weights(const float* w, float* p, int Cout, int Cin, int KS, int KinP, int NoutP, int TN, int transpose, hipStream_t st);
 
+#define PACK_MAX_JOBS 32
+struct PackJob { const float* w; float* p; int Cout, Cin, KS, KinP, NoutP, TN, transpose, block0; };
+struct PackTable { int njobs, nblocks; PackJob job[PACK_MAX_JOBS]; };
+int aesr_launch_pack_many(const PackTable& t, hipStream_t st);
+
 struct WgradArgs {
     const float* x; const float* dy; float* slab;
     int N, H, W, Cin, CinP, Cout, CoutP, Ho, Wo, pad;
     int TH, TW, tiles_y, tiles_x, ntiles;
     int S;
     int PWS, TWS, PSX, PSD;   // LDS row / plane strides in floats (even; planes = 4 mod 64)
+    float* dbgbuf;            // debug phase stamps (AESR_WGRAD_DBG=1), nullptr in normal operation
 };
 int aesr_launch_conv_wgrad(const WgradArgs& a, int KS, int variant, hipStream_t st);
 int aesr_launch_wgrad_reduce(const float* slab, float* dw, float* db, int nslab, int KS, int Cin, int CinP, int Cout, int CoutP, hipStream_t st);
@@ -75,6 +81,8 @@ struct ThinArgs {
 };
 int aesr_launch_thin_expand(ThinArgs a, hipStream_t st);
 int aesr_launch_thin_reduce(ThinArgs a, int nwg, hipStream_t st);
+int aesr_launch_thin_collapse(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C, int act,
+                              float slope, hipStream_t st);
 int aesr_launch_thin_stem_fold(const float* ws, const float* bs, const float* w1, float* folded, int Cs, int C1, hipStream_t st);
 int aesr_launch_thin_stem_finish(const float* R, const float* ws, const float* bs, const float* w1, float* dws, float* dbs,
                                  float* dw1, float* db1, int Cs, int C1, hipStream_t st);

@@ -121,39 +121,40 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, BnFinArgs f)
         bn_finalize_one(f, c, g, f.train ? sums[(g * 2 + 0) * f.C + c] : 0.0, f.train ? sums[(g * 2 + 1) * f.C + c] : 0.0);
 }
 
-// column sums of partial[g][wg][2][C] for one channel column: 16 row-lanes x 4 independent accumulators, fixed order.
-// Returns the total in the rl == 0 threads.  red: [16][64] doubles.
+// column sums of partial[g][wg][2][C] for one channel column: BNR_RL row-lanes x 4 independent accumulators, fixed
+// order.  Returns the total in the rl == 0 threads.  red: [BNR_RL][BNR_COLS] doubles.
+#define BNR_COLS 16
+#define BNR_RL 64
 __device__ __forceinline__ double bn_column_total(const float* __restrict__ base, int nwg, int rowstride, bool live,
-                                                  double (*red)[64], int col, int rl) {
+                                                  double (*red)[BNR_COLS], int col, int rl) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (live) {
         int k = rl;
-        for (; k + 48 < nwg; k += 64) {
-            const float v0 = base[(size_t)k * rowstride], v1 = base[(size_t)(k + 16) * rowstride];
-            const float v2 = base[(size_t)(k + 32) * rowstride], v3 = base[(size_t)(k + 48) * rowstride];
+        for (; k + 3 * BNR_RL < nwg; k += 4 * BNR_RL) {
+            const float v0 = base[(size_t)k * rowstride], v1 = base[(size_t)(k + BNR_RL) * rowstride];
+            const float v2 = base[(size_t)(k + 2 * BNR_RL) * rowstride], v3 = base[(size_t)(k + 3 * BNR_RL) * rowstride];
             s0 += (double)v0;
             s1 += (double)v1;
             s2 += (double)v2;
             s3 += (double)v3;
         }
-        for (; k < nwg; k += 16) s0 += (double)base[(size_t)k * rowstride];
+        for (; k < nwg; k += BNR_RL) s0 += (double)base[(size_t)k * rowstride];
     }
     __syncthreads();
     red[rl][col] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    double t = 0.0;
-    if (rl == 0) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][col];
+    for (int h = BNR_RL / 2; h > 0; h >>= 1) {
+        if (rl < h) red[rl][col] += red[rl + h][col];
+        __syncthreads();
     }
-    return t;
+    return red[0][col];
 }
 
-// Statistics partials -> finalize in ONE launch (no SyncBN exchange in between).  block = 64 channels x 16 row-lanes.
+// Statistics partials -> finalize in ONE launch (no SyncBN exchange in between).  block = 16 channels x 64 row-lanes.
 __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ partial, int nwg, BnFinArgs f) {
-    __shared__ double red[16][64];
-    const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + col;
+    __shared__ double red[BNR_RL][BNR_COLS];
+    const int col = threadIdx.x % BNR_COLS, rl = threadIdx.x / BNR_COLS;
+    const int c = blockIdx.x * BNR_COLS + col;
     const bool live = c < f.C;
     if (c == 0 && rl == 0 && f.update_running && f.nbt) *f.nbt += f.G;
     for (int g = 0; g < f.G; ++g) {
@@ -264,9 +265,9 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, BnCounts
 __global__ __launch_bounds__(1024) void bn_bwd_reduce_finalize_kernel(const float* __restrict__ partial, int nwg, BnCounts counts,
                                                                       float* __restrict__ coef, float* __restrict__ dgamma,
                                                                       float* __restrict__ dbeta, int C, int G) {
-    __shared__ double red[16][64];
-    const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + col;
+    __shared__ double red[BNR_RL][BNR_COLS];
+    const int col = threadIdx.x % BNR_COLS, rl = threadIdx.x / BNR_COLS;
+    const int c = blockIdx.x * BNR_COLS + col;
     const bool live = c < C;
     double dg = 0.0, db = 0.0;
     for (int g = 0; g < G; ++g) {
@@ -363,7 +364,7 @@ int aesr_launch_bn_reduce_finalize(const float* partial, int nwg, const double* 
                                    hipStream_t st) {
     const BnFinArgs f = bn_fin_args(counts, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift, C, G, momentum,
                                     eps, 1, update_running);
-    hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, st, partial, nwg, f);
+    hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(ceil_div(C, BNR_COLS)), dim3(BNR_COLS * BNR_RL), 0, st, partial, nwg, f);
     AESR_LAUNCH_CHECK("bn_reduce_finalize");
     return AESR_OK;
 }
@@ -372,7 +373,7 @@ int aesr_launch_bn_bwd_reduce_finalize(const float* partial, int nwg, const doub
                                        float* dbeta, int C, int G, hipStream_t st) {
     BnCounts cnt;
     for (int g = 0; g < 4; ++g) cnt.c[g] = (counts && g < G) ? counts[g] : 1.0;
-    hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, st, partial, nwg, cnt, coef, dgamma,
+    hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(ceil_div(C, BNR_COLS)), dim3(BNR_COLS * BNR_RL), 0, st, partial, nwg, cnt, coef, dgamma,
                        dbeta, C, G);
     AESR_LAUNCH_CHECK("bn_bwd_reduce_finalize");
     return AESR_OK;

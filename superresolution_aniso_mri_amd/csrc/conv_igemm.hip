@@ -399,11 +399,11 @@ _Pragma("unroll")  \
 // P[ci chunk][cout tile][tap][q(4)][col(TN)][r(4)]   K-side channel kc = chunk*16 + q*4 + r, N-side channel no = tile*TN + col
 // forward : P = W[no][kc][ky][kx],                  tap = ky*KS+kx
 // dgrad   : P = W[kc][no][KS-1-ky][KS-1-kx]         (the "input channels" of the dgrad GEMM are the forward Cout)
-__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int KS,
-                                    int KinP, int NoutP, int TN, int transpose) {
+__device__ __forceinline__ void pack_elements(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int KS,
+                                              int KinP, int NoutP, int TN, int transpose, size_t first, size_t stride) {
     const size_t total = (size_t)KS * KS * KinP * NoutP;
     const int ncot = NoutP / TN, KS2 = KS * KS;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    for (size_t idx = first; idx < total; idx += stride) {
         const int r = idx & 3;
         size_t rest = idx >> 2;
         const int col = rest % TN;
@@ -426,6 +426,23 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int KS,
+                                    int KinP, int NoutP, int TN, int transpose) {
+    pack_elements(w, p, Cout, Cin, KS, KinP, NoutP, TN, transpose, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
+                  (size_t)gridDim.x * blockDim.x);
+}
+
+// many filters, one launch: the block looks its job up in the by-value table
+__global__ __launch_bounds__(256) void pack_many_kernel(PackTable t) {
+    int j = 0;
+    for (int k = 1; k < t.njobs; ++k)
+        if ((int)blockIdx.x >= t.job[k].block0) j = k;
+    const PackJob& jb = t.job[j];
+    const int b1 = (j + 1 < t.njobs) ? t.job[j + 1].block0 : t.nblocks;
+    pack_elements(jb.w, jb.p, jb.Cout, jb.Cin, jb.KS, jb.KinP, jb.NoutP, jb.TN, jb.transpose,
+                  (size_t)(blockIdx.x - jb.block0) * 256 + threadIdx.x, (size_t)(b1 - jb.block0) * 256);
+}
+
 int aesr_launch_pack_weights(const float* w, float* p, int Cout, int Cin, int KS, int KinP, int NoutP, int TN, int transpose,
                              hipStream_t st) {
     const size_t total = (size_t)KS * KS * KinP * NoutP;
@@ -433,6 +450,12 @@ int aesr_launch_pack_weights(const float* w, float* p, int Cout, int Cin, int KS
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, st, w, p, Cout, Cin, KS, KinP, NoutP, TN, transpose);
     AESR_LAUNCH_CHECK("pack_weights");
+    return AESR_OK;
+}
+
+int aesr_launch_pack_many(const PackTable& t, hipStream_t st) {
+    hipLaunchKernelGGL(pack_many_kernel, dim3(t.nblocks), dim3(256), 0, st, t);
+    AESR_LAUNCH_CHECK("pack_many");
     return AESR_OK;
 }
 

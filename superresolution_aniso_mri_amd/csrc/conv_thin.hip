@@ -184,6 +184,85 @@ __global__ __launch_bounds__(256) void thin_reduce_kernel(ThinArgs a) {
             (red[o] + red[(size_t)nout + o]) + (red[2 * (size_t)nout + o] + red[3 * (size_t)nout + o]);
 }
 
+// collapse  out[n,y,x] = act(b + sum_{t,c} w[c][t] * T[n, y+dy_t, x+dx_t, c])      (C -> 1, 3x3 pad 1; w in PyTorch [1][C][3][3] order)
+// The Cout == 1 output convolution forward (networks/acai_vanilla.py:98 + Sigmoid).  Thread = (channel quad, input column):
+// it walks the rows of its column (every element of T is loaded exactly once, 16 B per lane, plus a one-column halo per
+// tile) and produces, per output row, the three partial sums its column contributes to the outputs at x-1, x, x+1
+// (12 fma each); the C/4 quad-lanes are summed with a butterfly and the three neighbours meet through a tiny LDS
+// exchange.  Rows go in chunks of 4 so that 4 loads per lane are in flight.
+__global__ __launch_bounds__(256) void thin_collapse_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int N, int H,
+                                                            int W, int C, int TH, int tiles_y, int tiles_x, int act, float slope) {
+    __shared__ float S[2][3][4][64];         // [chunk parity][kx][row of the chunk][pixel lane]
+    const int C4 = C >> 2, TW = thin_tw(C4), TO = TW - 2;
+    const int tid = threadIdx.x, c4 = tid % C4, pl = tid / C4;
+    int tile = blockIdx.x;
+    const int tx = tile % tiles_x;
+    tile /= tiles_x;
+    const int ty = tile % tiles_y;
+    const int n = tile / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TO;
+    const int xc = x0 - 1 + pl;                          // the input column this thread owns
+    const bool live = pl < TW && xc >= 0 && xc < W;
+    f32x4 wq[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wq[t][e] = w[(c4 * 4 + e) * 9 + t];
+    const float b0 = bias ? bias[0] : 0.f;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const float* base = x + ((size_t)n * H * W + (live ? xc : 0)) * C + c4 * 4;
+    auto load1 = [&](int yy) -> f32x4 {
+        if (live && yy >= 0 && yy < H) return *(const f32x4*)(base + (size_t)yy * W * C);
+        return zero;
+    };
+    f32x4 r[6];
+    r[0] = load1(y0 - 1);
+    r[1] = load1(y0);
+    int par = 0;
+    for (int i = 0; i < TH; i += 4, par ^= 1) {
+        const int oy = y0 + i;
+        if (oy >= H) break;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[2 + k] = load1(oy + 1 + k);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float sk[3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                f32x4 acc = zero;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(wq[ky * 3 + kx][e], r[k + ky][e], acc[e]);
+                sk[kx] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            }
+            for (int m = 1; m < C4; m <<= 1) {
+                sk[0] += __shfl_xor(sk[0], m, 64);
+                sk[1] += __shfl_xor(sk[1], m, 64);
+                sk[2] += __shfl_xor(sk[2], m, 64);
+            }
+            if (c4 == 0 && pl < TW) {
+                S[par][0][k][pl] = sk[0];
+                S[par][1][k][pl] = sk[1];
+                S[par][2][k][pl] = sk[2];
+            }
+        }
+        __syncthreads();
+        for (int o = tid; o < 4 * TO; o += 256) {
+            const int k = o / TO, j = o - k * TO;
+            const int xo = x0 + j, yo = oy + k;
+            if (xo < W && yo < H && i + k < TH) {
+                // output column xo: kx = 0 comes from input column xo-1 (lane j), kx = 1 from xo (lane j+1), kx = 2 from xo+1
+                const float v = (S[par][0][k][j] + S[par][1][k][j + 1]) + S[par][2][k][j + 2];
+                out[((size_t)n * H + yo) * W + xo] = act_apply(v + b0, act, slope);
+            }
+        }
+        r[0] = r[4];
+        r[1] = r[5];
+    }
+}
+
 // ---- tiny parameter-side kernels ----------------------------------------------------------------------------------
 
 // folded[0][t][co] = sum_c W1[co,c,t]*ws[c]   folded[1][t][co] = sum_c W1[co,c,t]*bs[c]   (double accumulation)
@@ -302,6 +381,21 @@ int aesr_launch_thin_reduce(ThinArgs a, int nwg, hipStream_t st) {
     else
         hipLaunchKernelGGL(thin_reduce_kernel<false>, dim3(nwg), dim3(256), shmem, st, a);
     AESR_LAUNCH_CHECK("thin_reduce");
+    return AESR_OK;
+}
+
+int aesr_launch_thin_collapse(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C, int act,
+                              float slope, hipStream_t st) {
+    const int C4 = C / 4;
+    if (C < 4 || C % 4 != 0 || C > 256 || (C4 & (C4 - 1)) != 0) {
+        aesr_set_error("thin conv: C=%d must be 4 times a power of two (4..256)", C);
+        return AESR_ERR_ARG;
+    }
+    const int TW = thin_tw(C4), TH = H < 20 ? H : 20;
+    const int tiles_y = ceil_div(H, TH), tiles_x = ceil_div(W, TW - 2);
+    hipLaunchKernelGGL(thin_collapse_kernel, dim3(N * tiles_y * tiles_x), dim3(256), 0, st, x, w, bias, out, N, H, W, C, TH, tiles_y,
+                       tiles_x, act, slope);
+    AESR_LAUNCH_CHECK("thin_collapse");
     return AESR_OK;
 }
 

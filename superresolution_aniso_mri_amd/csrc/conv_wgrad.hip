@@ -20,30 +20,55 @@
 
 // WG covers 32 ci x (16*NWCO) co.  NWCO == 2: wave = (ci block, co block), 1 ci block per wave;
 // NWCO == 4: wave = co block, 2 ci blocks per wave.
+//
+// Pipeline per pixel tile: [write the prefetched registers to LDS] barrier [issue the global loads of the NEXT tile into
+// registers] [MFMA loop over LDS] barrier.  The loads of tile i+1 are in flight during the MFMA loop of tile i, so only the
+// LDS write phase and the two barriers are exposed.
+// Global-load lane map (chosen for the LDS side): a 32-lane group = 16 consecutive pixels x 2 adjacent channel quads, so
+// the transposing ds_write_b32 (bank = address mod 32, plane stride = 4 mod 32) hit 32 distinct banks.
+// float4 prefetch registers per thread: X patch (PP * 8 <= 256 * NX) and dY tile (TP * COT/4 <= 256 * ND); the 64-cout
+// variant carries twice the accumulators, so it gets fewer slots (tiles up to 10x8) to stay at 3 waves per SIMD
+#define WG_NX(nwco) ((nwco) == 4 ? 4 : 6)
+#define WG_ND(nwco) ((nwco) == 4 ? 5 : 6)
+
 template <int KS, int NWCO>
-__global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_wgrad_f32(WgradArgs a) {
     constexpr int CIBW = (NWCO == 2) ? 1 : 2;        // ci blocks per wave
     constexpr int CIT = 32, COT = 16 * NWCO;
+    constexpr int XPAIRS = CIT / 8, DPAIRS = COT / 8;   // channel-quad pairs per pixel
+    constexpr int NX = WG_NX(NWCO), ND = WG_ND(NWCO);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
     const int wco = (NWCO == 2) ? (wave >> 1) : wave;
     const int wci = (NWCO == 2) ? (wave & 1) : 0;
-    const int ci0 = blockIdx.y * CIT, co0 = blockIdx.z * COT;
+    // Workgroup ids are dealt round-robin to the 8 XCDs.  The nchunks workgroups that walk the SAME pixel tiles (one per
+    // (ci chunk, co chunk)) get ids that land on one XCD back to back, so that XCD's L2 serves their re-reads of X and dY.
+    const int nci = a.CinP / CIT, nchunks = nci * (a.CoutP / COT);
+    int chunk, split;
+    if ((a.S & 7) == 0) {
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        chunk = local % nchunks;
+        split = (local / nchunks) * 8 + xcd;
+    } else {
+        chunk = blockIdx.x % nchunks;
+        split = blockIdx.x / nchunks;
+    }
+    const int ciy = chunk % nci, coz = chunk / nci;
+    const int ci0 = ciy * CIT, co0 = coz * COT;
     const int PH = a.TH + KS - 1;
     const int PWS = a.PWS, TWS = a.TWS, PSX = a.PSX, PSD = a.PSD;      // row / plane strides (floats), host-chosen
     float* ldsX = lds;                      // [CIT][PSX]
     float* ldsD = lds + CIT * PSX;          // [COT][PSD]
-    const bool do_bias = (blockIdx.y == 0) && (wci == 0);
+    const bool do_bias = (ciy == 0) && (wci == 0);
 
     f32x4 acc[KS * KS][CIBW];
-    f32x4 accb = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float accb = 0.f;
 #pragma unroll
     for (int t = 0; t < KS * KS; ++t)
 #pragma unroll
         for (int i = 0; i < CIBW; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float a_one = (l15 == 0) ? 1.f : 0.f;
 
     const int tpi = a.tiles_y * a.tiles_x;
     const int PWp = a.TW + KS - 1;          // patch pixels per row actually staged
@@ -52,40 +77,87 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a) {
     const int xbase0 = ((wci * CIBW) * 16 + l15) * PSX + 2 * g;
     const int dbase = (wco * 16 + l15) * PSD + 2 * g;
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += a.S) {
+    // ---- per-thread staging slots (tile independent): slot k of this thread moves the float4 of (pixel, quad) ----
+    // unit u = (k*256 + tid) >> 5 (a 32-lane group); pair j = u % PAIRS, pixel block = u / PAIRS; pixel = block*16 + (tid & 15),
+    // quad = 2*j + ((tid >> 4) & 1)
+    int xrc[NX], drc[ND];                          // (row << 16 | col) of the slot's pixel, or -1
+    const int qbit = (tid >> 4) & 1, u0 = tid >> 5;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        const int pix = ((k * 8 + u0) / XPAIRS) * 16 + (tid & 15);
+        const int pr = pix / PWp, pc = pix - pr * PWp;
+        xrc[k] = pix < PP ? ((pr << 16) | pc) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+        const int pix = ((k * 8 + u0) / DPAIRS) * 16 + (tid & 15);
+        const int r = pix / a.TW, c = pix - r * a.TW;
+        drc[k] = pix < TP ? ((r << 16) | c) : -1;
+    }
+    f32x4 RX[NX], RD[ND];
+    auto issue_loads = [&](int tile) {
         const int n = tile / tpi;
         const int trem = tile - n * tpi;
         const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
         const int y0 = ty * a.TH, x0 = tx * a.TW;
-        // ---- stage X patch, transposing to channel-major ----
-        for (int q = tid; q < PP * (CIT / 4); q += 256) {
-            const int p = q >> 3, part = q & 7;                  // CIT/4 == 8 pieces per pixel
-            const int pr = p / PWp, pc = p - pr * PWp;
-            const int gy = y0 + pr - a.pad, gx = x0 + pc - a.pad, ci = ci0 + part * 4;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci < a.Cin)
-                v = *(const f32x4*)(a.x + (((size_t)n * a.H + gy) * a.W + gx) * a.Cin + ci);
-            float* d = ldsX + (part * 4) * PSX + pr * PWS + pc;
-            d[0] = v[0];
-            d[PSX] = v[1];
-            d[2 * PSX] = v[2];
-            d[3 * PSX] = v[3];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            RX[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int quad = 2 * ((k * 8 + u0) % XPAIRS) + qbit;
+            const int gy = y0 + (xrc[k] >> 16) - a.pad, gx = x0 + (xrc[k] & 0xffff) - a.pad, ci = ci0 + quad * 4;
+            if (xrc[k] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci < a.Cin)
+                RX[k] = *(const f32x4*)(a.x + (((size_t)n * a.H + gy) * a.W + gx) * a.Cin + ci);
         }
-        // ---- stage dY tile, transposing to channel-major ----
-        for (int q = tid; q < TP * (COT / 4); q += 256) {
-            const int p = q / (COT / 4), part = q - p * (COT / 4);
-            const int r = p / a.TW, c = p - r * a.TW;
-            const int gy = y0 + r, gx = x0 + c, co = co0 + part * 4;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (gy < a.Ho && gx < a.Wo && co < a.Cout)
-                v = *(const f32x4*)(a.dy + (((size_t)n * a.Ho + gy) * a.Wo + gx) * a.Cout + co);
-            float* d = ldsD + (part * 4) * PSD + r * TWS + c;
-            d[0] = v[0];
-            d[PSD] = v[1];
-            d[2 * PSD] = v[2];
-            d[3 * PSD] = v[3];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            RD[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int quad = 2 * ((k * 8 + u0) % DPAIRS) + qbit;
+            const int gy = y0 + (drc[k] >> 16), gx = x0 + (drc[k] & 0xffff), co = co0 + quad * 4;
+            if (drc[k] >= 0 && gy < a.Ho && gx < a.Wo && co < a.Cout)
+                RD[k] = *(const f32x4*)(a.dy + (((size_t)n * a.Ho + gy) * a.Wo + gx) * a.Cout + co);
         }
+    };
+
+    // debug stamps (wave 0 of each workgroup): cycles in [LDS write | barrier 1 | issue loads | MFMA loop | barrier 2]
+    long long st[5] = {0, 0, 0, 0, 0}, t0 = 0, t1;
+#define WG_STAMP(i)                                   \
+    if (a.dbgbuf) {                                   \
+        t1 = __builtin_amdgcn_s_memtime();            \
+        st[i] += t1 - t0;                             \
+        t0 = t1;                                      \
+    }
+    int tile = split;
+    if (tile < a.ntiles) issue_loads(tile);
+    if (a.dbgbuf) t0 = __builtin_amdgcn_s_memtime();
+    while (tile < a.ntiles) {
+        // ---- registers -> LDS, transposing to channel-major ----
+#pragma unroll
+        for (int k = 0; k < NX; ++k)
+            if (xrc[k] >= 0) {
+                const int quad = 2 * ((k * 8 + u0) % XPAIRS) + qbit;
+                float* d = ldsX + quad * 4 * PSX + (xrc[k] >> 16) * PWS + (xrc[k] & 0xffff);
+                d[0] = RX[k][0];
+                d[PSX] = RX[k][1];
+                d[2 * PSX] = RX[k][2];
+                d[3 * PSX] = RX[k][3];
+            }
+#pragma unroll
+        for (int k = 0; k < ND; ++k)
+            if (drc[k] >= 0) {
+                const int quad = 2 * ((k * 8 + u0) % DPAIRS) + qbit;
+                float* d = ldsD + quad * 4 * PSD + (drc[k] >> 16) * TWS + (drc[k] & 0xffff);
+                d[0] = RD[k][0];
+                d[PSD] = RD[k][1];
+                d[2 * PSD] = RD[k][2];
+                d[3 * PSD] = RD[k][3];
+            }
+        WG_STAMP(0)
         __syncthreads();
+        WG_STAMP(1)
+        const int next = tile + a.S;
+        if (next < a.ntiles) issue_loads(next);
+        __builtin_amdgcn_sched_barrier(0);          // keep the prefetch loads ahead of the MFMA loop
+        WG_STAMP(2)
         // ---- k loop: groups of 8 consecutive pixels of one row; lane (.,g) owns pixels c0+2g, c0+2g+1 (+ halo) ----
         for (int r = 0; r < a.TH; ++r) {
             for (int c0 = 0; c0 < a.TW; c0 += 8) {
@@ -111,17 +183,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a) {
                         for (int kx = 0; kx < KS; ++kx)
                             acc[ky * KS + kx][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[kx + 1], dv.y, acc[ky * KS + kx][i], 0, 0, 0);
                     }
-                    if (do_bias && ky == 0) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(a_one, dv.x, accb, 0, 0, 0);
-                    if (do_bias && ky == KS - 1) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(a_one, dv.y, accb, 0, 0, 0);
                 }
+                accb += dv.x + dv.y;                  // bias gradient: this lane's share of column sum co = l15 (VALU, free beside the MFMAs)
             }
         }
+        WG_STAMP(3)
         __syncthreads();
+        WG_STAMP(4)
+        tile = next;
     }
+#undef WG_STAMP
+    if (a.dbgbuf && tid == 0)
+        for (int i = 0; i < 5; ++i) a.dbgbuf[blockIdx.x * 5 + i] = (float)st[i];
 
     // ---- write the partial slab: D layout col (co) = lane&15, row (ci) = 4*(lane>>4)+j ----
     const size_t plane = (size_t)a.CinP * a.CoutP;
-    float* sl = a.slab + (size_t)blockIdx.x * (KS * KS + 1) * plane;
+    float* sl = a.slab + (size_t)split * (KS * KS + 1) * plane;
     const int co = co0 + wco * 16 + l15;
 #pragma unroll
     for (int t = 0; t < KS * KS; ++t)
@@ -132,7 +209,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a) {
                 const int ci = ci0 + (wci * CIBW + i) * 16 + g * 4 + e;
                 sl[t * plane + (size_t)ci * a.CoutP + co] = acc[t][i][e];
             }
-    if (do_bias && g == 0) sl[(KS * KS) * plane + co] = accb[0];
+    accb += __shfl_xor(accb, 16, 64);
+    accb += __shfl_xor(accb, 32, 64);
+    if (do_bias && g == 0) sl[(KS * KS) * plane + co] = accb;
 }
 
 // dW[co][ci][ky][kx] = sum_s slab[s][tap][ci][co];  db[co] = sum_s slab[s][KS*KS][0][co]
@@ -188,12 +267,31 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
         aesr_set_error("conv_wgrad: tile needs %zu B of LDS", shmem);
         return AESR_ERR_ARG;
     }
+    if ((a.TH + KS - 1) * (a.TW + KS - 1) * 8 > 256 * WG_NX(NWCO) || a.TH * a.TW * (COT / 4) > 256 * WG_ND(NWCO)) {
+        aesr_set_error("conv_wgrad: tile %dx%d does not fit the register prefetch slots", a.TH, a.TW);
+        return AESR_ERR_ARG;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_f32<KS, NWCO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    dim3 grid(a.S, a.CinP / 32, a.CoutP / COT);
+    dim3 grid(a.S * (a.CinP / 32) * (a.CoutP / COT));
+    if (getenv("AESR_WGRAD_DBG")) {           // debug: per-phase cycle stamps, printed after a host sync
+        static float* dbuf = nullptr;
+        if (!dbuf) (void)hipMalloc(&dbuf, 4096 * 5 * sizeof(float));
+        WgradArgs b = a;
+        b.dbgbuf = grid.x <= 4096 ? dbuf : nullptr;
+        hipLaunchKernelGGL((conv_wgrad_f32<KS, NWCO>), grid, dim3(256), shmem, st, b);
+        (void)hipStreamSynchronize(st);
+        static float host[4096 * 5];
+        (void)hipMemcpy(host, dbuf, grid.x * 5 * sizeof(float), hipMemcpyDeviceToHost);
+        double s5[5] = {0, 0, 0, 0, 0};
+        for (unsigned i = 0; i < grid.x; ++i) for (int k = 0; k < 5; ++k) s5[k] += host[i * 5 + k];
+        fprintf(stderr, "[wgrad stamps] grid=%u tiles=%d tile=%dx%d per-WG kcycles: lds-write %.1f | barrier1 %.1f | issue-loads %.1f | mfma %.1f | barrier2 %.1f\n",
+                grid.x, a.ntiles, a.TH, a.TW, s5[0] / grid.x / 1e3, s5[1] / grid.x / 1e3, s5[2] / grid.x / 1e3, s5[3] / grid.x / 1e3, s5[4] / grid.x / 1e3);
+        return AESR_OK;
+    }
     hipLaunchKernelGGL((conv_wgrad_f32<KS, NWCO>), grid, dim3(256), shmem, st, a);
     AESR_LAUNCH_CHECK("conv_wgrad_f32");
     return AESR_OK;

@@ -215,26 +215,38 @@ class SequentialRunner:
         self.weights_epoch += 1
 
     # ---- weight packing ------------------------------------------------------------------------------------
-    def _ensure_packed(self, s):
-        w = s.mod.weight
-        epoch = (self.weights_epoch, w._version, w.data_ptr())
-        if s.packed_epoch == epoch:
+    def _ensure_packed(self, steps):
+        """Refresh the packed MFMA operands of every convolution in ``steps`` whose filter changed since the last call
+        (after an optimizer step: all of them) with ONE aesr_conv2d_pack_many launch."""
+        stale = []
+        for s in steps:
+            if s.kind != "conv":
+                continue
+            w = s.mod.weight
+            epoch = (self.weights_epoch, w._version, w.data_ptr())
+            if s.packed_epoch != epoch:
+                stale.append((s, epoch))
+        if not stale:
             return
-        _hip.require_gpu_tensor(w, "conv weight")
-        wk = s.weight_for_kernels()
-        if s.cin % 4 == 0:
-            n = lib.aesr_conv2d_packed_floats(s.cout, s.cin, s.ks, 0)
-            if s.packed is None or s.packed.numel() != n:
-                s.packed = _empty((n,), w)
-            check(lib.aesr_conv2d_pack(ptr(wk), ptr(s.packed), s.cout, s.cin, s.ks, 0, stream()), "aesr_conv2d_pack")
-        if s.cout % 4 == 0:
-            n = lib.aesr_conv2d_packed_floats(s.cout, s.cin, s.ks, 1)
-            if s.packed_t is None or s.packed_t.numel() != n:
-                s.packed_t = _empty((n,), w)
-            check(lib.aesr_conv2d_pack(ptr(wk), ptr(s.packed_t), s.cout, s.cin, s.ks, 1, stream()), "aesr_conv2d_pack")
-        s.packed_epoch = epoch
+        jobs = []
+        for s, _ in stale:
+            _hip.require_gpu_tensor(s.mod.weight, "conv weight")
+            wk = s.weight_for_kernels()
+            for transpose, attr, ok in ((0, "packed", s.cin % 4 == 0), (1, "packed_t", s.cout % 4 == 0)):
+                if not ok:
+                    continue
+                n = lib.aesr_conv2d_packed_floats(s.cout, s.cin, s.ks, transpose)
+                buf = getattr(s, attr)
+                if buf is None or buf.numel() != n:
+                    buf = _empty((n,), wk)
+                    setattr(s, attr, buf)
+                jobs.append(_hip.PackJob(wk.data_ptr(), buf.data_ptr(), s.cout, s.cin, s.ks, transpose))
+        if jobs:
+            arr = (_hip.PackJob * len(jobs))(*jobs)
+            check(lib.aesr_conv2d_pack_many(arr, len(jobs), stream()), "aesr_conv2d_pack_many")
+        for s, epoch in stale:
+            s.packed_epoch = epoch
 
-    # ---- forward ---------------------------------------------------------------------------------------------
     def _ensure_folded(self, s):
         ws, w1 = s.stem.weight, s.mod.weight
         epoch = (self.weights_epoch, ws._version, s.stem.bias._version, w1._version, ws.data_ptr(), w1.data_ptr())
@@ -257,6 +269,7 @@ class SequentialRunner:
         saved = []
         cur = x
         steps = self.steps_fused if (fused and self.steps_fused is not None) else self.steps
+        self._ensure_packed(steps)
         for s in steps:
             if s.kind == "stemconv":
                 if C != 1:
@@ -279,7 +292,6 @@ class SequentialRunner:
                     cur, H, W, C = xs, H // 2, W // 2, 4 * C
                 if C != s.cin:
                     raise RuntimeError("channel mismatch: tensor has %d channels, conv expects %d" % (C, s.cin))
-                self._ensure_packed(s)
                 Ho, Wo = (H, W) if s.s2d else s.out_hw(H, W)
                 out = _empty((N, Ho, Wo, s.cout), x)
                 bias = s.mod.bias
