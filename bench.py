@@ -137,6 +137,16 @@ def main():
             roofline["wgrad_achieved"] = round(w["flops"] / (w["ms"] * 1e-3) / 1e12, 2)
             roofline["wgrad_ms_per_step"] = round(w["ms"] / min(opt.steps, 5), 3)
         roofline["igemm_ms_per_step"] = round(k["ms"] / max(1, min(opt.steps, 5)), 3)
+        # HBM-side bytes per launch of the same kernel: PMC counters cannot be read from inside this process; they come from the
+        # committed rocprofv3 --pmc passes of this very command (scripts/pmc_traffic.py -> profiles/), N=1 and B=12 only
+        tpath = os.path.join(ROOT, "profiles", "r01_%s_hbm_traffic.json" % opt.config)
+        if opt.gpus == 1 and B == 12 and os.path.exists(tpath):
+            tk = json.load(open(tpath))["kernels"]
+            ig = [v for name, v in tk.items() if "conv_igemm_f32" in name]
+            nl = sum(v["launches_per_step"] for v in ig)
+            if nl > 0:
+                roofline["traffic"] = round(sum(v["MB_per_step"] for v in ig) / nl * 1e6)
+                roofline["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_%s_hbm_traffic.json)" % opt.config
 
     if dp.rank != 0:
         return
