@@ -117,6 +117,17 @@ int aesr_stemconv_wgrad(const float* x, const float* g, const float* w_stem, con
 int aesr_space_to_depth2(const float* x, float* out, int N, int H, int W, int C, void* stream);
 int aesr_depth_to_space2(const float* g, float* dx, int N, int H, int W, int C, void* stream);
 
+/* ---- stand-alone x2 resampling (networks/acai_vanilla.py:59,92 without BatchNorm; networks/ae_standard.py:41,68) ---------
+ * mode: AESR_RS_POOL AvgPool2d(2) (out [N,H/2,W/2,C]); AESR_RS_NEAREST / AESR_RS_BILINEAR Upsample(scale_factor=2)
+ * (out [N,2H,2W,C]; bilinear = align_corners False).  C % 4 == 0.  H, W are the INPUT sizes of the forward op in both calls.
+ * Backward: dx[N,H,W,C] from gout, times act'(x_saved) when x_saved (= the forward input, output of that activation) is given. */
+#define AESR_RS_POOL 1
+#define AESR_RS_NEAREST 2
+#define AESR_RS_BILINEAR 3
+int aesr_resample2_fwd(const float* x, float* out, int N, int H, int W, int C, int mode, void* stream);
+int aesr_resample2_bwd(const float* gout, const float* x_saved, float* dx, int N, int H, int W, int C, int mode, int mask_act,
+                       float slope, void* stream);
+
 /* ---- BatchNorm2d (+AvgPool2d(2) / nearest Upsample x2) (networks/acai_vanilla.py:58-59,90-92) ------------ */
 #define AESR_BN_NONE 0
 #define AESR_BN_POOL 1

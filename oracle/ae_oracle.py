@@ -202,3 +202,15 @@ def acdc_args(width=128, latent_width=32, depth=32, latent=128, colors=1):
     """Architecture dict of BASELINE configs C2/C3 (train_cardiac_aesr.py:216-218 + net_config.py:19-33)."""
     return dict(width=width, latent_width=latent_width, depth=depth, latent=latent, colors=colors,
                 use_batchnorm=True, use_sigmoid=True, n_res_block=None, device="cpu")
+
+
+def ae_standard_blocks(params, x):
+    """networks/ae_standard.py:34-80 restated: BasicEncoderBlock(use_batchnorm=False, downsample=True) then BasicDecoderBlock
+    (do_upsample=True).  ``params``: {"enc.conv2d_1.weight", ..., "dec.conv2d_2.bias"}.  Returns (mid, out)."""
+    h = F.leaky_relu(F.conv2d(x, params["enc.conv2d_1.weight"], params["enc.conv2d_1.bias"], padding=1), 0.01)
+    h = F.leaky_relu(F.conv2d(h, params["enc.conv2d_2.weight"], params["enc.conv2d_2.bias"], padding=1), 0.01)
+    mid = F.avg_pool2d(h, 2)
+    h = F.leaky_relu(F.conv2d(mid, params["dec.conv2d_1.weight"], params["dec.conv2d_1.bias"], padding=1), 0.01)
+    h = F.leaky_relu(F.conv2d(h, params["dec.conv2d_2.weight"], params["dec.conv2d_2.bias"], padding=1), 0.01)
+    out = F.interpolate(h, scale_factor=2, mode="bilinear", align_corners=False)
+    return mid, out

@@ -268,10 +268,45 @@ def gen_supervolume(av):
     np.savez_compressed(os.path.join(OUT, "supervolume.npz"), **rec)
 
 
+def gen_ae_standard_blocks():
+    """networks/ae_standard.py:34-80: one BasicEncoderBlock (conv, LReLU, conv, LReLU, AvgPool2d; no BatchNorm) followed by
+    one BasicDecoderBlock (conv, LReLU, conv, LReLU, bilinear Upsample x2): forward, input gradient, parameter gradients.
+    The module imports without shims; its AE class needs a missing `networks.model_configs`, the blocks do not."""
+    import networks.ae_standard as ast
+    for tag, (N, H, W, cin, cmid) in {"a": (2, 12, 16, 8, 16), "b": (3, 10, 6, 4, 8)}.items():
+        torch.manual_seed(4242 + N)
+        enc = ast.BasicEncoderBlock(cin, cmid, kernel=3, padding=1, downsample=True, use_batchnorm=False)
+        dec = ast.BasicDecoderBlock(cmid, cin, kernel=3, padding=1, do_upsample=True)
+        for m in list(enc.modules()) + list(dec.modules()):
+            ast.weights_init(m)
+            if isinstance(m, nn.Conv2d):
+                m.bias.data.normal_(std=0.1)
+        x = torch.rand(N, cin, H, W, requires_grad=True)
+        tgt = torch.randn(N, cin, H, W)
+        mid = enc(x)
+        out = dec(mid)
+        loss = (out * tgt).mean() + 0.5 * (out ** 2).mean()
+        loss.backward()
+        rec = {"x": x.detach().numpy().copy(), "tgt": tgt.numpy().copy(), "mid": mid.detach().numpy().copy(),
+               "out": out.detach().numpy().copy(), "loss": np.float64(loss.item()), "dx": x.grad.numpy().copy()}
+        for name, mod in (("enc", enc), ("dec", dec)):
+            for k, p_ in mod.named_parameters():
+                if k.startswith("batchnorm"):
+                    continue
+                rec["p/%s.%s" % (name, k)] = p_.detach().numpy().copy()
+                rec["grad/%s.%s" % (name, k)] = p_.grad.numpy().copy()
+        np.savez_compressed(os.path.join(OUT, "ae_standard_blocks_%s.npz" % tag), **rec)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "ae_standard":
+        import_reference()
+        gen_ae_standard_blocks()
+        return
     av, avs, avm, nb = import_reference()
+    gen_ae_standard_blocks()
     gen_ae_small(av, avs, avm)
     m = gen_ae_init(av)
     gen_ae_acdc_probe(m)

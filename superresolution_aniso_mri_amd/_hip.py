@@ -49,6 +49,8 @@ SIGNATURES = {
     "aesr_stemconv_wgrad": (c_int, [P] * 10 + [c_int] * 6 + [P]),
     "aesr_space_to_depth2": (c_int, [P, P] + [c_int] * 4 + [P]),
     "aesr_depth_to_space2": (c_int, [P, P] + [c_int] * 4 + [P]),
+    "aesr_resample2_fwd": (c_int, [P, P] + [c_int] * 5 + [P]),
+    "aesr_resample2_bwd": (c_int, [P, P, P] + [c_int] * 6 + [c_float, P]),
     "aesr_bn_stats": (c_int, [P, P, P, c_int, c_int, c_int, IP, P]),
     "aesr_bn_finalize": (c_int, [P, DP] + [P] * 9 + [c_int, c_int, c_float, c_float, c_int, c_int, P]),
     "aesr_bn_stats_finalize": (c_int, [P, P, DP] + [P] * 9 + [c_int, c_int, c_int, IP, c_float, c_float, c_int, P]),
@@ -73,6 +75,7 @@ SIGNATURES = {
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 BN_NONE, BN_POOL, BN_UP = 0, 1, 2
+RS_POOL, RS_NEAREST, RS_BILINEAR = 1, 2, 3
 BN_NWG = 512
 MSE_NPART = 512
 LPIPS_NCH = 64

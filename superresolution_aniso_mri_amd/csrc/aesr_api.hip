@@ -27,12 +27,13 @@ static void cout_padding(int Cout, int* CoutP, int* NB) {
     else { *CoutP = round_up(Cout, 64); *NB = 4; }
 }
 
-struct ConvPlan { int TI, TH, TW, NB, MBW, CinP, CoutP; };
+struct ConvPlan { int TI, TH, TW, NB, MBW, CinP, CoutP, NT; };
 static std::mutex g_plan_mu;
 static std::map<std::tuple<int, int, int, int, int, int>, ConvPlan> g_conv_plans;
 
-// Pick the output tile (TI images x TH x TW) that minimises estimated MFMA time: idle M-block slots at tile
-// edges (the network's sizes are 162, 81, 40 ...) and the workgroup-count quantisation over 256 CUs.
+// Pick the workgroup shape (512 threads = one workgroup per CU, or 256 = two per CU) and the output tile (TI images x TH x
+// TW) that minimise estimated MFMA time: idle M-block slots at tile edges (the network's sizes are 162, 81, 40 ...) and the
+// work-item quantisation over the CUs.
 static ConvPlan plan_conv(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
     const auto key = std::make_tuple(N, Ho, Wo, Cin, Cout, KS);
@@ -41,40 +42,53 @@ static ConvPlan plan_conv(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
     ConvPlan p;
     cout_padding(Cout, &p.CoutP, &p.NB);
     p.CinP = round_up(Cin, 16);
-    p.MBW = (p.NB == 4) ? 2 : 4;                     // M-blocks per wave; 8 waves per workgroup
-    const int maxpix = 128 * p.MBW, maxpatch = 760;  // 760 px * 80 B = 61 KB -> two workgroups per CU
+    p.MBW = (p.NB == 4) ? 2 : 4;                     // M-blocks per wave
     const int ncout = p.CoutP / (16 * p.NB);
+    int force_nt = 0;
+    if (const char* e = getenv("AESR_IGEMM_NT")) force_nt = atoi(e);
     double best = 1e300;
-    p.TI = 1; p.TH = 1; p.TW = 1;
-    auto consider = [&](int TI, int TH, int TW) {
-        const int PP = TI * (TH + KS - 1) * (TW + KS - 1);
-        const int TP = TI * TH * TW;
-        if (TP > maxpix || PP > maxpatch) return;
-        const int nblk = ceil_div(TP, 16);
-        const long nwg = (long)ceil_div(N, TI) * ceil_div(Ho, TH) * ceil_div(Wo, TW) * ncout;
-        // per work item: per 16-channel chunk the MFMA time of a SIMD (2 waves x blocks x NB x taps x 4 k-steps x 32 cycles)
-        // plus ~4.5k cycles of staging / barrier phases in which the matrix pipe idles (measured with the phase stamps)
-        const double nch = p.CinP / 16;
-        const double per = nch * (ceil_div(nblk, 8) * 2.0 * p.NB * KS * KS * 4 * 32 + 4500.0) + 3000.0;
-        const double rounds = nwg <= 2048 ? (double)ceil_div((int)nwg, 256) : (double)nwg / 256.0;
-        const double t = per * rounds;
-        if (t < best * 0.999 || (t < best * 1.001 && TP > p.TI * p.TH * p.TW)) {
-            if (t < best) best = t;
-            p.TI = TI; p.TH = TH; p.TW = TW;
+    p.TI = 1; p.TH = 1; p.TW = 1; p.NT = 512;
+    for (int NT = 512; NT >= 256; NT -= 256) {
+        if (force_nt && NT != force_nt) continue;
+        const int NW = NT / 64, wgs_per_cu = 512 / NT;
+        const int maxpix = 16 * NW * p.MBW;
+        // LDS per workgroup: patch (80 B per pixel) + the chunk's weights + bias; 6 staging pieces of 16 B per thread
+        const int lds_budget = 160 * 1024 / wgs_per_cu - (KS * KS * 4 * 16 * p.NB * 16 + p.CoutP * 4);
+        int maxpatch = lds_budget / 80;
+        if (maxpatch > NT * 6 / 4) maxpatch = NT * 6 / 4;
+        if (NT == 512 && maxpatch > 760) maxpatch = 760;
+        auto consider = [&](int TI, int TH, int TW) {
+            const int PP = TI * (TH + KS - 1) * (TW + KS - 1);
+            const int TP = TI * TH * TW;
+            if (TP > maxpix || PP > maxpatch) return;
+            const int nblk = ceil_div(TP, 16);
+            const long nwg = (long)ceil_div(N, TI) * ceil_div(Ho, TH) * ceil_div(Wo, TW) * ncout;
+            // per CU and 16-channel chunk: the MFMA time of a SIMD (2 waves x blocks x NB x taps x 4 k-steps x 32 cycles)
+            // plus the staging / barrier phases in which the matrix pipe idles (phase stamps: ~4.5k cycles with one
+            // workgroup per CU)
+            const double nch = p.CinP / 16;
+            const double per = nch * (ceil_div(nblk, NW) * 2.0 * p.NB * KS * KS * 4 * 32 + 4500.0) + 3000.0;
+            const double slots = 256.0 * wgs_per_cu;
+            const double rounds = nwg <= 8 * slots ? (double)ceil_div((int)nwg, (int)slots) : (double)nwg / slots;
+            const double t = per * rounds;
+            if (t < best * 0.999 || (t < best * 1.001 && NT == p.NT && TP > p.TI * p.TH * p.TW)) {
+                if (t < best) best = t;
+                p.TI = TI; p.TH = TH; p.TW = TW; p.NT = NT;
+            }
+        };
+        if (Ho * Wo <= maxpix && (Ho + KS - 1) * (Wo + KS - 1) <= maxpatch) {
+            for (int TI = 1; TI <= N && TI * Ho * Wo <= maxpix; ++TI) consider(TI, Ho, Wo);
         }
-    };
-    if (Ho * Wo <= maxpix && (Ho + KS - 1) * (Wo + KS - 1) <= maxpatch) {
-        for (int TI = 1; TI <= N && TI * Ho * Wo <= maxpix; ++TI) consider(TI, Ho, Wo);
+        for (int TH = 1; TH <= Ho && TH <= 64; ++TH)
+            for (int TW = 1; TW <= Wo && TW <= 64; ++TW) consider(1, TH, TW);
     }
-    for (int TH = 1; TH <= Ho && TH <= 64; ++TH)
-        for (int TW = 1; TW <= Wo && TW <= 64; ++TW) consider(1, TH, TW);
     if (const char* e = getenv("AESR_IGEMM_TILE")) {          // experiments: force "TI,TH,TW"
         int ti, th, tw;
         if (sscanf(e, "%d,%d,%d", &ti, &th, &tw) == 3) { p.TI = ti; p.TH = th < Ho ? th : Ho; p.TW = tw < Wo ? tw : Wo; }
     }
     if (getenv("AESR_PLAN_DEBUG"))
-        fprintf(stderr, "[aesr plan] conv N=%d %dx%d Cin=%d Cout=%d KS=%d -> TI=%d TH=%d TW=%d NB=%d nblk=%d items=%ld\n", N, Ho, Wo, Cin,
-                Cout, KS, p.TI, p.TH, p.TW, p.NB, ceil_div(p.TI * p.TH * p.TW, 16),
+        fprintf(stderr, "[aesr plan] conv N=%d %dx%d Cin=%d Cout=%d KS=%d -> NT=%d TI=%d TH=%d TW=%d NB=%d nblk=%d items=%ld\n", N, Ho, Wo,
+                Cin, Cout, KS, p.NT, p.TI, p.TH, p.TW, p.NB, ceil_div(p.TI * p.TH * p.TW, 16),
                 (long)ceil_div(N, p.TI) * ceil_div(Ho, p.TH) * ceil_div(Wo, p.TW) * ncout);
     g_conv_plans[key] = p;
     return p;
@@ -178,7 +192,7 @@ static int run_igemm(const float* in, const float* packed, const float* bias, co
     a.in = in; a.wpk = packed; a.bias = bias; a.ysave = ysave; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = p.CinP; a.Cout = Cout; a.CoutP = p.CoutP; a.Ho = Ho; a.Wo = Wo; a.pad = pad;
     a.TI = p.TI; a.TH = p.TH; a.TW = p.TW; a.tiles_y = ceil_div(Ho, p.TH); a.tiles_x = ceil_div(Wo, p.TW);
-    a.act = act; a.mask_act = mask_act; a.slope = slope; a.dbgbuf = nullptr;
+    a.act = act; a.mask_act = mask_act; a.slope = slope; a.dbgbuf = nullptr; a.NT = p.NT;
     return aesr_launch_conv_igemm(a, KS, p.NB, p.MBW, st);
 }
 
@@ -391,6 +405,22 @@ int aesr_stemconv_wgrad(const float* x, const float* g, const float* w_stem, con
     if (int e = aesr_launch_thin_reduce(a, THIN_NWG, (hipStream_t)stream)) return e;
     if (int e = aesr_launch_sum_partials(workspace, THIN_NWG, 19 * C1, R, 19 * C1, nullptr, (hipStream_t)stream)) return e;
     return aesr_launch_thin_stem_finish(R, w_stem, b_stem, w1, dw_stem, db_stem, dw1, db1, Cs, C1, (hipStream_t)stream);
+}
+
+int aesr_resample2_fwd(const float* x, float* out, int N, int H, int W, int C, int mode, void* stream) {
+    AESR_CHECK_ARG(x && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "aesr_resample2_fwd: bad arguments (C %% 4 == 0)");
+    AESR_CHECK_ARG(mode >= AESR_RS_POOL && mode <= AESR_RS_BILINEAR, "aesr_resample2_fwd: unknown mode %d", mode);
+    AESR_CHECK_ARG(mode != AESR_RS_POOL || (H >= 2 && W >= 2), "aesr_resample2_fwd: pooling needs H, W >= 2");
+    return aesr_launch_resample2(x, nullptr, nullptr, out, N, H, W, C, mode, 0, ACT_NONE, 0.f, (hipStream_t)stream);
+}
+
+int aesr_resample2_bwd(const float* gout, const float* x_saved, float* dx, int N, int H, int W, int C, int mode, int mask_act,
+                       float slope, void* stream) {
+    AESR_CHECK_ARG(gout && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "aesr_resample2_bwd: bad arguments (C %% 4 == 0)");
+    AESR_CHECK_ARG(mode >= AESR_RS_POOL && mode <= AESR_RS_BILINEAR, "aesr_resample2_bwd: unknown mode %d", mode);
+    AESR_CHECK_ARG(mode != AESR_RS_POOL || (H >= 2 && W >= 2), "aesr_resample2_bwd: pooling needs H, W >= 2");
+    return aesr_launch_resample2(nullptr, gout, x_saved, dx, N, H, W, C, mode, 1, x_saved ? mask_act : ACT_NONE, slope,
+                                 (hipStream_t)stream);
 }
 
 int aesr_bn_stats(const float* y, float* partial, double* sums, int HW, int C, int G, const int* nstart_host, void* stream) {

@@ -7,6 +7,7 @@ struct IgemmArgs {
     const float* in; const float* wpk; const float* bias; const float* ysave; float* out;
     int N, H, W, Cin, CinP, Cout, CoutP, Ho, Wo, pad;
     int TI, TH, TW, tiles_y, tiles_x, nitems, dbg;
+    int NT;          // threads per workgroup: 512 or 256
     float* dbgbuf;   // debug stamps (nullptr in normal operation)
     int act, mask_act;
     float slope;
@@ -133,4 +134,6 @@ int aesr_launch_lpips_tap_fwd(const float* f, const float* lin, float* partial, 
 int aesr_launch_lpips_tap_bwd(const float* f, const float* lin, const float* gd, float* gf0, int B, int HW, int C, hipStream_t st);
 int aesr_launch_lpips_finalize(const float* const* partials, const int* hw, int ntaps, float* d, int B, hipStream_t st);
 int aesr_launch_scale_expand(const float* x, float* out4, int n, const float* ca, const float* cb, int backward, hipStream_t st);
+int aesr_launch_resample2(const float* x, const float* gout, const float* xsave, float* dst, int N, int H, int W, int C, int mode,
+                          int backward, int mask_act, float slope, hipStream_t st);
 int aesr_launch_s2d(const float* x, float* out, int N, int H, int W, int C, int inverse, hipStream_t st);

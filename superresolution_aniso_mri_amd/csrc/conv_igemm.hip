@@ -29,8 +29,8 @@
 
 
 constexpr int IG_S = 20;     // LDS floats per patch pixel: 16 channels + 4 pad (80 B keeps b128 alignment)
-constexpr int IG_NT = 512;   // threads per workgroup: 8 waves = 2 per SIMD from ONE workgroup (they fill each other's issue gaps)
-constexpr int IG_NW = IG_NT / 64;
+// threads per workgroup (template parameter NT): 512 = 8 waves, ONE workgroup per CU; 256 = 4 waves, TWO workgroups per CU
+// that run out of phase (one's staging/barrier phases under the other's MFMAs) and give small layers twice the work items
 constexpr int IG_MAXP = 6;   // staging pieces (16 B) per thread: patch pixels * 4 <= IG_NT * IG_MAXP
 
 // Persistent workgroups: each walks work items (spatial tile x cout tile) item, item+G, ...  The pixel->LDS maps are
@@ -39,8 +39,9 @@ constexpr int IG_MAXP = 6;   // staging pieces (16 B) per thread: patch pixels *
 // so HBM/L2 latency of the patch hides behind ~18k cycles of matrix work; weight fragments are prefetched one tap ahead.
 // MFMA operand roles: A = weights (M = 16 couts), B = activations (N = 16 pixels): a lane's 4 accumulator registers are
 // 4 CONSECUTIVE couts of one pixel -> bias/activation/mask/store of the epilogue are 16-byte wide.
-template <int KS, int NB, int MBW>
-__global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
+template <int KS, int NB, int MBW, int NT>
+__global__ __launch_bounds__(NT, 2) void conv_igemm_f32(IgemmArgs a) {
+    constexpr int NW = NT / 64;                 // waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU, out of phase)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
     const int tid = threadIdx.x, lane = tid & 63;
@@ -56,16 +57,16 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
     const int nchunks = a.CinP >> 4;
     constexpr int TN = 16 * NB;
     constexpr int NWP = KS * KS * 4 * TN;                 // 16-byte weight pieces per (chunk, cout tile)
-    constexpr int WP = (NWP + IG_NT - 1) / IG_NT;         // ... per thread
+    constexpr int WP = (NWP + NT - 1) / NT;         // ... per thread
     float* ldsW = lds + PP * IG_S;                        // [tap][ci/4][TN][4]
     float* ldsBias = ldsW + NWP * 4;                       // [CoutP] (zeros when there is no bias)
-    for (int c = tid; c < a.CoutP; c += IG_NT) ldsBias[c] = (a.bias && c < a.Cout) ? a.bias[c] : 0.f;
+    for (int c = tid; c < a.CoutP; c += NT) ldsBias[c] = (a.bias && c < a.Cout) ? a.bias[c] : 0.f;
 
     // ---- position-independent maps (computed once) ------------------------------------------------------------
     int a_off[MBW], pix[MBW];                 // pix = img<<20 | r<<10 | c of this lane's pixel of block i, or -1
 #pragma unroll
     for (int i = 0; i < MBW; ++i) {
-        const int t = (wave + IG_NW * i) * 16 + l15;
+        const int t = (wave + NW * i) * 16 + l15;
         const bool valid = t < TP;
         const int tt = valid ? t : 0;
         const int img = tt / TPI;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
     int piece[IG_MAXP];                        // img<<20 | pr<<10 | pc of the patch pixel of staging piece j, or -1
 #pragma unroll
     for (int j = 0; j < IG_MAXP; ++j) {
-        const int q = tid + IG_NT * j;
+        const int q = tid + NT * j;
         int v = -1;
         if (q < PP * 4) {
             const int p = q >> 2;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(IG_NT, 2) void conv_igemm_f32(IgemmArgs a) {
     {                                                                                                       \
         const float* wsrc_ = a.wpk + ((size_t)(cc) * ncot + ((item) % ncot)) * (NWP * 4);                   \
         _Pragma("unroll") for (int j = 0; j < WP; ++j) {                                                    \
-            const int w_ = tid + IG_NT * j;                                                                 \
+            const int w_ = tid + NT * j;                                                                 \
             RW[j] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                            \
             if (w_ < NWP && !(a.dbg & 2)) RW[j] = *(const f32x4*)(wsrc_ + w_ * 4);                          \
         }                                                                                                   \
@@ -224,10 +225,10 @@ _Pragma("unroll")  \
         IG_STAMP(0)
 #pragma unroll
         for (int j = 0; j < IG_MAXP; ++j)
-            if (piece[j] >= 0) *(f32x4*)(lds + ((tid + IG_NT * j) >> 2) * IG_S + part4) = R[j];
+            if (piece[j] >= 0) *(f32x4*)(lds + ((tid + NT * j) >> 2) * IG_S + part4) = R[j];
 #pragma unroll
         for (int j = 0; j < WP; ++j)
-            if (tid + IG_NT * j < NWP) *(f32x4*)(ldsW + (tid + IG_NT * j) * 4) = RW[j];
+            if (tid + NT * j < NWP) *(f32x4*)(ldsW + (tid + NT * j) * 4) = RW[j];
         IG_STAMP(1)
         __syncthreads();
         IG_STAMP(2)
@@ -285,7 +286,7 @@ _Pragma("unroll")  \
                                 R[pj < IG_MAXP ? pj : 0] = *(const f32x4*)(a.in + goff[pj < IG_MAXP ? pj : 0] + l_cc * 16);
                         } else if (pj - IG_MAXP < WP) {
                             const int wj = pj - IG_MAXP < WP ? pj - IG_MAXP : 0;
-                            const int w_ = tid + IG_NT * wj;
+                            const int w_ = tid + NT * wj;
                             RW[wj] = (f32x4){0.f, 0.f, 0.f, 0.f};
                             if (w_ < NWP && !(a.dbg & 2)) RW[wj] = *(const f32x4*)(wsrc + w_ * 4);
                         }
@@ -459,20 +460,20 @@ int aesr_launch_pack_many(const PackTable& t, hipStream_t st) {
     return AESR_OK;
 }
 
-template <int KS, int NB, int MBW>
+template <int KS, int NB, int MBW, int NT>
 static int launch_one(const IgemmArgs& a, hipStream_t st) {
     const int PP = a.TI * (a.TH + KS - 1) * (a.TW + KS - 1);
     const size_t shmem = ((size_t)PP * IG_S + (size_t)KS * KS * 4 * 16 * NB * 4 + a.CoutP) * sizeof(float);
-    if (shmem > 160 * 1024) {
+    if (shmem > (size_t)160 * 1024 / (512 / NT)) {
         aesr_set_error("conv_igemm: tile needs %zu B of LDS", shmem);
         return AESR_ERR_ARG;
     }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_f32<KS, NB, MBW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_f32<KS, NB, MBW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    int grid = 256;                           // persistent: one 8-wave workgroup per CU (register budget allows one)
+    int grid = 256 * (512 / NT);              // persistent: 2 waves per SIMD (register budget), as one 8-wave or two 4-wave workgroups per CU
     if (const char* e = getenv("AESR_IGEMM_GRID")) grid = atoi(e);
     if (grid > a.nitems) grid = a.nitems;
     if (a.dbg & 8) {                          // debug: per-phase cycle stamps, printed after a host sync
@@ -480,7 +481,7 @@ static int launch_one(const IgemmArgs& a, hipStream_t st) {
         if (!dbuf) (void)hipMalloc(&dbuf, 1024 * 7 * sizeof(float));
         IgemmArgs b = a;
         b.dbgbuf = dbuf;
-        hipLaunchKernelGGL((conv_igemm_f32<KS, NB, MBW>), dim3(grid), dim3(IG_NT), shmem, st, b);
+        hipLaunchKernelGGL((conv_igemm_f32<KS, NB, MBW, NT>), dim3(grid), dim3(NT), shmem, st, b);
         (void)hipStreamSynchronize(st);
         static float host[1024 * 7];
         (void)hipMemcpy(host, dbuf, grid * 7 * sizeof(float), hipMemcpyDeviceToHost);
@@ -491,7 +492,7 @@ static int launch_one(const IgemmArgs& a, hipStream_t st) {
                 s5[5] / grid / 1e3, s5[6] / grid / 1e3);
         return AESR_OK;
     }
-    hipLaunchKernelGGL((conv_igemm_f32<KS, NB, MBW>), dim3(grid), dim3(IG_NT), shmem, st, a);
+    hipLaunchKernelGGL((conv_igemm_f32<KS, NB, MBW, NT>), dim3(grid), dim3(NT), shmem, st, a);
     AESR_LAUNCH_CHECK("conv_igemm_f32");
     return AESR_OK;
 }
@@ -503,17 +504,18 @@ int aesr_launch_conv_igemm(const IgemmArgs& a_in, int KS, int NB, int MBW, hipSt
     a.dbg = dbg;
     const int TP = a.TI * a.TH * a.TW;
     const int nblk = (TP + 15) / 16;
-    if (nblk > IG_NW * MBW) {
-        aesr_set_error("conv_igemm: tile of %d pixels needs %d M-blocks > %d", TP, nblk, IG_NW * MBW);
+    const int NT = a.NT == 256 ? 256 : 512, NW = NT / 64;
+    if (nblk > NW * MBW) {
+        aesr_set_error("conv_igemm: tile of %d pixels needs %d M-blocks > %d", TP, nblk, NW * MBW);
         return AESR_ERR_ARG;
     }
-    MBW = (nblk + IG_NW - 1) / IG_NW;          // exact blocks per wave: the inner loop has no runtime block bound
+    MBW = (nblk + NW - 1) / NW;                // exact blocks per wave: the inner loop has no runtime block bound
     if (a.CoutP % (16 * NB) != 0 || a.CinP % 16 != 0 || a.Cin % 4 != 0) {
         aesr_set_error("conv_igemm: bad channel padding Cin=%d CinP=%d CoutP=%d NB=%d", a.Cin, a.CinP, a.CoutP, NB);
         return AESR_ERR_ARG;
     }
     const int PPc = a.TI * (a.TH + KS - 1) * (a.TW + KS - 1);
-    if (PPc * 4 > IG_NT * IG_MAXP) {
+    if (PPc * 4 > NT * IG_MAXP) {
         aesr_set_error("conv_igemm: patch of %d pixels exceeds the staging capacity", PPc);
         return AESR_ERR_ARG;
     }
@@ -526,8 +528,9 @@ int aesr_launch_conv_igemm(const IgemmArgs& a_in, int KS, int NB, int MBW, hipSt
         aesr_set_error("conv_igemm: tile dimensions exceed the packed-coordinate range");
         return AESR_ERR_ARG;
     }
-#define IG_CASE(ks, nb, mbw) \
-    if (KS == ks && NB == nb && MBW == mbw) return launch_one<ks, nb, mbw>(a, st);
+#define IG_CASE(ks, nb, mbw)                                                          \
+    if (KS == ks && NB == nb && MBW == mbw)                                           \
+        return NT == 256 ? launch_one<ks, nb, mbw, 256>(a, st) : launch_one<ks, nb, mbw, 512>(a, st);
     IG_CASE(3, 1, 1) IG_CASE(3, 1, 2) IG_CASE(3, 1, 3) IG_CASE(3, 1, 4) IG_CASE(3, 2, 1) IG_CASE(3, 2, 2) IG_CASE(3, 2, 3) IG_CASE(3, 2, 4)
     IG_CASE(3, 4, 1) IG_CASE(3, 4, 2)
     IG_CASE(1, 1, 1) IG_CASE(1, 1, 2) IG_CASE(1, 1, 3) IG_CASE(1, 1, 4) IG_CASE(1, 2, 1) IG_CASE(1, 2, 2) IG_CASE(1, 2, 3) IG_CASE(1, 2, 4)

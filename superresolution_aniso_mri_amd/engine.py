@@ -165,6 +165,37 @@ class BnStep:
         return h, w
 
 
+class ResampleStep:
+    """Stand-alone AvgPool2d(2) / Upsample(x2, nearest | bilinear): not behind a BatchNorm (use_batchnorm=False stacks), or
+    the bilinear form of networks/ae_standard.py:68 which the BatchNorm kernels do not fuse."""
+    kind = "resample"
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def out_hw(self, h, w):
+        return (h // 2, w // 2) if self.mode == _hip.RS_POOL else (2 * h, 2 * w)
+
+
+def _resample_of(m):
+    if isinstance(m, nn.AvgPool2d):
+        ks = m.kernel_size if isinstance(m.kernel_size, tuple) else (m.kernel_size, m.kernel_size)
+        st = m.stride if isinstance(m.stride, tuple) else (m.stride, m.stride)
+        if ks != (2, 2) or st != (2, 2) or m.padding not in (0, (0, 0)):
+            raise NotImplementedError("only AvgPool2d(2) is lowered (got %r)" % (m,))
+        return ResampleStep(_hip.RS_POOL)
+    if isinstance(m, nn.Upsample):
+        sf = m.scale_factor
+        if sf not in (2, 2.0, (2, 2), (2.0, 2.0)):
+            raise NotImplementedError("only Upsample(scale_factor=2) is lowered (got %r)" % (m,))
+        if m.mode == "nearest":
+            return ResampleStep(_hip.RS_NEAREST)
+        if m.mode == "bilinear" and not m.align_corners:
+            return ResampleStep(_hip.RS_BILINEAR)
+        raise NotImplementedError("Upsample mode %s (align_corners=%s) has no HIP lowering" % (m.mode, m.align_corners))
+    return None
+
+
 def compile_steps(seq):
     mods = list(seq)
     steps, i = [], 0
@@ -181,12 +212,13 @@ def compile_steps(seq):
             if i + 1 < len(mods) and isinstance(mods[i + 1], nn.AvgPool2d):
                 mode = _hip.BN_POOL
                 i += 1
-            elif i + 1 < len(mods) and isinstance(mods[i + 1], nn.Upsample):
-                if mods[i + 1].mode != "nearest":
-                    raise NotImplementedError("only nearest Upsample is fused (got %s)" % mods[i + 1].mode)
+            elif i + 1 < len(mods) and isinstance(mods[i + 1], nn.Upsample) and mods[i + 1].mode == "nearest":
+                _resample_of(mods[i + 1])         # validates the scale factor
                 mode = _hip.BN_UP
                 i += 1
             steps.append(BnStep(m, mode))
+        elif _resample_of(m) is not None:
+            steps.append(_resample_of(m))
         else:
             raise NotImplementedError("no HIP lowering for %r at position %d (use_batchnorm=False stacks are not "
                                       "covered)" % (m, i))
@@ -194,6 +226,8 @@ def compile_steps(seq):
     for k, s in enumerate(steps):
         if s.kind == "bn" and (k == 0 or steps[k - 1].kind != "conv"):
             raise NotImplementedError("BatchNorm must follow a convolution")
+        if s.kind == "resample" and (k == 0 or steps[k - 1].kind not in ("conv", "bn", "stemconv")):
+            raise NotImplementedError("a pooling / upsampling step must follow a convolution or a BatchNorm")
     return steps
 
 
@@ -312,6 +346,15 @@ class SequentialRunner:
                 if save:
                     saved.append((cur, out, full_hw) if s.s2d else (cur, out))
                 cur, H, W, C = out, Ho, Wo, s.cout
+            elif s.kind == "resample":
+                if C % 4 != 0:
+                    raise NotImplementedError("stand-alone pooling / upsampling of %d channels (needs a multiple of 4)" % C)
+                Ho, Wo = s.out_hw(H, W)
+                out = _empty((N, Ho, Wo, C), x)
+                check(lib.aesr_resample2_fwd(ptr(cur), ptr(out), N, H, W, C, s.mode, stream()), "aesr_resample2_fwd")
+                if save:
+                    saved.append((cur,))
+                cur, H, W = out, Ho, Wo
             else:
                 bn = s.mod
                 st = self._bn_forward_stats(bn, cur, N, H, W, C, nstart, train)
@@ -468,6 +511,15 @@ class SequentialRunner:
                     dfull = _empty((N, fh, fw, s.cin_full), g)
                     check(lib.aesr_depth_to_space2(ptr(dx), ptr(dfull), N, fh, fw, s.cin_full, stream()), "aesr_depth_to_space2")
                     dx = dfull
+                g = dx
+            elif s.kind == "resample":
+                xin = saved[k][0]
+                _, H, W, C = xin.shape
+                prev = steps[k - 1]
+                mask_act, mslope = (prev.act, prev.slope) if prev.kind in ("conv", "stemconv") else (_hip.ACT_NONE, 0.0)
+                dx = _empty((ngrad, H, W, C), g)
+                check(lib.aesr_resample2_bwd(ptr(g), ptr(xin) if mask_act != _hip.ACT_NONE else None, ptr(dx), ngrad, H, W, C,
+                                             s.mode, mask_act, mslope, stream()), "aesr_resample2_bwd")
                 g = dx
             else:
                 y, st = saved[k]

@@ -54,8 +54,9 @@ def Encoder(scales, depth, latent, colors, n_res_block=None, use_batchnorm=False
 
 
 def Decoder(scales, depth, latent, colors, n_res_block=None, use_upsample=True, use_batchnorm=False, use_sigmoid=False,
-            stem_1x1=False):
-    """networks/acai_vanilla.py:75-102 (``stem_1x1``: the LargerAE 1x1 conv (+BN) in front)."""
+            stem_1x1=False, upsample_mode="nearest"):
+    """networks/acai_vanilla.py:75-102 (``stem_1x1``: the LargerAE 1x1 conv (+BN) in front; ``upsample_mode="bilinear"``:
+    the align_corners=False bilinear x2 upsample of networks/ae_standard.py:68 instead of nearest)."""
     if n_res_block is not None or not use_upsample:
         raise NotImplementedError("ResBlock / ConvTranspose decoders are not part of the ae_combined path")
     layers, kp = [], latent
@@ -68,7 +69,8 @@ def Decoder(scales, depth, latent, colors, n_res_block=None, use_upsample=True, 
     for scale in range(scales - 1, -1, -1):
         k = depth << scale
         layers += _block(kp, k, use_batchnorm)
-        layers.append(nn.Upsample(scale_factor=2))
+        layers.append(nn.Upsample(scale_factor=2) if upsample_mode == "nearest" else
+                      nn.Upsample(scale_factor=2, mode=upsample_mode, align_corners=False))
         kp = k
     layers += [nn.Conv2d(kp, depth, 3, padding=1), activation()]
     layers.append(nn.Conv2d(depth, colors, 3, padding=1))
@@ -157,7 +159,8 @@ class VanillaACAI(HipAE):
         self.enc = Encoder(scales, args["depth"], args["latent"], args["colors"], n_res_block=args["n_res_block"],
                            use_batchnorm=args["use_batchnorm"]).to(args["device"])
         self.dec = Decoder(scales, args["depth"], args["latent"], args["colors"], n_res_block=args["n_res_block"],
-                           use_batchnorm=args["use_batchnorm"], use_sigmoid=args["use_sigmoid"]).to(args["device"])
+                           use_batchnorm=args["use_batchnorm"], use_sigmoid=args["use_sigmoid"],
+                           upsample_mode=args.get("upsample_mode", "nearest")).to(args["device"])
 
 
 def create_decoder(args):

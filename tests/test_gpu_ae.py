@@ -157,6 +157,88 @@ def test_stem_folded_pass_equals_unfolded_pass(cname, args):
         assert rel_l2(r1[k], r0[k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_ae_standard_blocks_vs_reference_vectors(tag):
+    """networks/ae_standard.py:34-80 (conv, LReLU, conv, LReLU, AvgPool2d | conv, LReLU, conv, LReLU, bilinear x2) on the HIP
+    engine against vectors from the reference's own block modules: forward 1e-5, gradients 1e-4."""
+    import torch.nn as nn
+    from superresolution_aniso_mri_amd import engine
+    rec = dict(np.load(os.path.join(GOLDEN, "ae_standard_blocks_%s.npz" % tag)))
+    cin, cmid = rec["x"].shape[1], rec["p/enc.conv2d_2.weight"].shape[0]
+    seq = nn.Sequential(nn.Conv2d(cin, cin, 3, padding=1), nn.LeakyReLU(), nn.Conv2d(cin, cmid, 3, padding=1), nn.LeakyReLU(),
+                        nn.AvgPool2d(2),
+                        nn.Conv2d(cmid, cmid, 3, padding=1), nn.LeakyReLU(), nn.Conv2d(cmid, cin, 3, padding=1), nn.LeakyReLU(),
+                        nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False)).cuda()
+    names = {"enc.conv2d_1": 0, "enc.conv2d_2": 2, "dec.conv2d_1": 5, "dec.conv2d_2": 7}
+    with torch.no_grad():
+        for k, i in names.items():
+            seq[i].weight.copy_(torch.from_numpy(rec["p/%s.weight" % k]))
+            seq[i].bias.copy_(torch.from_numpy(rec["p/%s.bias" % k]))
+    runner = engine.SequentialRunner(seq)
+    assert [s.kind for s in runner.steps] == ["conv", "conv", "resample", "conv", "conv", "resample"]
+    x = torch.from_numpy(rec["x"]).cuda().requires_grad_(True)
+    out = engine.run_pass(runner, engine.to_nhwc(x), train=True).permute(0, 3, 1, 2)
+    tgt = torch.from_numpy(rec["tgt"]).cuda()
+    loss = (out * tgt).mean() + 0.5 * (out ** 2).mean()
+    loss.backward()
+    assert rel_l2(out.detach(), rec["out"]) < 1e-5
+    assert abs(loss.item() - float(rec["loss"])) < 1e-5 * max(1.0, abs(float(rec["loss"])))
+    assert rel_l2(x.grad, rec["dx"]) < 1e-4
+    for k, i in names.items():
+        assert rel_l2(seq[i].weight.grad, rec["grad/%s.weight" % k]) < 1e-4, k
+        assert rel_l2(seq[i].bias.grad, rec["grad/%s.bias" % k]) < 1e-4, k
+
+
+def test_ae_standard_block_modules_match_flat_pass():
+    """The BasicEncoderBlock / BasicDecoderBlock modules (reference constructor signature and parameter names) give the
+    golden output of the reference blocks, called one by one and chained in a BlockStack."""
+    from networks.ae_standard import BasicDecoderBlock, BasicEncoderBlock, BlockStack
+    rec = dict(np.load(os.path.join(GOLDEN, "ae_standard_blocks_a.npz")))
+    cin, cmid = rec["x"].shape[1], rec["p/enc.conv2d_2.weight"].shape[0]
+    enc = BasicEncoderBlock(cin, cmid, kernel=3, padding=1, downsample=True, use_batchnorm=False).cuda()
+    dec = BasicDecoderBlock(cmid, cin, kernel=3, padding=1, do_upsample=True).cuda()
+    enc.load_state_dict({k[len("p/enc."):]: torch.from_numpy(v) for k, v in rec.items() if k.startswith("p/enc.")}, strict=False)
+    dec.load_state_dict({k[len("p/dec."):]: torch.from_numpy(v) for k, v in rec.items() if k.startswith("p/dec.")}, strict=False)
+    x = torch.from_numpy(rec["x"]).cuda()
+    mid = enc(x)
+    out = dec(mid)
+    assert rel_l2(mid.detach(), rec["mid"]) < 1e-5 and rel_l2(out.detach(), rec["out"]) < 1e-5
+    stack = BlockStack(enc, dec)
+    out2 = stack(x)
+    assert rel_l2(out2.detach(), rec["out"]) < 1e-5
+    (out2 * torch.from_numpy(rec["tgt"]).cuda()).mean().add(0.5 * (out2 ** 2).mean()).backward()
+    assert rel_l2(enc.conv2d_1.weight.grad, rec["grad/enc.conv2d_1.weight"]) < 1e-4
+    assert rel_l2(dec.conv2d_2.bias.grad, rec["grad/dec.conv2d_2.bias"]) < 1e-4
+
+
+def test_bilinear_decoder_vs_oracle():
+    """VanillaACAI with the bilinear x2 upsample of networks/ae_standard.py:68 in the decoder (BatchNorm, then a stand-alone
+    bilinear step) against the CPU oracle: forward, gradients, running statistics."""
+    from oracle import ae_oracle
+    torch.manual_seed(3)
+    args = dict(SMALL, upsample_mode="bilinear")
+    model = _model("VanillaACAI", args)
+    kinds = [s.kind for s in model._runner("dec").steps]
+    assert kinds.count("resample") == 2
+    oracle = ae_oracle.OracleAE(SMALL, upsample_mode="bilinear", init=False).load_state_dict(
+        {k: v.cpu() for k, v in model.state_dict().items()})
+    x = torch.rand(4, 1, 32, 32)
+    model.train()
+    z = model.encode(x.cuda())
+    out = model.decode(z)
+    zo = oracle.encode(x, train=True)
+    oo = oracle.decode(zo, train=True)
+    assert rel_l2(out.detach(), oo.detach()) < 1e-5
+    ((out - 0.3) ** 2).mean().backward()
+    ((oo - 0.3) ** 2).mean().backward()
+    for k, p in model.named_parameters():
+        assert rel_l2(p.grad, oracle.params[k].grad) < 1e-4, k
+    sd = model.state_dict()
+    for k, v in oracle.buffers.items():
+        if "running" in k:
+            assert rel_l2(sd[k], v) < 1e-5, k
+
+
 def test_cpu_tensor_is_refused_loudly():
     model = _model("VanillaACAI", SMALL)
     with pytest.raises(RuntimeError, match="no CPU fallback"):

@@ -265,6 +265,37 @@ def test_cout1_conv_forward_sigmoid(hip, shape):
     assert rel_l2(nchw(out), ref) < 1e-6
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("shape", [(2, 12, 16, 8), (3, 7, 5, 4), (1, 40, 40, 64), (2, 1, 1, 16), (2, 2, 3, 8)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_resample2_fwd_bwd(hip, mode, shape, masked):
+    """Stand-alone AvgPool2d(2) / nearest x2 / bilinear x2 (align_corners=False, networks/ae_standard.py:68), forward and
+    backward (optionally fused with the LeakyReLU derivative of the producer) against ATen on the CPU."""
+    N, H, W, C = shape
+    if mode == 1 and (H < 2 or W < 2):
+        pytest.skip("pooling needs H, W >= 2")
+    g = torch.Generator().manual_seed(31 * H + W + mode)
+    pre = torch.randn(N, C, H, W, generator=g).requires_grad_(True)
+    x = F.leaky_relu(pre, 0.01) if masked else pre
+    if mode == 1:
+        ref = F.avg_pool2d(x, 2)
+    elif mode == 2:
+        ref = F.interpolate(x, scale_factor=2, mode="nearest")
+    else:
+        ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    L = hip.lib
+    xd = D(nhwc(x.detach()))
+    out = torch.full((N, ref.shape[2], ref.shape[3], C), float("nan"), device="cuda")
+    hip.check(L.aesr_resample2_fwd(hip.ptr(xd), hip.ptr(out), N, H, W, C, mode, hip.stream()), "resample fwd")
+    assert rel_l2(nchw(out), ref.detach()) < 1e-6
+    dx = torch.full((N, H, W, C), float("nan"), device="cuda")
+    hip.check(L.aesr_resample2_bwd(hip.ptr(D(nhwc(gout))), hip.ptr(xd) if masked else None, hip.ptr(dx), N, H, W, C, mode,
+                                   1 if masked else 0, 0.01, hip.stream()), "resample bwd")
+    assert rel_l2(nchw(dx), pre.grad) < 1e-6
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(6, 33, 31, 32), (4, 40, 40, 64), (3, 9, 9, 8)])
 def test_bn_groups_fwd_bwd(hip, mode, shape):

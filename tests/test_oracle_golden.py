@@ -142,3 +142,23 @@ def test_supervolume():
     hr = step_oracle.create_super_volume(ae, torch.from_numpy(rec["vol"]), rec["alpha_range"], use_original=True)
     assert hr.shape == rec["hr"].shape == ((5 - 1) * (3 + 1) + 1, 32, 32)
     np.testing.assert_allclose(hr.numpy(), rec["hr"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_ae_standard_blocks_oracle_vs_reference(tag):
+    """The oracle's restatement of the ae_standard encoder/decoder blocks (AvgPool without BatchNorm, bilinear x2 upsample,
+    networks/ae_standard.py:34-80) against vectors produced by the reference's own block modules."""
+    from oracle import ae_oracle
+    rec = dict(np.load(os.path.join(GOLDEN, "ae_standard_blocks_%s.npz" % tag)))
+    params = {k[2:]: torch.from_numpy(v).requires_grad_(True) for k, v in rec.items() if k.startswith("p/")}
+    x = torch.from_numpy(rec["x"]).requires_grad_(True)
+    mid, out = ae_oracle.ae_standard_blocks(params, x)
+    tgt = torch.from_numpy(rec["tgt"])
+    loss = (out * tgt).mean() + 0.5 * (out ** 2).mean()
+    loss.backward()
+    assert np.allclose(mid.detach().numpy(), rec["mid"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(out.detach().numpy(), rec["out"], rtol=1e-5, atol=1e-6)
+    assert abs(loss.item() - float(rec["loss"])) < 1e-6 * max(1.0, abs(float(rec["loss"])))
+    assert np.allclose(x.grad.numpy(), rec["dx"], rtol=1e-4, atol=1e-7)
+    for k, p in params.items():
+        assert np.allclose(p.grad.numpy(), rec["grad/" + k], rtol=1e-4, atol=1e-6), k
