@@ -208,6 +208,15 @@ int aesr_act_bwd(const float* dout, const float* y, float* dpre, size_t n, int a
 int aesr_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* state, size_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, void* stream);
 
+/* ---- validation metrics on the device (evaluate/metrics.py:111-194: skimage structural_similarity / peak_signal_noise_ratio
+ * slice by slice) -------------------------------------------------------------------------------------------------------
+ * a, b: [Z][H][W] fp32.  ssim[Z], mse[Z]: fp64 device arrays (mean SSIM with a uniform win x win window, sample covariance,
+ * C1 = (k1*data_range)^2, C2 = (k2*data_range)^2; mean squared difference).  win odd, 3..11, <= min(H, W).
+ * workspace: aesr_ssim_workspace_doubles(Z, H, W) doubles. */
+size_t aesr_ssim_workspace_doubles(int Z, int H, int W);
+int aesr_ssim_mse(const float* a, const float* b, double* workspace, double* ssim, double* mse, int Z, int H, int W, int win,
+                  double data_range, double k1, double k2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,8 @@ SIGNATURES = {
     "aesr_mse_fwd": (c_int, [P, P, P, P, c_size_t, P]),
     "aesr_mse_bwd": (c_int, [P, P, P, P, c_size_t, P]),
     "aesr_act_bwd": (c_int, [P, P, P, c_size_t, c_int, c_float, P]),
+    "aesr_ssim_workspace_doubles": (c_size_t, [c_int, c_int, c_int]),
+    "aesr_ssim_mse": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_double, c_double, c_double, P]),
     "aesr_adam_step": (c_int, [P, P, P, P, P, c_size_t] + [c_float] * 5 + [P]),
 }
 

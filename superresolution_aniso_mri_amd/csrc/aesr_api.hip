@@ -593,4 +593,15 @@ int aesr_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, 
     return aesr_launch_adam(p, g, exp_avg, exp_avg_sq, state, n, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream);
 }
 
+size_t aesr_ssim_workspace_doubles(int Z, int H, int W) { return (size_t)Z * ceil_div(H, 16) * ceil_div(W, 16) * 2; }
+
+int aesr_ssim_mse(const float* a, const float* b, double* workspace, double* ssim, double* mse, int Z, int H, int W, int win,
+                  double data_range, double k1, double k2, void* stream) {
+    AESR_CHECK_ARG(a && b && workspace && ssim && mse && Z > 0 && H > 0 && W > 0, "aesr_ssim_mse: null pointer or empty shape");
+    AESR_CHECK_ARG(win >= 3 && win <= 11 && (win & 1) && win <= H && win <= W,
+                   "aesr_ssim_mse: win=%d must be odd, 3..11 and not larger than the image (%dx%d)", win, H, W);
+    AESR_CHECK_ARG(data_range > 0.0, "aesr_ssim_mse: data_range must be positive");
+    return aesr_launch_ssim_mse(a, b, workspace, ssim, mse, Z, H, W, win, data_range, k1, k2, (hipStream_t)stream);
+}
+
 }  // extern "C"

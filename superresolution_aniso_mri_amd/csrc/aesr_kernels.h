@@ -136,4 +136,6 @@ int aesr_launch_lpips_finalize(const float* const* partials, const int* hw, int 
 int aesr_launch_scale_expand(const float* x, float* out4, int n, const float* ca, const float* cb, int backward, hipStream_t st);
 int aesr_launch_resample2(const float* x, const float* gout, const float* xsave, float* dst, int N, int H, int W, int C, int mode,
                           int backward, int mask_act, float slope, hipStream_t st);
+int aesr_launch_ssim_mse(const float* a, const float* b, double* partial, double* ssim, double* mse, int Z, int H, int W, int win,
+                         double data_range, double k1, double k2, hipStream_t st);
 int aesr_launch_s2d(const float* x, float* out, int N, int H, int W, int C, int inverse, hipStream_t st);

@@ -87,9 +87,15 @@ def load_images(input_dir, suffix=".nii*"):
             files = sorted(input_dir.rglob(pat))
             if files:
                 return [(f, sitk.ReadImage(str(f))) for f in files]
+    else:                                   # no SimpleITK: the built-in NIfTI-1 / MetaImage reader (volume_io.py)
+        from . import volume_io
+        for pat in ("*" + suffix, "*.mha", "*.mhd"):
+            files = sorted(f for f in input_dir.rglob(pat) if not str(f).endswith(".raw"))
+            if files:
+                return [(f, volume_io.read_volume(f)) for f in files]
     files = sorted(input_dir.rglob("*.npy"))
     if not files:
-        raise FileNotFoundError("Error - no files found in {} with extensions nii, mha, mhd (SimpleITK) or npy".format(input_dir))
+        raise FileNotFoundError("Error - no files found in {} with extensions nii, mha, mhd or npy".format(input_dir))
     return [(f, np.load(str(f))) for f in files]
 
 
@@ -118,8 +124,16 @@ def main(argv=None):
     trainer, _ = get_trainer_dynamic(src_path=args.exper_dir, model_nbr=args.model_nbr, model_nbr_sr=None, eval_mode=True)
     sitk = _sitk()
     results = []
+    from . import volume_io
     for fname, img in images:
-        if isinstance(img, np.ndarray):
+        if isinstance(img, volume_io.Volume):
+            hr = upsample_volume(trainer, img.array, args.num_interpolations)
+            spacing = list(img.spacing)
+            spacing[2] = spacing[2] / (args.num_interpolations + 1)
+            results.append((out_dir / fname.name, hr))
+            if args.save:
+                volume_io.write_volume(out_dir / fname.name, img, hr.astype(np.float32), spacing)
+        elif isinstance(img, np.ndarray):
             hr = upsample_volume(trainer, img, args.num_interpolations)
             results.append((out_dir / fname.name, hr))
             if args.save:

@@ -28,6 +28,21 @@ def test_train_then_generate(tmp_path):
                                     "--output_dir=" + str(tmp_path / "hr"), "--save"])
     hr = np.load(str(tmp_path / "hr" / "vol0.npy"))
     assert hr.shape == (4 * 4 + 1, 32, 32) and hr.min() >= 0 and hr.max() <= 1 and len(res) == 1
+    # the same volume as a NIfTI file (no SimpleITK in this image: volume_io.py reads / writes it) gives the same slices, a
+    # float32 .nii.gz with 17 slices and the z spacing divided by 4
+    import struct
+    from superresolution_aniso_mri_amd import volume_io
+    vol = np.random.RandomState(0).rand(5, 32, 32).astype(np.float32) * 900.0
+    nii = tmp_path / "nii"
+    nii.mkdir()
+    like = volume_io.Volume(vol, (1.5, 1.5, 8.0), "npy", {})
+    volume_io.write_volume(nii / "vol0.nii.gz", like, vol, (1.5, 1.5, 8.0))
+    generate_hr_volumes.main(["--exper_dir=" + src, "--model_nbr=2", "--num_interpolations=3", "--data_input_dir=" + str(nii),
+                              "--output_dir=" + str(tmp_path / "hr_nii"), "--save"])
+    back = volume_io.read_volume(tmp_path / "hr_nii" / "vol0.nii.gz")
+    assert back.array.shape == (17, 32, 32) and back.array.dtype == np.float32
+    assert abs(back.spacing[2] - 2.0) < 1e-6 and back.spacing[:2] == (1.5, 1.5)
+    assert np.array_equal(back.array, hr)
 
 
 def test_config1_mnist_shaped_step_vs_oracle():

@@ -1,0 +1,58 @@
+"""-m gpu: device SSIM / PSNR (aesr_ssim_mse, evaluate/metrics.py mirror) against the oracle's fp64 restatement of the skimage
+definitions (oracle/step_oracle.py: ssim, psnr).  Tolerance: 1e-9 absolute on SSIM (both sides fp64), 1e-9 relative on MSE."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(5, 160, 160), (3, 33, 47), (1, 7, 9), (4, 16, 16), (2, 220, 180)])
+@pytest.mark.parametrize("data_range", [1.0, 2.0])
+def test_slice_ssim_psnr_vs_oracle(shape, data_range):
+    from oracle import step_oracle
+    from evaluate.metrics import slice_ssim_psnr
+    g = torch.Generator().manual_seed(shape[1] * 7 + shape[2])
+    a = torch.rand(shape, generator=g)
+    b = (a + 0.1 * torch.randn(shape, generator=g)).clamp(0, 1)
+    b[0] = a[0] * 0.5 + 0.2                        # a structured (non-noise) difference as well
+    ssim, psnr, mse = slice_ssim_psnr(a, b, data_range=data_range)
+    win = 7 if min(shape[1:]) >= 8 else 5
+    for z in range(shape[0]):
+        ref_s = step_oracle.ssim(a[z], b[z], data_range=data_range, win=win)
+        ref_m = float(((a[z].double() - b[z].double()) ** 2).mean())
+        assert abs(ssim[z] - ref_s) < 1e-9, (z, ssim[z], ref_s)
+        assert abs(mse[z] - ref_m) < 1e-9 * ref_m
+        assert abs(psnr[z] - step_oracle.psnr(a[z], b[z], data_range=data_range)) < 1e-6
+
+
+def test_batch_entry_points_and_original_slice_skipping():
+    from oracle import step_oracle
+    from evaluate.metrics import compute_psnr_for_batch, compute_ssim_for_batch, determine_original_sliceids
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(11, 1, 40, 36, generator=g)
+    b = (a + 0.05 * torch.randn(a.shape, generator=g)).clamp(0, 1)
+    s_all = compute_ssim_for_batch(a, b.numpy())
+    ref = np.mean([step_oracle.ssim(a[z, 0], b[z, 0]) for z in range(11)])
+    assert abs(s_all - ref) < 1e-9
+    orig = determine_original_sliceids(a[:, 0].numpy(), 3)
+    assert list(orig) == [0, 3, 6, 9, 10]
+    keep = [z for z in range(11) if z not in set(orig)]
+    s_skip = compute_ssim_for_batch(a, b, downsample_steps=3)
+    assert abs(s_skip - np.mean([step_oracle.ssim(a[z, 0], b[z, 0]) for z in keep])) < 1e-9
+    p_skip = compute_psnr_for_batch(a, b, downsample_steps=3)
+    assert abs(p_skip - np.mean([step_oracle.psnr(a[z, 0], b[z, 0]) for z in keep])) < 1e-6
+    # identical volumes: PSNR is infinite for every slice -> dropped -> nan mean, SSIM exactly 1
+    assert abs(compute_ssim_for_batch(a, a) - 1.0) < 1e-12
+    # single image
+    assert abs(compute_psnr_for_batch(a[2, 0], b[2, 0]) - step_oracle.psnr(a[2, 0], b[2, 0])) < 1e-6
+
+
+def test_bad_window_fails_loudly():
+    from superresolution_aniso_mri_amd import _hip as hip
+    a = torch.rand(1, 4, 4, device="cuda")
+    ws = torch.empty(8, device="cuda", dtype=torch.float64)
+    out = torch.empty(2, device="cuda", dtype=torch.float64)
+    rc = hip.lib.aesr_ssim_mse(hip.ptr(a), hip.ptr(a), hip.ptr(ws), hip.ptr(out[0:1]), hip.ptr(out[1:2]), 1, 4, 4, 7, 1.0, 0.01, 0.03,
+                               hip.stream())
+    assert rc != 0 and "win" in hip.last_error()

@@ -172,3 +172,19 @@ def test_make_grid_and_recon_grid():
     assert g.shape == (1, 2 * 6 + 2, 3 * 7 + 2) and float(g[0, 0, 0]) == 0.5 and float(g[0, 2, 2]) == 0.0
     assert torch.equal(g[0, 8:12, 2:7], t[3, 0])
     assert generate_recon_grid(torch.rand(4, 1, 8, 8), torch.rand(4, 1, 8, 8)).shape[0] == 1
+
+
+def test_original_slice_ids_for_subsampled_volumes():
+    """evaluate/metrics.py:29-45: which slices of a sub-sampled-then-upsampled volume are originals (hand-derived cases)."""
+    import importlib.util, os, sys, types
+    # the module imports the HIP binding at import time only for the device functions; load just the pure function
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "superresolution_aniso_mri_amd", "evaluate", "metrics.py")).read()
+    start = src.index("def determine_original_sliceids"); end = src.index("def _as_volume")
+    ns = {"np": np}
+    exec(src[start:end], ns)
+    f = ns["determine_original_sliceids"]
+    assert list(f(np.zeros((13, 4, 4)), 2)) == [0, 2, 4, 6, 8, 10, 12]
+    assert list(f(np.zeros((10, 4, 4)), 3)) == [0, 3, 6, 9]
+    assert list(f(np.zeros((11, 4, 4)), 3)) == [0, 3, 6, 9, 10]
+    assert list(f(np.zeros((11, 4, 4)), 3, conv_interpol=True)) == [0, 3, 6, 9, 10]
+    assert list(f(np.zeros((12, 4, 4)), 4, conv_interpol=True)) == [0, 4, 8, 9, 10, 11]
