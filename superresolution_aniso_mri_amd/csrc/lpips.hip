@@ -144,6 +144,90 @@ __global__ __launch_bounds__(256) void lpips_tap_fwd_kernel(const float* __restr
     if (threadIdx.x == 0) partial[n * LP_NCH + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Narrow taps (C = 64, 128): LPP = C/4 lanes x float4 own one pixel, a wave works on 64/LPP pixels at once -- the wave-wide
+// form above spends most of its time in 6-step butterflies for a 64-channel pixel.
+template <int LPP>
+__device__ __forceinline__ float group_allsum(float v) {
+#pragma unroll
+    for (int o = LPP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int LPP>
+__global__ __launch_bounds__(256) void lpips_tap_fwd_sub_kernel(const float* __restrict__ f, const float* __restrict__ lin,
+                                                                float* __restrict__ partial, int B, int HW) {
+    constexpr int C = LPP * 4, PPW = 64 / LPP;
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPP, pg = lane / LPP;
+    const int n = blockIdx.y;
+    const f32x4 w = *(const f32x4*)(lin + sub * 4);
+    float acc = 0.f;
+    for (int p0 = (blockIdx.x * 4 + wave) * PPW; p0 < HW; p0 += LP_NCH * 4 * PPW) {
+        const int p = p0 + pg;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (p < HW) {
+            a = *(const f32x4*)(f + ((size_t)n * HW + p) * C + sub * 4);
+            b = *(const f32x4*)(f + ((size_t)(n + B) * HW + p) * C + sub * 4);
+        }
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sa = fmaf(a[k], a[k], sa); sb = fmaf(b[k], b[k], sb); }
+        sa = group_allsum<LPP>(sa);
+        sb = group_allsum<LPP>(sb);
+        const float ia = 1.f / (sqrtf(sa) + 1e-10f), ib = 1.f / (sqrtf(sb) + 1e-10f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d = a[k] * ia - b[k] * ib;
+            acc = fmaf(w[k] * d, d, acc);
+        }
+    }
+    acc = wave_allsum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[n * LP_NCH + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <int LPP>
+__global__ __launch_bounds__(256) void lpips_tap_bwd_sub_kernel(const float* __restrict__ f, const float* __restrict__ lin,
+                                                                const float* __restrict__ gd, float* __restrict__ gf0, int B,
+                                                                int HW, float inv_hw) {
+    constexpr int C = LPP * 4, PPW = 64 / LPP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPP, pg = lane / LPP;
+    const int n = blockIdx.y;
+    const f32x4 w = *(const f32x4*)(lin + sub * 4);
+    const float up = gd[n] * inv_hw;
+    for (int p0 = (blockIdx.x * 4 + wave) * PPW; p0 < HW; p0 += gridDim.x * 4 * PPW) {
+        const int p = p0 + pg;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (p < HW) {
+            a = *(const f32x4*)(f + ((size_t)n * HW + p) * C + sub * 4);
+            b = *(const f32x4*)(f + ((size_t)(n + B) * HW + p) * C + sub * 4);
+        }
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sa = fmaf(a[k], a[k], sa); sb = fmaf(b[k], b[k], sb); }
+        sa = group_allsum<LPP>(sa);
+        sb = group_allsum<LPP>(sb);
+        const float n0 = sqrtf(sa);
+        const float ia = 1.f / (n0 + 1e-10f), ib = 1.f / (sqrtf(sb) + 1e-10f);
+        f32x4 o;
+        float S = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d = a[k] * ia - b[k] * ib;
+            o[k] = 2.f * w[k] * d;
+            S = fmaf(o[k], a[k], S);
+        }
+        S = group_allsum<LPP>(S);
+        const float kn = n0 > 0.f ? S * ia * ia / n0 : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = up * (o[k] * ia - a[k] * kn);
+        if (p < HW) *(f32x4*)(gf0 + ((size_t)n * HW + p) * C + sub * 4) = o;
+    }
+}
+
 // gf0[n,p,c] = gd[n]*inv_hw * ( 2 w_c D_c / (n0+eps) - f0_c * S / (n0 (n0+eps)^2) ),  S = sum_c 2 w_c D_c f0_c
 // (an all-zero feature vector gets the finite limit 2 w_c D_c/(eps) -> its norm term is dropped, where autograd of the
 //  reference would produce NaN)
@@ -252,8 +336,8 @@ int aesr_launch_maxpool2_bwd(const float* gout, const float* x, const float* gad
 int aesr_launch_lpips_tap_fwd(const float* f, const float* lin, float* partial, int B, int HW, int C, hipStream_t st) {
     dim3 grid(LP_NCH, B);
     switch (C) {
-        case 64: hipLaunchKernelGGL(lpips_tap_fwd_kernel<1>, grid, dim3(256), 0, st, f, lin, partial, B, HW); break;
-        case 128: hipLaunchKernelGGL(lpips_tap_fwd_kernel<2>, grid, dim3(256), 0, st, f, lin, partial, B, HW); break;
+        case 64: hipLaunchKernelGGL(lpips_tap_fwd_sub_kernel<16>, grid, dim3(256), 0, st, f, lin, partial, B, HW); break;
+        case 128: hipLaunchKernelGGL(lpips_tap_fwd_sub_kernel<32>, grid, dim3(256), 0, st, f, lin, partial, B, HW); break;
         case 256: hipLaunchKernelGGL(lpips_tap_fwd_kernel<4>, grid, dim3(256), 0, st, f, lin, partial, B, HW); break;
         case 512: hipLaunchKernelGGL(lpips_tap_fwd_kernel<8>, grid, dim3(256), 0, st, f, lin, partial, B, HW); break;
         default: aesr_set_error("lpips_tap_fwd: unsupported channel count %d (64/128/256/512)", C); return AESR_ERR_UNSUPPORTED;
@@ -267,9 +351,11 @@ int aesr_launch_lpips_tap_bwd(const float* f, const float* lin, const float* gd,
     if (gx > 256) gx = 256;
     dim3 grid(gx, B);
     const float inv = 1.f / (float)HW;
+    int gs = (HW + 15) / 16;                 // narrow taps: 4 (C=64) / 2 (C=128) pixels per wave
+    if (gs > 256) gs = 256;
     switch (C) {
-        case 64: hipLaunchKernelGGL(lpips_tap_bwd_kernel<1>, grid, dim3(256), 0, st, f, lin, gd, gf0, B, HW, inv); break;
-        case 128: hipLaunchKernelGGL(lpips_tap_bwd_kernel<2>, grid, dim3(256), 0, st, f, lin, gd, gf0, B, HW, inv); break;
+        case 64: hipLaunchKernelGGL(lpips_tap_bwd_sub_kernel<16>, dim3(gs, B), dim3(256), 0, st, f, lin, gd, gf0, B, HW, inv); break;
+        case 128: hipLaunchKernelGGL(lpips_tap_bwd_sub_kernel<32>, dim3(gs, B), dim3(256), 0, st, f, lin, gd, gf0, B, HW, inv); break;
         case 256: hipLaunchKernelGGL(lpips_tap_bwd_kernel<4>, grid, dim3(256), 0, st, f, lin, gd, gf0, B, HW, inv); break;
         case 512: hipLaunchKernelGGL(lpips_tap_bwd_kernel<8>, grid, dim3(256), 0, st, f, lin, gd, gf0, B, HW, inv); break;
         default: aesr_set_error("lpips_tap_bwd: unsupported channel count %d (64/128/256/512)", C); return AESR_ERR_UNSUPPORTED;
