@@ -44,6 +44,9 @@ def cpu_baseline(B, H, steps=3):
     """The oracle (PyTorch-CPU restatement of the same step, MSE synthesis loss) on this host's cores."""
     from oracle import ae_oracle, step_oracle
     from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+    # a 1-GPU box gives this process a 16-CPU share of the host: more intra-op threads than that only oversubscribe
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(16, avail)))
     torch.manual_seed(892372)
     ae = ae_oracle.OracleAE(ae_oracle.acdc_args())
     st = step_oracle.OracleStep(ae, lr=1e-5, ex_loss_weight1=0.05, image_mix_loss_func="mse")

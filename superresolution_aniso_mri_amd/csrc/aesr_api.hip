@@ -143,6 +143,11 @@ static WgradPlan plan_wgrad(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
             p.S = S0 < ntiles ? S0 : ntiles;
         }
     }
+    if (const char* e = getenv("AESR_WGRAD_S")) {             // experiment knob: splits per (ci, co) chunk
+        const int s_ = atoi(e);
+        const int ntiles = N * ceil_div(Ho, p.TH) * ceil_div(Wo, p.TW);
+        if (s_ > 0) p.S = s_ < ntiles ? s_ : ntiles;
+    }
     p.PWS = p.TW + KS - 1 + ((p.TW + KS - 1) & 1);
     p.TWS = p.TW;
     p.PSX = plane_stride((p.TH + KS - 1) * p.PWS);
