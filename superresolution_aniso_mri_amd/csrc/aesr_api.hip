@@ -51,7 +51,8 @@ static ConvPlan plan_conv(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
     for (int NT = 512; NT >= 256; NT -= 256) {
         // two 4-wave workgroups per CU measured 2-5 % slower than one 8-wave workgroup on all but the 32->32 160x160 layer
         // (profiles/r01_igemm_nt256.txt): kept as an experiment knob, not chosen by the planner
-        if (NT != (force_nt == 256 ? 256 : 512)) continue;
+        (void)force_nt;
+        if (NT != 512) continue;
         const int NW = NT / 64, wgs_per_cu = 512 / NT;
         const int maxpix = 16 * NW * p.MBW;
         // LDS per workgroup: patch (80 B per pixel) + the chunk's weights + bias; 6 staging pieces of 16 B per thread

@@ -39,7 +39,7 @@ constexpr int IG_MAXP = 6;   // staging pieces (16 B) per thread: patch pixels *
 // so HBM/L2 latency of the patch hides behind ~18k cycles of matrix work; weight fragments are prefetched one tap ahead.
 // MFMA operand roles: A = weights (M = 16 couts), B = activations (N = 16 pixels): a lane's 4 accumulator registers are
 // 4 CONSECUTIVE couts of one pixel -> bias/activation/mask/store of the epilogue are 16-byte wide.
-template <int KS, int NB, int MBW, int NT>
+template <int KS, int NB, int MBW, int NT, bool MASK>
 __global__ __launch_bounds__(NT, 2) void conv_igemm_f32(IgemmArgs a) {
     constexpr int NW = NT / 64;                 // waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU, out of phase)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -157,7 +157,7 @@ _Pragma("unroll")  \
                                 v += *(const f32x4*)(ldsBias + co);  \
 _Pragma("unroll")  \
                                 for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act, a.slope);  \
-                                if (a.ysave) {  \
+                                if (MASK) {  \
                                     const f32x4 ys = *(const f32x4*)(a.ysave + ob + co);  \
 _Pragma("unroll")  \
                                     for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_output(ys[e], a.mask_act, a.slope);  \
@@ -171,7 +171,7 @@ _Pragma("unroll")  \
                                     float s = v[e];  \
                                     s += ldsBias[co + e];  \
                                     s = act_apply(s, a.act, a.slope);  \
-                                    if (a.ysave) s *= act_grad_from_output(a.ysave[ob + co + e], a.mask_act, a.slope);  \
+                                    if (MASK) s *= act_grad_from_output(a.ysave[ob + co + e], a.mask_act, a.slope);  \
                                     a.out[ob + co + e] = s;  \
                                 }  \
                             }  \
@@ -205,6 +205,11 @@ _Pragma("unroll")  \
     int pend_co0 = 0;
     bool pend_valid = false;
     const bool vec = (a.Cout & 3) == 0;
+    // data-gradient use (MASK): derivative of the activation that produced the forward input, from its saved output y:
+    // LeakyReLU / ReLU: y > 0 ? 1 : mslope; sigmoid: y (1 - y).  Wave-uniform selects, no per-element branching.
+    const float mslope = a.mask_act == ACT_LRELU ? a.slope : 0.f;
+    const bool msig = a.mask_act == ACT_SIGMOID, mnone = a.mask_act == ACT_NONE;
+#define IG_MASK_OF(y) (mnone ? 1.f : (msig ? (y) * (1.f - (y)) : ((y) > 0.f ? 1.f : mslope)))
 
     unsigned long long tphase[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     const bool stamp = (a.dbg & 8) && a.dbgbuf;
@@ -242,7 +247,7 @@ _Pragma("unroll")  \
         }
         // the pending item's mask values (data-gradient use) go in flight BEFORE the patch prefetch: vmcnt retires in
         // order, so they must not queue behind HBM loads
-        if (pend_valid && a.ysave) {
+        if (MASK && pend_valid) {
 #pragma unroll
             for (int i = 0; i < MBW; ++i)
 #pragma unroll
@@ -318,9 +323,9 @@ _Pragma("unroll")  \
                             const int co = pend_co0 + pnb * 16 + 4 * g;
                             if (pend_ob[pi] >= 0 && co < a.Cout && !(a.dbg & 4)) {
                                 f32x4 v = pend[pi][pnb];
-                                if (a.ysave) {
+                                if (MASK) {
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_output(pmask[pi][pnb][e], a.mask_act, a.slope);
+                                    for (int e = 0; e < 4; ++e) v[e] *= IG_MASK_OF(pmask[pi][pnb][e]);
                                 }
                                 *(f32x4*)(a.out + pend_ob[pi] + co) = v;
                             }
@@ -376,10 +381,10 @@ _Pragma("unroll")  \
                 const int co = pend_co0 + nb * 16 + 4 * g;
                 if (pend_ob[i] >= 0 && co < a.Cout) {
                     f32x4 v = pend[i][nb];
-                    if (a.ysave) {
+                    if (MASK) {
                         const f32x4 ys = *(const f32x4*)(a.ysave + pend_ob[i] + co);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_output(ys[e], a.mask_act, a.slope);
+                        for (int e = 0; e < 4; ++e) v[e] *= IG_MASK_OF(ys[e]);
                     }
                     *(f32x4*)(a.out + pend_ob[i] + co) = v;
                 }
@@ -389,6 +394,7 @@ _Pragma("unroll")  \
         tphase[6] = __builtin_amdgcn_s_memtime() - tlast;
         for (int k = 0; k < 7; ++k) a.dbgbuf[blockIdx.x * 7 + k] = (float)tphase[k];
     }
+#undef IG_MASK_OF
 #undef IG_STAMP
 #undef IG_EPILOGUE
 #undef IG_TILE_ORIGIN
@@ -460,7 +466,7 @@ int aesr_launch_pack_many(const PackTable& t, hipStream_t st) {
     return AESR_OK;
 }
 
-template <int KS, int NB, int MBW, int NT>
+template <int KS, int NB, int MBW, int NT, bool MASK>
 static int launch_one(const IgemmArgs& a, hipStream_t st) {
     const int PP = a.TI * (a.TH + KS - 1) * (a.TW + KS - 1);
     const size_t shmem = ((size_t)PP * IG_S + (size_t)KS * KS * 4 * 16 * NB * 4 + a.CoutP) * sizeof(float);
@@ -470,7 +476,7 @@ static int launch_one(const IgemmArgs& a, hipStream_t st) {
     }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_f32<KS, NB, MBW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_f32<KS, NB, MBW, NT, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     int grid = 256 * (512 / NT);              // persistent: 2 waves per SIMD (register budget), as one 8-wave or two 4-wave workgroups per CU
@@ -481,7 +487,7 @@ static int launch_one(const IgemmArgs& a, hipStream_t st) {
         if (!dbuf) (void)hipMalloc(&dbuf, 1024 * 7 * sizeof(float));
         IgemmArgs b = a;
         b.dbgbuf = dbuf;
-        hipLaunchKernelGGL((conv_igemm_f32<KS, NB, MBW, NT>), dim3(grid), dim3(NT), shmem, st, b);
+        hipLaunchKernelGGL((conv_igemm_f32<KS, NB, MBW, NT, MASK>), dim3(grid), dim3(NT), shmem, st, b);
         (void)hipStreamSynchronize(st);
         static float host[1024 * 7];
         (void)hipMemcpy(host, dbuf, grid * 7 * sizeof(float), hipMemcpyDeviceToHost);
@@ -492,7 +498,7 @@ static int launch_one(const IgemmArgs& a, hipStream_t st) {
                 s5[5] / grid / 1e3, s5[6] / grid / 1e3);
         return AESR_OK;
     }
-    hipLaunchKernelGGL((conv_igemm_f32<KS, NB, MBW, NT>), dim3(grid), dim3(NT), shmem, st, a);
+    hipLaunchKernelGGL((conv_igemm_f32<KS, NB, MBW, NT, MASK>), dim3(grid), dim3(NT), shmem, st, a);
     AESR_LAUNCH_CHECK("conv_igemm_f32");
     return AESR_OK;
 }
@@ -504,7 +510,7 @@ int aesr_launch_conv_igemm(const IgemmArgs& a_in, int KS, int NB, int MBW, hipSt
     a.dbg = dbg;
     const int TP = a.TI * a.TH * a.TW;
     const int nblk = (TP + 15) / 16;
-    const int NT = a.NT == 256 ? 256 : 512, NW = NT / 64;
+    const int NT = 512, NW = NT / 64;       // the 256-thread (two workgroups per CU) form measured slower: not instantiated
     if (nblk > NW * MBW) {
         aesr_set_error("conv_igemm: tile of %d pixels needs %d M-blocks > %d", TP, nblk, NW * MBW);
         return AESR_ERR_ARG;
@@ -530,7 +536,7 @@ int aesr_launch_conv_igemm(const IgemmArgs& a_in, int KS, int NB, int MBW, hipSt
     }
 #define IG_CASE(ks, nb, mbw)                                                          \
     if (KS == ks && NB == nb && MBW == mbw)                                           \
-        return NT == 256 ? launch_one<ks, nb, mbw, 256>(a, st) : launch_one<ks, nb, mbw, 512>(a, st);
+        return a.ysave ? launch_one<ks, nb, mbw, 512, true>(a, st) : launch_one<ks, nb, mbw, 512, false>(a, st);
     IG_CASE(3, 1, 1) IG_CASE(3, 1, 2) IG_CASE(3, 1, 3) IG_CASE(3, 1, 4) IG_CASE(3, 2, 1) IG_CASE(3, 2, 2) IG_CASE(3, 2, 3) IG_CASE(3, 2, 4)
     IG_CASE(3, 4, 1) IG_CASE(3, 4, 2)
     IG_CASE(1, 1, 1) IG_CASE(1, 1, 2) IG_CASE(1, 1, 3) IG_CASE(1, 1, 4) IG_CASE(1, 2, 1) IG_CASE(1, 2, 2) IG_CASE(1, 2, 3) IG_CASE(1, 2, 4)

@@ -88,25 +88,6 @@ def test_conv_fwd(hip, case, act):
     assert rel_l2(nchw(out), ref) < 1e-5
 
 
-@pytest.mark.parametrize("case", [(2, 37, 41, 32, 32, 3, 1), (3, 19, 23, 64, 128, 3, 1), (2, 13, 11, 16, 16, 1, 0)])
-def test_conv_fwd_two_workgroups_per_cu(hip, case, monkeypatch):
-    """The 256-thread form of the implicit-GEMM kernel (two workgroups per CU; AESR_IGEMM_NT=256 experiment knob)."""
-    monkeypatch.setenv("AESR_IGEMM_NT", "256")
-    N, H, W, cin, cout, ks, pad = case
-    g = torch.Generator().manual_seed(17)
-    x = torch.randn(N, cin, H, W, generator=g)
-    w = torch.randn(cout, cin, ks, ks, generator=g) / np.sqrt(cin * ks * ks)
-    b = torch.randn(cout, generator=g)
-    ref = F.leaky_relu(F.conv2d(x, w, b, padding=pad), 0.01)
-    L = hip.lib
-    pk = _pack(hip, D(w), 0)
-    Ho, Wo = H + 2 * pad - ks + 1, W + 2 * pad - ks + 1
-    out = torch.full((N, Ho, Wo, cout), float("nan"), device="cuda")
-    hip.check(L.aesr_conv2d_fwd(hip.ptr(D(nhwc(x))), hip.ptr(pk), hip.ptr(D(b)), hip.ptr(out), N, H, W, cin, cout, ks, pad, 1, 0.01,
-                                hip.stream()), "fwd")
-    assert rel_l2(nchw(out), ref) < 1e-5
-
-
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[4] % 4 == 0])
 @pytest.mark.parametrize("masked", [False, True])
 def test_conv_dgrad(hip, case, masked):
