@@ -33,6 +33,13 @@ constexpr int IG_S = 20;     // LDS floats per patch pixel: 16 channels + 4 pad 
 // that run out of phase (one's staging/barrier phases under the other's MFMAs) and give small layers twice the work items
 constexpr int IG_MAXP = 6;   // staging pieces (16 B) per thread: patch pixels * 4 <= IG_NT * IG_MAXP
 
+__device__ __forceinline__ f32x4 ig_ld(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+}
+__device__ __forceinline__ void ig_st(__amdgpu_buffer_rsrc_t rs, int byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), rs, byte_off, 0, 0);
+}
+
 // Persistent workgroups: each walks work items (spatial tile x cout tile) item, item+G, ...  The pixel->LDS maps are
 // position independent, so every integer division happens once per kernel.  Software pipeline per 16-channel chunk:
 //   barrier | registers -> LDS | barrier | issue global loads of the NEXT chunk (or next item) | 9 taps of MFMAs
@@ -61,6 +68,15 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f32(IgemmArgs a) {
     float* ldsW = lds + PP * IG_S;                        // [tap][ci/4][TN][4]
     float* ldsBias = ldsW + NWP * 4;                       // [CoutP] (zeros when there is no bias)
     for (int c = tid; c < a.CoutP; c += NT) ldsBias[c] = (a.bias && c < a.Cout) ? a.bias[c] : 0.f;
+
+    // Global accesses of the hot loop go through buffer descriptors: an out-of-range byte offset makes a load return 0 and
+    // drops a store, so halo / padding / tail pieces need no exec masking, no branches and no zero-initialised registers.
+    // IG_OOB + any in-range offset stays >= 2^31 - 2^28 > the tensor size (the host refuses tensors of 2^29 floats or more).
+    constexpr int IG_OOB = 0x70000000;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (int)((size_t)KS * KS * a.CinP * a.CoutP * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (a.dbg & 4) ? 0 : (int)((size_t)a.N * a.Ho * a.Wo * a.Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ys = __builtin_amdgcn_make_buffer_rsrc((void*)(MASK ? a.ysave : a.out), 0, (int)((size_t)a.N * a.Ho * a.Wo * a.Cout * 4), 0x00020000);
 
     // ---- position-independent maps (computed once) ------------------------------------------------------------
     int a_off[MBW], pix[MBW];                 // pix = img<<20 | r<<10 | c of this lane's pixel of block i, or -1
@@ -115,28 +131,24 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f32(IgemmArgs a) {
         IG_TILE_ORIGIN(item, n0_, y0_, x0_, co0_)                                                                 \
         (void)co0_;                                                                                               \
         _Pragma("unroll") for (int j = 0; j < IG_MAXP; ++j) {                                                     \
-            int go = -2;                                                                                          \
+            int go = IG_OOB;                                                                                      \
             if (piece[j] >= 0) {                                                                                  \
                 const int n = n0_ + (piece[j] >> 20), gy = y0_ + ((piece[j] >> 10) & 1023) - a.pad;               \
                 const int gx = x0_ + (piece[j] & 1023) - a.pad;                                                   \
-                go = (n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? ((n * a.H + gy) * a.W + gx) * a.Cin + part4 : -1; \
+                go = (n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (((n * a.H + gy) * a.W + gx) * a.Cin + part4) * 4 : IG_OOB; \
             }                                                                                                     \
             goff[j] = go;                                                                                         \
         }                                                                                                         \
     }
 #define IG_ISSUE_LOADS(item, cc)                                                                            \
     {                                                                                                       \
-        const float* wsrc_ = a.wpk + ((size_t)(cc) * ncot + ((item) % ncot)) * (NWP * 4);                   \
+        const int wbase_ = (int)(((size_t)(cc) * ncot + ((item) % ncot)) * (NWP * 4) * 4);                  \
         _Pragma("unroll") for (int j = 0; j < WP; ++j) {                                                    \
-            const int w_ = tid + NT * j;                                                                 \
-            RW[j] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                            \
-            if (w_ < NWP && !(a.dbg & 2)) RW[j] = *(const f32x4*)(wsrc_ + w_ * 4);                          \
+            const int w_ = tid + NT * j;                                                                    \
+            RW[j] = ig_ld(rs_w, (w_ < NWP && !(a.dbg & 2)) ? wbase_ + w_ * 16 : IG_OOB);                    \
         }                                                                                                   \
-        const bool chan_ok = (cc) * 16 + part4 < a.Cin;                                                     \
-        _Pragma("unroll") for (int j = 0; j < IG_MAXP; ++j) {                                               \
-            R[j] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                             \
-            if (goff[j] >= 0 && chan_ok && !(a.dbg & 1)) R[j] = *(const f32x4*)(a.in + goff[j] + (cc) * 16); \
-        }                                                                                                   \
+        const int coff_ = ((cc) * 16 + part4 < a.Cin && !(a.dbg & 1)) ? (cc) * 64 : IG_OOB;                 \
+        _Pragma("unroll") for (int j = 0; j < IG_MAXP; ++j) R[j] = ig_ld(rs_in, goff[j] + coff_);           \
     }
 
 // epilogue of one finished item: D layout of 16x16x4: column (pixel) = lane&15, row (cout) = 4*(lane>>4)+j
@@ -201,15 +213,13 @@ _Pragma("unroll")  \
     constexpr int LPT = (IG_MAXP + WP + KS * KS - 1) / (KS * KS) < 2 ? 2 : (IG_MAXP + WP + KS * KS - 1) / (KS * KS);   // loads per tap
     constexpr int PPS = (NPIECE + KS * KS * MBW - 1) / (KS * KS * MBW);       // pieces per (tap, block) slot
     f32x4 pend[MBW][NB], pmask[MBW][NB];
-    int pend_ob[MBW];
-    int pend_co0 = 0;
+    int pend_ob[MBW], pend_cob[NB];          // byte offsets of the pending item's pixels / of this lane's cout quads (or IG_OOB)
     bool pend_valid = false;
     const bool vec = (a.Cout & 3) == 0;
     // data-gradient use (MASK): derivative of the activation that produced the forward input, from its saved output y:
-    // LeakyReLU / ReLU: y > 0 ? 1 : mslope; sigmoid: y (1 - y).  Wave-uniform selects, no per-element branching.
-    const float mslope = a.mask_act == ACT_LRELU ? a.slope : 0.f;
-    const bool msig = a.mask_act == ACT_SIGMOID, mnone = a.mask_act == ACT_NONE;
-#define IG_MASK_OF(y) (mnone ? 1.f : (msig ? (y) * (1.f - (y)) : ((y) > 0.f ? 1.f : mslope)))
+    // y > 0 ? 1 : mslope with mslope = slope (LeakyReLU), 0 (ReLU) or 1 (none).  One compare + select per element.
+    const float mslope = a.mask_act == ACT_LRELU ? a.slope : (a.mask_act == ACT_RELU ? 0.f : 1.f);
+#define IG_MASK_OF(y) ((y) > 0.f ? 1.f : mslope)
 
     unsigned long long tphase[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     const bool stamp = (a.dbg & 8) && a.dbgbuf;
@@ -252,16 +262,14 @@ _Pragma("unroll")  \
             for (int i = 0; i < MBW; ++i)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const int co = pend_co0 + nb * 16 + 4 * g;
-                    pmask[i][nb] = (f32x4){1.f, 1.f, 1.f, 1.f};
-                    if (pend_ob[i] >= 0 && co < a.Cout) pmask[i][nb] = *(const f32x4*)(a.ysave + pend_ob[i] + co);
+                    pmask[i][nb] = ig_ld(rs_ys, pend_ob[i] + pend_cob[nb]);      // out of range -> 0 -> the store is dropped too
                 }
         }
         // the prefetch of the next chunk is TRICKLED through the first taps (IG_LOADS_PER_TAP pieces per tap): issued
         // as one burst right after the barrier, the 8 waves would queue on the CU's address path for ~2.5k cycles
         const bool do_load = l_item < nitems;
-        const float* wsrc = a.wpk + ((size_t)l_cc * ncot + (l_item % ncot)) * (NWP * 4);
-        const bool chan_ok = l_cc * 16 + part4 < a.Cin;
+        const int wbase = (int)(((size_t)l_cc * ncot + (l_item % ncot)) * (NWP * 4) * 4);
+        const int coff = (l_cc * 16 + part4 < a.Cin && !(a.dbg & 1)) ? l_cc * 64 : IG_OOB;
 
         const bool last_chunk = (cc + 1 == nchunks);
         IG_STAMP(3)
@@ -286,14 +294,11 @@ _Pragma("unroll")  \
                         constexpr int zero = 0;
                         const int pj = tap * LPT + u + zero;
                         if (pj < IG_MAXP) {
-                            R[pj < IG_MAXP ? pj : 0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            if (goff[pj < IG_MAXP ? pj : 0] >= 0 && chan_ok && !(a.dbg & 1))
-                                R[pj < IG_MAXP ? pj : 0] = *(const f32x4*)(a.in + goff[pj < IG_MAXP ? pj : 0] + l_cc * 16);
+                            R[pj < IG_MAXP ? pj : 0] = ig_ld(rs_in, goff[pj < IG_MAXP ? pj : 0] + coff);
                         } else if (pj - IG_MAXP < WP) {
                             const int wj = pj - IG_MAXP < WP ? pj - IG_MAXP : 0;
                             const int w_ = tid + NT * wj;
-                            RW[wj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            if (w_ < NWP && !(a.dbg & 2)) RW[wj] = *(const f32x4*)(wsrc + w_ * 4);
+                            RW[wj] = ig_ld(rs_w, (w_ < NWP && !(a.dbg & 2)) ? wbase + w_ * 16 : IG_OOB);
                         }
                     }
                 }
@@ -320,15 +325,12 @@ _Pragma("unroll")  \
                         const int k = (tap * MBW + i) * PPS + pp + dummy;
                         if (k < NPIECE) {
                             const int pi = k / NB, pnb = k % NB;
-                            const int co = pend_co0 + pnb * 16 + 4 * g;
-                            if (pend_ob[pi] >= 0 && co < a.Cout && !(a.dbg & 4)) {
-                                f32x4 v = pend[pi][pnb];
-                                if (MASK) {
+                            f32x4 v = pend[pi][pnb];
+                            if (MASK) {
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] *= IG_MASK_OF(pmask[pi][pnb][e]);
-                                }
-                                *(f32x4*)(a.out + pend_ob[pi] + co) = v;
+                                for (int e = 0; e < 4; ++e) v[e] *= IG_MASK_OF(pmask[pi][pnb][e]);
                             }
+                            ig_st(rs_out, pend_ob[pi] + pend_cob[pnb], v);
                         }
                     }
                 }
@@ -345,10 +347,10 @@ _Pragma("unroll")  \
         if (vec) {
 #pragma unroll
             for (int i = 0; i < MBW; ++i) {
-                pend_ob[i] = -1;
+                pend_ob[i] = IG_OOB;
                 if (pix[i] >= 0) {
                     const int n = cn0 + (pix[i] >> 20), y = cy0 + ((pix[i] >> 10) & 1023), x = cx0 + (pix[i] & 1023);
-                    if (n < a.N && y < a.Ho && x < a.Wo) pend_ob[i] = ((n * a.Ho + y) * a.Wo + x) * a.Cout;
+                    if (n < a.N && y < a.Ho && x < a.Wo) pend_ob[i] = ((n * a.Ho + y) * a.Wo + x) * a.Cout * 4;
                 }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
@@ -359,7 +361,8 @@ _Pragma("unroll")  \
                     acc[i][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
-            pend_co0 = co0;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) pend_cob[nb] = (co0 + nb * 16 + 4 * g < a.Cout) ? (co0 + nb * 16 + 4 * g) * 4 : IG_OOB;
             pend_valid = true;
         } else {
             IG_EPILOGUE(cn0, cy0, cx0, co0)
@@ -373,21 +376,18 @@ _Pragma("unroll")  \
         cc = 0;
         IG_TILE_ORIGIN(c_item, cn0, cy0, cx0, co0)
     }
-    if (pend_valid && !(a.dbg & 4)) {            // last item of this workgroup: flush
+    if (pend_valid) {            // last item of this workgroup: flush
 #pragma unroll
         for (int i = 0; i < MBW; ++i)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const int co = pend_co0 + nb * 16 + 4 * g;
-                if (pend_ob[i] >= 0 && co < a.Cout) {
-                    f32x4 v = pend[i][nb];
-                    if (MASK) {
-                        const f32x4 ys = *(const f32x4*)(a.ysave + pend_ob[i] + co);
+                f32x4 v = pend[i][nb];
+                if (MASK) {
+                    const f32x4 ys = ig_ld(rs_ys, pend_ob[i] + pend_cob[nb]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= IG_MASK_OF(ys[e]);
-                    }
-                    *(f32x4*)(a.out + pend_ob[i] + co) = v;
+                    for (int e = 0; e < 4; ++e) v[e] *= IG_MASK_OF(ys[e]);
                 }
+                ig_st(rs_out, pend_ob[i] + pend_cob[nb], v);
             }
     }
     if (stamp && tid == 0) {
@@ -525,8 +525,13 @@ int aesr_launch_conv_igemm(const IgemmArgs& a_in, int KS, int NB, int MBW, hipSt
         aesr_set_error("conv_igemm: patch of %d pixels exceeds the staging capacity", PPc);
         return AESR_ERR_ARG;
     }
-    if ((size_t)a.N * a.H * a.W * a.Cin >= ((size_t)1 << 31) || (size_t)a.N * a.Ho * a.Wo * a.Cout >= ((size_t)1 << 31)) {
-        aesr_set_error("conv_igemm: tensors beyond 2^31 elements need 64-bit indexing (not built)");
+    // byte offsets are 32-bit buffer offsets and 0x70000000 marks "out of range": tensors must stay below that many bytes
+    if ((size_t)a.N * a.H * a.W * a.Cin >= (size_t)0x1C000000 || (size_t)a.N * a.Ho * a.Wo * a.Cout >= (size_t)0x1C000000) {
+        aesr_set_error("conv_igemm: tensors of 469M elements (1.75 GB) or more need 64-bit indexing (not built)");
+        return AESR_ERR_UNSUPPORTED;
+    }
+    if (a.ysave && a.mask_act == ACT_SIGMOID) {
+        aesr_set_error("conv_igemm: a sigmoid derivative mask is not fused into the data gradient (use aesr_act_bwd)");
         return AESR_ERR_UNSUPPORTED;
     }
     a.nitems = ceil_div(a.N, a.TI) * a.tiles_y * a.tiles_x * (a.CoutP / (16 * NB));
