@@ -80,19 +80,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // ---- per-thread staging slots (tile independent): slot k of this thread moves the float4 of (pixel, quad) ----
     // unit u = (k*256 + tid) >> 5 (a 32-lane group); pair j = u % PAIRS, pixel block = u / PAIRS; pixel = block*16 + (tid & 15),
     // quad = 2*j + ((tid >> 4) & 1)
+    // Global loads go through buffer descriptors: an out-of-range byte offset returns 0, so halo / tail / padded-channel
+    // slots need no exec masking and no zeroed registers; per slot the tile-independent part of the offset is kept.
+    constexpr int WG_OOB = 0x70000000;       // + any in-range offset stays beyond the tensor (host: tensors < 1.75 GB)
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((size_t)a.N * a.Ho * a.Wo * a.Cout * 4), 0x00020000);
     int xrc[NX], drc[ND];                          // (row << 16 | col) of the slot's pixel, or -1
+    int xrel[NX], drel[ND];                        // byte offset of the slot relative to the tile origin pixel, or WG_OOB
     const int qbit = (tid >> 4) & 1, u0 = tid >> 5;
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
         const int pix = ((k * 8 + u0) / XPAIRS) * 16 + (tid & 15);
         const int pr = pix / PWp, pc = pix - pr * PWp;
+        const int ci = ci0 + (2 * ((k * 8 + u0) % XPAIRS) + qbit) * 4;
         xrc[k] = pix < PP ? ((pr << 16) | pc) : -1;
+        xrel[k] = (pix < PP && ci < a.Cin) ? ((pr * a.W + pc) * a.Cin + ci) * 4 : WG_OOB;
     }
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
         const int pix = ((k * 8 + u0) / DPAIRS) * 16 + (tid & 15);
         const int r = pix / a.TW, c = pix - r * a.TW;
+        const int co = co0 + (2 * ((k * 8 + u0) % DPAIRS) + qbit) * 4;
         drc[k] = pix < TP ? ((r << 16) | c) : -1;
+        drel[k] = (pix < TP && co < a.Cout) ? ((r * a.Wo + c) * a.Cout + co) * 4 : WG_OOB;
     }
     f32x4 RX[NX], RD[ND];
     auto issue_loads = [&](int tile) {
@@ -100,21 +110,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int trem = tile - n * tpi;
         const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
         const int y0 = ty * a.TH, x0 = tx * a.TW;
+        // tile origin (may lie in the padding: the per-slot row / column checks decide)
+        const int xorg = ((n * a.H + y0 - a.pad) * a.W + (x0 - a.pad)) * a.Cin * 4;
+        const int dorg = ((n * a.Ho + y0) * a.Wo + x0) * a.Cout * 4;
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
-            RX[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int quad = 2 * ((k * 8 + u0) % XPAIRS) + qbit;
-            const int gy = y0 + (xrc[k] >> 16) - a.pad, gx = x0 + (xrc[k] & 0xffff) - a.pad, ci = ci0 + quad * 4;
-            if (xrc[k] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci < a.Cin)
-                RX[k] = *(const f32x4*)(a.x + (((size_t)n * a.H + gy) * a.W + gx) * a.Cin + ci);
+            const unsigned gy = (unsigned)(y0 + (xrc[k] >> 16) - a.pad), gx = (unsigned)(x0 + (xrc[k] & 0xffff) - a.pad);
+            const int off = (gy < (unsigned)a.H && gx < (unsigned)a.W) ? xorg + xrel[k] : WG_OOB;
+            RX[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
         }
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
-            RD[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int quad = 2 * ((k * 8 + u0) % DPAIRS) + qbit;
-            const int gy = y0 + (drc[k] >> 16), gx = x0 + (drc[k] & 0xffff), co = co0 + quad * 4;
-            if (drc[k] >= 0 && gy < a.Ho && gx < a.Wo && co < a.Cout)
-                RD[k] = *(const f32x4*)(a.dy + (((size_t)n * a.Ho + gy) * a.Wo + gx) * a.Cout + co);
+            const int gy = y0 + (drc[k] >> 16), gx = x0 + (drc[k] & 0xffff);
+            const int off = (gy < a.Ho && gx < a.Wo) ? dorg + drel[k] : WG_OOB;
+            RD[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, off, 0, 0));
         }
     };
 
@@ -159,32 +168,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         __builtin_amdgcn_sched_barrier(0);          // keep the prefetch loads ahead of the MFMA loop
         WG_STAMP(2)
         // ---- k loop: groups of 8 consecutive pixels of one row; lane (.,g) owns pixels c0+2g, c0+2g+1 (+ halo) ----
-        for (int r = 0; r < a.TH; ++r) {
-            for (int c0 = 0; c0 < a.TW; c0 += 8) {
-                const float2 dv = *(const float2*)(ldsD + dbase + r * TWS + c0);
+        // Explicit software pipeline, pinned with sched_barrier: the LDS reads of step s+1 (next tap row / ci block, or the
+        // first step of the next pixel group) are issued BEFORE the 2*KS MFMAs of step s.
+        {
+            constexpr int NSTEP = KS * CIBW;
+            const int gpr = a.TW >> 3, ngrp = a.TH * gpr;
+            int r = 0, cg = 0;
+            float2 dv = *(const float2*)(ldsD + dbase);
+            float2 e01 = *(const float2*)(ldsX + xbase0), e23 = e01;
+            if (KS > 1) e23 = *(const float2*)(ldsX + xbase0 + 2);
+            for (int gi = 0; gi < ngrp; ++gi) {
+                const int c0 = cg * 8;
+                int rn = r, cgn = cg + 1;
+                if (cgn == gpr) { cgn = 0; rn = r + 1; }
+                if (gi + 1 == ngrp) { rn = r; cgn = cg; }             // last group: re-read it (value unused, address stays inside the tile)
+                float2 dvn = dv;
 #pragma unroll
-                for (int ky = 0; ky < KS; ++ky) {
-#pragma unroll
-                    for (int i = 0; i < CIBW; ++i) {
-                        const float* xp = ldsX + xbase0 + i * 16 * PSX + (r + ky) * PWS + c0;
-                        float e[4];
-                        const float2 e01 = *(const float2*)xp;
-                        e[0] = e01.x;
-                        e[1] = e01.y;
-                        if (KS > 1) {
-                            const float2 e23 = *(const float2*)(xp + 2);
-                            e[2] = e23.x;
-                            e[3] = e23.y;
-                        }
-#pragma unroll
-                        for (int kx = 0; kx < KS; ++kx)      // pixel sub-step 0, then sub-step 1: same accumulator 3 MFMAs apart
-                            acc[ky * KS + kx][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[kx], dv.x, acc[ky * KS + kx][i], 0, 0, 0);
-#pragma unroll
-                        for (int kx = 0; kx < KS; ++kx)
-                            acc[ky * KS + kx][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[kx + 1], dv.y, acc[ky * KS + kx][i], 0, 0, 0);
+                for (int st_ = 0; st_ < NSTEP; ++st_) {
+                    const int ky = st_ / CIBW, i = st_ % CIBW;
+                    const float* xn;
+                    if (st_ + 1 < NSTEP) {
+                        const int kyn = (st_ + 1) / CIBW, in_ = (st_ + 1) % CIBW;
+                        xn = ldsX + xbase0 + in_ * 16 * PSX + (r + kyn) * PWS + c0;
+                    } else {
+                        xn = ldsX + xbase0 + rn * PWS + cgn * 8;
+                        dvn = *(const float2*)(ldsD + dbase + rn * TWS + cgn * 8);
                     }
+                    const float2 n01 = *(const float2*)xn;
+                    float2 n23 = n01;
+                    if (KS > 1) n23 = *(const float2*)(xn + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float e[4] = {e01.x, e01.y, e23.x, e23.y};
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx)      // pixel sub-step 0, then sub-step 1: same accumulator KS MFMAs apart
+                        acc[ky * KS + kx][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[kx], dv.x, acc[ky * KS + kx][i], 0, 0, 0);
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx)
+                        acc[ky * KS + kx][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[kx + 1], dv.y, acc[ky * KS + kx][i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    e01 = n01;
+                    e23 = n23;
                 }
                 accb += dv.x + dv.y;                  // bias gradient: this lane's share of column sum co = l15 (VALU, free beside the MFMAs)
+                dv = dvn;
+                r = rn;
+                cg = cgn;
             }
         }
         WG_STAMP(3)
@@ -299,6 +327,10 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
 
 // variant: 0 -> 32 ci x 32 co per workgroup; 1 -> 32 ci x 64 co
 int aesr_launch_conv_wgrad(const WgradArgs& a, int KS, int variant, hipStream_t st) {
+    if ((size_t)a.N * a.H * a.W * a.Cin >= (size_t)0x1C000000 || (size_t)a.N * a.Ho * a.Wo * a.Cout >= (size_t)0x1C000000) {
+        aesr_set_error("conv_wgrad: tensors of 469M elements (1.75 GB) or more need 64-bit indexing (not built)");
+        return AESR_ERR_UNSUPPORTED;
+    }
     if (a.TW % 8 != 0 || (a.PWS & 1) || (a.TWS & 1) || (a.PSX & 1) || (a.PSD & 1)) {
         aesr_set_error("conv_wgrad: TW=%d must be a multiple of 8 and strides even", a.TW);
         return AESR_ERR_ARG;
