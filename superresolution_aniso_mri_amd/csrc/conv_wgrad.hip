@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((size_t)a.N * a.Ho * a.Wo * a.Cout * 4), 0x00020000);
     int xrc[NX], drc[ND];                          // (row << 16 | col) of the slot's pixel, or -1
     int xrel[NX], drel[ND];                        // byte offset of the slot relative to the tile origin pixel, or WG_OOB
+    int xlds[NX], dlds[ND];                        // LDS float offset of the slot's (quad, pixel), or -1
     const int qbit = (tid >> 4) & 1, u0 = tid >> 5;
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int ci = ci0 + (2 * ((k * 8 + u0) % XPAIRS) + qbit) * 4;
         xrc[k] = pix < PP ? ((pr << 16) | pc) : -1;
         xrel[k] = (pix < PP && ci < a.Cin) ? ((pr * a.W + pc) * a.Cin + ci) * 4 : WG_OOB;
+        xlds[k] = pix < PP ? (2 * ((k * 8 + u0) % XPAIRS) + qbit) * 4 * PSX + pr * PWS + pc : -1;
     }
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int co = co0 + (2 * ((k * 8 + u0) % DPAIRS) + qbit) * 4;
         drc[k] = pix < TP ? ((r << 16) | c) : -1;
         drel[k] = (pix < TP && co < a.Cout) ? ((r * a.Wo + c) * a.Cout + co) * 4 : WG_OOB;
+        dlds[k] = pix < TP ? (2 * ((k * 8 + u0) % DPAIRS) + qbit) * 4 * PSD + r * TWS + c : -1;
     }
     f32x4 RX[NX], RD[ND];
     auto issue_loads = [&](int tile) {
@@ -142,9 +145,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         // ---- registers -> LDS, transposing to channel-major ----
 #pragma unroll
         for (int k = 0; k < NX; ++k)
-            if (xrc[k] >= 0) {
-                const int quad = 2 * ((k * 8 + u0) % XPAIRS) + qbit;
-                float* d = ldsX + quad * 4 * PSX + (xrc[k] >> 16) * PWS + (xrc[k] & 0xffff);
+            if (xlds[k] >= 0) {
+                float* d = ldsX + xlds[k];
                 d[0] = RX[k][0];
                 d[PSX] = RX[k][1];
                 d[2 * PSX] = RX[k][2];
@@ -152,9 +154,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
 #pragma unroll
         for (int k = 0; k < ND; ++k)
-            if (drc[k] >= 0) {
-                const int quad = 2 * ((k * 8 + u0) % DPAIRS) + qbit;
-                float* d = ldsD + quad * 4 * PSD + (drc[k] >> 16) * TWS + (drc[k] & 0xffff);
+            if (dlds[k] >= 0) {
+                float* d = ldsD + dlds[k];
                 d[0] = RD[k][0];
                 d[PSD] = RD[k][1];
                 d[2 * PSD] = RD[k][2];
