@@ -54,6 +54,17 @@ int aesr_conv2d_pack_many(const aesr_pack_job* jobs_host, int njobs, void* strea
 int aesr_conv2d_fwd(const float* in, const float* packed, const float* bias, float* out, int N, int H, int W, int Cin,
                     int Cout, int KS, int pad, int act, float slope, void* stream);
 
+/* The same with a caller-owned workspace that lets the planner split the input channels of under-filled layers (few, deep work
+ * items: VGG conv4/5 at 20x20 / 10x10) into extra work items + a fix-up pass.  aesr_conv2d_workspace_floats returns the size the
+ * plan of this shape wants (0: no split, workspace may be NULL).  For the data gradient pass the forward conv's N, H, W, Cin,
+ * Cout, KS, pad to aesr_conv2d_dgrad_workspace_floats.  Results equal the plain entry points up to fp32 summation order. */
+size_t aesr_conv2d_workspace_floats(int N, int H, int W, int Cin, int Cout, int KS, int pad);
+size_t aesr_conv2d_dgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int KS, int pad);
+int aesr_conv2d_fwd_ws(const float* in, const float* packed, const float* bias, float* out, float* workspace, int N, int H, int W,
+                       int Cin, int Cout, int KS, int pad, int act, float slope, void* stream);
+int aesr_conv2d_dgrad_ws(const float* dy, const float* packed_t, const float* x_saved, float* dx, float* workspace, int N, int H,
+                         int W, int Cin, int Cout, int KS, int pad, int mask_act, float slope, void* stream);
+
 /* dx = conv_transpose(dy, w) * act'(x_saved)            [same kernel on the transposed packing; Cout % 4 == 0]
  * dy is [N,Ho,Wo,Cout], dx is [N,H,W,Cin]; x_saved (may be NULL) is the saved OUTPUT of the activation that
  * produced the convolution's input, mask_act its code: fuses the LeakyReLU/ReLU backward of the previous layer. */

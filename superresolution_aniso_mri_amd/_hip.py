@@ -31,6 +31,10 @@ SIGNATURES = {
     "aesr_conv2d_pack": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "aesr_conv2d_pack_many": (c_int, [ctypes.POINTER(PackJob), c_int, P]),
     "aesr_conv2d_fwd": (c_int, [P, P, P, P] + [c_int] * 8 + [c_float, P]),
+    "aesr_conv2d_workspace_floats": (c_size_t, [c_int] * 7),
+    "aesr_conv2d_dgrad_workspace_floats": (c_size_t, [c_int] * 7),
+    "aesr_conv2d_fwd_ws": (c_int, [P, P, P, P, P] + [c_int] * 8 + [c_float, P]),
+    "aesr_conv2d_dgrad_ws": (c_int, [P, P, P, P, P] + [c_int] * 8 + [c_float, P]),
     "aesr_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 8 + [c_float, P]),
     "aesr_conv2d_wgrad_workspace_floats": (c_size_t, [c_int] * 7),
     "aesr_conv2d_wgrad": (c_int, [P, P, P, P, P] + [c_int] * 7 + [P]),

@@ -27,7 +27,7 @@ static void cout_padding(int Cout, int* CoutP, int* NB) {
     else { *CoutP = round_up(Cout, 64); *NB = 4; }
 }
 
-struct ConvPlan { int TI, TH, TW, NB, MBW, CinP, CoutP, NT; };
+struct ConvPlan { int TI, TH, TW, NB, MBW, CinP, CoutP, NT, ksplit; };
 static std::mutex g_plan_mu;
 static std::map<std::tuple<int, int, int, int, int, int>, ConvPlan> g_conv_plans;
 
@@ -89,10 +89,30 @@ static ConvPlan plan_conv(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
         int ti, th, tw;
         if (sscanf(e, "%d,%d,%d", &ti, &th, &tw) == 3) { p.TI = ti; p.TH = th < Ho ? th : Ho; p.TW = tw < Wo ? tw : Wo; }
     }
+    // K-split for layers whose work items under-fill the 256 persistent workgroups (VGG conv4/5 at 20x20 / 10x10): slices of
+    // the input channels become extra work items that write raw partial sums, a fix-up pass adds them (+bias, activation,
+    // mask).  Used only when the caller passes a workspace (aesr_conv2d_fwd_ws / _dgrad_ws).
+    p.ksplit = 1;
+    {
+        const long items = (long)ceil_div(N, p.TI) * ceil_div(Ho, p.TH) * ceil_div(Wo, p.TW) * ncout;
+        const int nch = p.CinP / 16, nblk = ceil_div(p.TI * p.TH * p.TW, 16);
+        const double chunk = ceil_div(nblk, 8) * 2.0 * p.NB * KS * KS * 4 * 32 + 4500.0;
+        const double out_bytes = (double)N * Ho * Wo * Cout * 4;
+        double bestt = 1e300;
+        for (int ks = 1; ks <= 4; ++ks) {
+            if (nch % ks != 0 || nch / ks < 4 || (Cout & 3)) continue;
+            if (ks > 1 && items * ks > 4 * 256) break;
+            const double rounds = (double)ceil_div((int)(items * ks), 256);
+            double t = rounds * ((nch / ks) * chunk + 3000.0);
+            if (ks > 1) t += (ks + 2) * out_bytes / 2000.0 + 12000.0;        // fix-up traffic at ~4 TB/s + a launch
+            if (t < bestt * 0.97) { bestt = t; p.ksplit = ks; }
+        }
+        if (const char* e = getenv("AESR_IGEMM_KSPLIT")) { const int k = atoi(e); if (k >= 1 && nch % k == 0) p.ksplit = k; }
+    }
     if (getenv("AESR_PLAN_DEBUG"))
-        fprintf(stderr, "[aesr plan] conv N=%d %dx%d Cin=%d Cout=%d KS=%d -> NT=%d TI=%d TH=%d TW=%d NB=%d nblk=%d items=%ld\n", N, Ho, Wo,
+        fprintf(stderr, "[aesr plan] conv N=%d %dx%d Cin=%d Cout=%d KS=%d -> NT=%d TI=%d TH=%d TW=%d NB=%d nblk=%d items=%ld ksplit=%d\n", N, Ho, Wo,
                 Cin, Cout, KS, p.NT, p.TI, p.TH, p.TW, p.NB, ceil_div(p.TI * p.TH * p.TW, 16),
-                (long)ceil_div(N, p.TI) * ceil_div(Ho, p.TH) * ceil_div(Wo, p.TW) * ncout);
+                (long)ceil_div(N, p.TI) * ceil_div(Ho, p.TH) * ceil_div(Wo, p.TW) * ncout, p.ksplit);
     g_conv_plans[key] = p;
     return p;
 }
@@ -193,14 +213,22 @@ int aesr_conv2d_pack(const float* w, float* packed, int Cout, int Cin, int KS, i
 }
 
 static int run_igemm(const float* in, const float* packed, const float* bias, const float* ysave, float* out, int N, int H,
-                     int W, int Cin, int Cout, int KS, int pad, int act, int mask_act, float slope, hipStream_t st) {
+                     int W, int Cin, int Cout, int KS, int pad, int act, int mask_act, float slope, float* workspace,
+                     hipStream_t st) {
     const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
     const ConvPlan p = plan_conv(N, Ho, Wo, Cin, Cout, KS);
     IgemmArgs a;
     a.in = in; a.wpk = packed; a.bias = bias; a.ysave = ysave; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = p.CinP; a.Cout = Cout; a.CoutP = p.CoutP; a.Ho = Ho; a.Wo = Wo; a.pad = pad;
     a.TI = p.TI; a.TH = p.TH; a.TW = p.TW; a.tiles_y = ceil_div(Ho, p.TH); a.tiles_x = ceil_div(Wo, p.TW);
-    a.act = act; a.mask_act = mask_act; a.slope = slope; a.dbgbuf = nullptr; a.NT = p.NT;
+    a.act = act; a.mask_act = mask_act; a.slope = slope; a.dbgbuf = nullptr; a.NT = p.NT; a.ksplit = 1;
+    if (workspace && p.ksplit > 1) {
+        // raw partial sums of the k slices -> workspace, then the fix-up pass (bias, activation, derivative mask)
+        a.ksplit = p.ksplit; a.out = workspace; a.bias = nullptr; a.ysave = nullptr; a.act = ACT_NONE; a.mask_act = ACT_NONE;
+        if (int e = aesr_launch_conv_igemm(a, KS, p.NB, p.MBW, st)) return e;
+        return aesr_launch_conv_ksplit_fixup(workspace, bias, ysave, out, (size_t)N * Ho * Wo * Cout, Cout, p.ksplit, act, mask_act,
+                                             slope, st);
+    }
     return aesr_launch_conv_igemm(a, KS, p.NB, p.MBW, st);
 }
 
@@ -237,7 +265,38 @@ int aesr_conv2d_fwd(const float* in, const float* packed, const float* bias, flo
     AESR_CHECK_ARG(in && packed && out && N > 0 && H > 0 && W > 0, "aesr_conv2d_fwd: null pointer or empty shape");
     AESR_CHECK_ARG(Cin % 4 == 0 && Cin > 0 && Cout > 0, "aesr_conv2d_fwd: Cin=%d must be a positive multiple of 4", Cin);
     AESR_CHECK_ARG((KS == 1 || KS == 3) && pad >= 0 && pad < KS, "aesr_conv2d_fwd: unsupported KS=%d pad=%d", KS, pad);
-    return run_igemm(in, packed, bias, nullptr, out, N, H, W, Cin, Cout, KS, pad, act, ACT_NONE, slope, (hipStream_t)stream);
+    return run_igemm(in, packed, bias, nullptr, out, N, H, W, Cin, Cout, KS, pad, act, ACT_NONE, slope, nullptr, (hipStream_t)stream);
+}
+
+size_t aesr_conv2d_workspace_floats(int N, int H, int W, int Cin, int Cout, int KS, int pad) {
+    const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
+    if (N <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || (KS != 1 && KS != 3)) return 0;
+    const ConvPlan p = plan_conv(N, Ho, Wo, Cin, Cout, KS);
+    return p.ksplit > 1 ? (size_t)p.ksplit * N * Ho * Wo * Cout : 0;
+}
+
+size_t aesr_conv2d_dgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int KS, int pad) {
+    // the data gradient is the forward kernel on dy [N,Ho,Wo,Cout] with Cout and Cin swapped and padding KS-1-pad
+    const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
+    return aesr_conv2d_workspace_floats(N, Ho, Wo, Cout, Cin, KS, KS - 1 - pad);
+}
+
+int aesr_conv2d_fwd_ws(const float* in, const float* packed, const float* bias, float* out, float* workspace, int N, int H, int W,
+                       int Cin, int Cout, int KS, int pad, int act, float slope, void* stream) {
+    AESR_CHECK_ARG(in && packed && out && N > 0 && H > 0 && W > 0, "aesr_conv2d_fwd_ws: null pointer or empty shape");
+    AESR_CHECK_ARG(Cin % 4 == 0 && Cin > 0 && Cout > 0, "aesr_conv2d_fwd_ws: Cin=%d must be a positive multiple of 4", Cin);
+    AESR_CHECK_ARG((KS == 1 || KS == 3) && pad >= 0 && pad < KS, "aesr_conv2d_fwd_ws: unsupported KS=%d pad=%d", KS, pad);
+    return run_igemm(in, packed, bias, nullptr, out, N, H, W, Cin, Cout, KS, pad, act, ACT_NONE, slope, workspace, (hipStream_t)stream);
+}
+
+int aesr_conv2d_dgrad_ws(const float* dy, const float* packed_t, const float* x_saved, float* dx, float* workspace, int N, int H,
+                         int W, int Cin, int Cout, int KS, int pad, int mask_act, float slope, void* stream) {
+    AESR_CHECK_ARG(dy && packed_t && dx && N > 0 && H > 0 && W > 0, "aesr_conv2d_dgrad_ws: null pointer or empty shape");
+    AESR_CHECK_ARG(Cout % 4 == 0 && Cin > 0 && Cout > 0, "aesr_conv2d_dgrad_ws: Cout=%d must be a positive multiple of 4", Cout);
+    AESR_CHECK_ARG((KS == 1 || KS == 3) && pad >= 0 && pad < KS, "aesr_conv2d_dgrad_ws: unsupported KS=%d pad=%d", KS, pad);
+    const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
+    return run_igemm(dy, packed_t, nullptr, x_saved, dx, N, Ho, Wo, Cout, Cin, KS, KS - 1 - pad, ACT_NONE, mask_act, slope, workspace,
+                     (hipStream_t)stream);
 }
 
 int aesr_conv2d_dgrad(const float* dy, const float* packed_t, const float* x_saved, float* dx, int N, int H, int W, int Cin,
@@ -247,7 +306,7 @@ int aesr_conv2d_dgrad(const float* dy, const float* packed_t, const float* x_sav
     AESR_CHECK_ARG((KS == 1 || KS == 3) && pad >= 0 && pad < KS, "aesr_conv2d_dgrad: unsupported KS=%d pad=%d", KS, pad);
     const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
     // dx = conv(dy [N,Ho,Wo,Cout], flipped w) with padding KS-1-pad -> output [N,H,W,Cin]
-    return run_igemm(dy, packed_t, nullptr, x_saved, dx, N, Ho, Wo, Cout, Cin, KS, KS - 1 - pad, ACT_NONE, mask_act, slope,
+    return run_igemm(dy, packed_t, nullptr, x_saved, dx, N, Ho, Wo, Cout, Cin, KS, KS - 1 - pad, ACT_NONE, mask_act, slope, nullptr,
                      (hipStream_t)stream);
 }
 

@@ -8,11 +8,14 @@ struct IgemmArgs {
     int N, H, W, Cin, CinP, Cout, CoutP, Ho, Wo, pad;
     int TI, TH, TW, tiles_y, tiles_x, nitems, dbg;
     int NT;          // threads per workgroup: 512 or 256
+    int ksplit;      // K-split slices (1 = off): raw partial sums go to slab ks of `out`, see conv_igemm.hip
     float* dbgbuf;   // debug stamps (nullptr in normal operation)
     int act, mask_act;
     float slope;
 };
 int aesr_launch_conv_igemm(const IgemmArgs& a, int KS, int NB, int MBW, hipStream_t st);
+int aesr_launch_conv_ksplit_fixup(const float* partial, const float* bias, const float* ysave, float* out, size_t nelem, int Cout,
+                                  int ksplit, int act, int mask_act, float slope, hipStream_t st);
 int aesr_launch_pack_weights(const float* w, float* p, int Cout, int Cin, int KS, int KinP, int NoutP, int TN, int transpose, hipStream_t st);
 
 #define PACK_MAX_JOBS 32

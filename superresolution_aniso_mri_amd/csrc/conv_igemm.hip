@@ -61,7 +61,10 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f32(IgemmArgs a) {
     const int PW = a.TW + KS - 1, PH = a.TH + KS - 1;
     const int PPI = PH * PW, PP = a.TI * PPI;
     const int TPI = a.TH * a.TW, TP = a.TI * TPI;
-    const int nchunks = a.CinP >> 4;
+    // K-split (a.ksplit > 1): a work item is (tile, cout tile, k slice); slice ks walks chunks [ks*nchunks, (ks+1)*nchunks) of the
+    // input channels and writes RAW partial sums to slab ks of the output buffer (the host then runs the fix-up kernel)
+    const int ksplit = a.ksplit, nchunks = (a.CinP >> 4) / ksplit;
+    const int slab_bytes = a.N * a.Ho * a.Wo * a.Cout * 4;
     constexpr int TN = 16 * NB;
     constexpr int NWP = KS * KS * 4 * TN;                 // 16-byte weight pieces per (chunk, cout tile)
     constexpr int WP = (NWP + NT - 1) / NT;         // ... per thread
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f32(IgemmArgs a) {
     constexpr int IG_OOB = 0x70000000;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (int)((size_t)KS * KS * a.CinP * a.CoutP * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (a.dbg & 4) ? 0 : (int)((size_t)a.N * a.Ho * a.Wo * a.Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (a.dbg & 4) ? 0 : (int)((size_t)a.ksplit * a.N * a.Ho * a.Wo * a.Cout * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_ys = __builtin_amdgcn_make_buffer_rsrc((void*)(MASK ? a.ysave : a.out), 0, (int)((size_t)a.N * a.Ho * a.Wo * a.Cout * 4), 0x00020000);
 
     // ---- position-independent maps (computed once) ------------------------------------------------------------
@@ -116,8 +119,9 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f32(IgemmArgs a) {
 
 #define IG_TILE_ORIGIN(item, n0, y0, x0, co0)                 \
     {                                                         \
-        int tile_ = (item) / ncot;                            \
-        co0 = ((item) - tile_ * ncot) * (16 * NB);            \
+        const int rest_ = (item) / ksplit;                    \
+        int tile_ = rest_ / ncot;                             \
+        co0 = (rest_ - tile_ * ncot) * (16 * NB);             \
         const int tx_ = tile_ % a.tiles_x;                    \
         tile_ /= a.tiles_x;                                   \
         const int ty_ = tile_ % a.tiles_y;                    \
@@ -142,12 +146,13 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f32(IgemmArgs a) {
     }
 #define IG_ISSUE_LOADS(item, cc)                                                                            \
     {                                                                                                       \
-        const int wbase_ = (int)(((size_t)(cc) * ncot + ((item) % ncot)) * (NWP * 4) * 4);                  \
+        const int gcc_ = ((item) % ksplit) * nchunks + (cc);                                                \
+        const int wbase_ = (int)(((size_t)gcc_ * ncot + (((item) / ksplit) % ncot)) * (NWP * 4) * 4);       \
         _Pragma("unroll") for (int j = 0; j < WP; ++j) {                                                    \
             const int w_ = tid + NT * j;                                                                    \
             RW[j] = ig_ld(rs_w, (w_ < NWP && !(a.dbg & 2)) ? wbase_ + w_ * 16 : IG_OOB);                    \
         }                                                                                                   \
-        const int coff_ = ((cc) * 16 + part4 < a.Cin && !(a.dbg & 1)) ? (cc) * 64 : IG_OOB;                 \
+        const int coff_ = (gcc_ * 16 + part4 < a.Cin && !(a.dbg & 1)) ? gcc_ * 64 : IG_OOB;                 \
         _Pragma("unroll") for (int j = 0; j < IG_MAXP; ++j) R[j] = ig_ld(rs_in, goff[j] + coff_);           \
     }
 
@@ -268,8 +273,9 @@ _Pragma("unroll")  \
         // the prefetch of the next chunk is TRICKLED through the first taps (IG_LOADS_PER_TAP pieces per tap): issued
         // as one burst right after the barrier, the 8 waves would queue on the CU's address path for ~2.5k cycles
         const bool do_load = l_item < nitems;
-        const int wbase = (int)(((size_t)l_cc * ncot + (l_item % ncot)) * (NWP * 4) * 4);
-        const int coff = (l_cc * 16 + part4 < a.Cin && !(a.dbg & 1)) ? l_cc * 64 : IG_OOB;
+        const int l_gcc = (l_item % ksplit) * nchunks + l_cc;
+        const int wbase = (int)(((size_t)l_gcc * ncot + ((l_item / ksplit) % ncot)) * (NWP * 4) * 4);
+        const int coff = (l_gcc * 16 + part4 < a.Cin && !(a.dbg & 1)) ? l_gcc * 64 : IG_OOB;
 
         const bool last_chunk = (cc + 1 == nchunks);
         IG_STAMP(3)
@@ -350,7 +356,7 @@ _Pragma("unroll")  \
                 pend_ob[i] = IG_OOB;
                 if (pix[i] >= 0) {
                     const int n = cn0 + (pix[i] >> 20), y = cy0 + ((pix[i] >> 10) & 1023), x = cx0 + (pix[i] & 1023);
-                    if (n < a.N && y < a.Ho && x < a.Wo) pend_ob[i] = ((n * a.Ho + y) * a.Wo + x) * a.Cout * 4;
+                    if (n < a.N && y < a.Ho && x < a.Wo) pend_ob[i] = ((n * a.Ho + y) * a.Wo + x) * a.Cout * 4 + (c_item % ksplit) * slab_bytes;
                 }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
@@ -503,6 +509,36 @@ static int launch_one(const IgemmArgs& a, hipStream_t st) {
     return AESR_OK;
 }
 
+// K-split fix-up: out = act(sum_ks partial[ks] + bias) * act'(ysave), 16 bytes per thread
+__global__ __launch_bounds__(256) void conv_ksplit_fixup_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                                const float* __restrict__ ysave, float* __restrict__ out, size_t n4,
+                                                                int Cout, int ksplit, int act, int mask_act, float slope) {
+    const size_t slab = n4 * 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 v = *(const f32x4*)(partial + i * 4);
+        for (int k = 1; k < ksplit; ++k) v += *(const f32x4*)(partial + k * slab + i * 4);
+        if (bias) v += *(const f32x4*)(bias + (i * 4) % Cout);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act, slope);
+        if (ysave) {
+            const f32x4 ys = *(const f32x4*)(ysave + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_output(ys[e], mask_act, slope);
+        }
+        *(f32x4*)(out + i * 4) = v;
+    }
+}
+
+int aesr_launch_conv_ksplit_fixup(const float* partial, const float* bias, const float* ysave, float* out, size_t nelem, int Cout,
+                                  int ksplit, int act, int mask_act, float slope, hipStream_t st) {
+    const size_t n4 = nelem / 4;
+    int grid = (int)((n4 + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(conv_ksplit_fixup_kernel, dim3(grid), dim3(256), 0, st, partial, bias, ysave, out, n4, Cout, ksplit, act, mask_act, slope);
+    AESR_LAUNCH_CHECK("conv_ksplit_fixup");
+    return AESR_OK;
+}
+
 int aesr_launch_conv_igemm(const IgemmArgs& a_in, int KS, int NB, int MBW, hipStream_t st) {
     IgemmArgs a = a_in;
     static int dbg = -1;
@@ -534,7 +570,13 @@ int aesr_launch_conv_igemm(const IgemmArgs& a_in, int KS, int NB, int MBW, hipSt
         aesr_set_error("conv_igemm: a sigmoid derivative mask is not fused into the data gradient (use aesr_act_bwd)");
         return AESR_ERR_UNSUPPORTED;
     }
-    a.nitems = ceil_div(a.N, a.TI) * a.tiles_y * a.tiles_x * (a.CoutP / (16 * NB));
+    if (a.ksplit < 1) a.ksplit = 1;
+    if (a.ksplit > 1 && ((a.CinP >> 4) % a.ksplit != 0 || a.bias || a.ysave || a.act != ACT_NONE || (a.Cout & 3) ||
+                         (size_t)a.ksplit * a.N * a.Ho * a.Wo * a.Cout >= (size_t)0x1C000000)) {
+        aesr_set_error("conv_igemm: invalid K-split launch (ksplit=%d)", a.ksplit);
+        return AESR_ERR_ARG;
+    }
+    a.nitems = ceil_div(a.N, a.TI) * a.tiles_y * a.tiles_x * (a.CoutP / (16 * NB)) * a.ksplit;
     if (a.TH + KS - 1 > 1023 || a.TW + KS - 1 > 1023 || a.TI > 1023) {
         aesr_set_error("conv_igemm: tile dimensions exceed the packed-coordinate range");
         return AESR_ERR_ARG;

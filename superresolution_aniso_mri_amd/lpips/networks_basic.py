@@ -190,8 +190,10 @@ class PNetLin(nn.Module):
                 continue
             c = convs[nconv]
             out = torch.empty((N, h, w, v), device=x.device)
-            check(lib.aesr_conv2d_fwd(ptr(cur), ptr(pk["fwd"][nconv]), ptr(c.bias), ptr(out), N, h, w, cin, v, 3, 1,
-                                      _hip.ACT_RELU, 0.0, stream()), "aesr_conv2d_fwd(vgg)")
+            nws = lib.aesr_conv2d_workspace_floats(N, h, w, cin, v, 3, 1)      # > 0: the small deep layers (conv4/5) get K-split
+            ws = torch.empty((nws,), device=x.device) if nws else None
+            check(lib.aesr_conv2d_fwd_ws(ptr(cur), ptr(pk["fwd"][nconv]), ptr(c.bias), ptr(out), ptr(ws), N, h, w, cin, v, 3, 1,
+                                         _hip.ACT_RELU, 0.0, stream()), "aesr_conv2d_fwd_ws(vgg)")
             cur, cin = out, v
             nconv += 1
             acts.append(cur)
@@ -247,9 +249,11 @@ class PNetLin(nn.Module):
             producer_is_pool = (n - 1) in tap_of           # conv n reads pool(tap layer n-1)
             mask = None if producer_is_pool else prev
             dxs = torch.empty((B, h, w, cv.in_channels), device=dev)
-            check(lib.aesr_conv2d_dgrad(ptr(g), ptr(pk["bwd"][n - 1]), ptr(mask), ptr(dxs), B, h, w, cv.in_channels,
-                                        cv.out_channels, 3, 1, _hip.ACT_RELU if mask is not None else 0, 0.0, stream()),
-                  "aesr_conv2d_dgrad(vgg)")
+            nws = lib.aesr_conv2d_dgrad_workspace_floats(B, h, w, cv.in_channels, cv.out_channels, 3, 1)
+            ws = torch.empty((nws,), device=dev) if nws else None
+            check(lib.aesr_conv2d_dgrad_ws(ptr(g), ptr(pk["bwd"][n - 1]), ptr(mask), ptr(dxs), ptr(ws), B, h, w, cv.in_channels,
+                                           cv.out_channels, 3, 1, _hip.ACT_RELU if mask is not None else 0, 0.0, stream()),
+                  "aesr_conv2d_dgrad_ws(vgg)")
             g = dxs
         raise AssertionError("unreachable")
 

@@ -88,6 +88,39 @@ def test_conv_fwd(hip, case, act):
     assert rel_l2(nchw(out), ref) < 1e-5
 
 
+@pytest.mark.parametrize("case", [(24, 20, 20, 512, 512, 4), (12, 10, 10, 512, 512, 2), (6, 10, 10, 256, 128, 4), (3, 9, 11, 128, 64, 2)])
+def test_conv_ksplit_workspace_paths(hip, case, monkeypatch):
+    """Under-filled deep layers (VGG conv4/5 shapes): the workspace entry points split the input channels into extra work
+    items + a fix-up pass.  Forward (bias + ReLU) and masked data gradient equal the unsplit kernels' results (1e-5)."""
+    N, H, W, cin, cout, ks_forced = case
+    monkeypatch.setenv("AESR_IGEMM_KSPLIT", str(ks_forced))
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(N, H, W, cin, generator=g).cuda()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    L = hip.lib
+    pf, pb = _pack(hip, w, 0), _pack(hip, w, 1)
+    ref = torch.empty(N, H, W, cout, device="cuda")
+    hip.check(L.aesr_conv2d_fwd(hip.ptr(x), hip.ptr(pf), hip.ptr(b), hip.ptr(ref), N, H, W, cin, cout, 3, 1, 2, 0.0, hip.stream()), "fwd")
+    nws = L.aesr_conv2d_workspace_floats(N, H, W, cin, cout, 3, 1)
+    assert nws == ks_forced * N * H * W * cout
+    ws = torch.empty(nws, device="cuda")
+    out = torch.full_like(ref, float("nan"))
+    hip.check(L.aesr_conv2d_fwd_ws(hip.ptr(x), hip.ptr(pf), hip.ptr(b), hip.ptr(out), hip.ptr(ws), N, H, W, cin, cout, 3, 1, 2, 0.0,
+                                   hip.stream()), "fwd_ws")
+    assert rel_l2(out, ref) < 1e-5
+    dy = torch.randn(N, H, W, cout, generator=g).cuda()
+    mask = torch.randn(N, H, W, cin, generator=g).cuda()
+    dref = torch.empty(N, H, W, cin, device="cuda")
+    hip.check(L.aesr_conv2d_dgrad(hip.ptr(dy), hip.ptr(pb), hip.ptr(mask), hip.ptr(dref), N, H, W, cin, cout, 3, 1, 2, 0.0, hip.stream()), "dgrad")
+    nwd = L.aesr_conv2d_dgrad_workspace_floats(N, H, W, cin, cout, 3, 1)
+    wsd = torch.empty(max(nwd, 1), device="cuda")
+    dx = torch.full_like(dref, float("nan"))
+    hip.check(L.aesr_conv2d_dgrad_ws(hip.ptr(dy), hip.ptr(pb), hip.ptr(mask), hip.ptr(dx), hip.ptr(wsd) if nwd else None, N, H, W, cin,
+                                     cout, 3, 1, 2, 0.0, hip.stream()), "dgrad_ws")
+    assert rel_l2(dx, dref) < 1e-5
+
+
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[4] % 4 == 0])
 @pytest.mark.parametrize("masked", [False, True])
 def test_conv_dgrad(hip, case, masked):
