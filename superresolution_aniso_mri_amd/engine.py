@@ -334,8 +334,10 @@ class SequentialRunner:
                                                     s.slope, stream()), "aesr_conv2d_cout1_fwd")
                 elif s.mfma_fwd:
                     _pb("conv_igemm_f32", 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
-                    check(lib.aesr_conv2d_fwd(ptr(cur), ptr(s.packed), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, s.ks,
-                                              s.pad, s.act, s.slope, stream()), "aesr_conv2d_fwd")
+                    nws = lib.aesr_conv2d_workspace_floats(N, H, W, s.cin, s.cout, s.ks, s.pad)    # > 0: few, deep work items
+                    ws = _empty((nws,), x) if nws else None
+                    check(lib.aesr_conv2d_fwd_ws(ptr(cur), ptr(s.packed), ptr(bias), ptr(out), ptr(ws), N, H, W, s.cin, s.cout,
+                                                 s.ks, s.pad, s.act, s.slope, stream()), "aesr_conv2d_fwd_ws")
                     _pe()
                 elif s.cin <= 4:
                     check(lib.aesr_conv2d_smallcin_fwd(ptr(cur), ptr(s.mod.weight), ptr(bias), None, ptr(out), N, H, W,
@@ -490,8 +492,10 @@ class SequentialRunner:
                                                          s.pad, 0, None, stream()), "aesr_conv2d_smallcin_dgrad")
                 elif s.cout % 4 == 0:
                     _pb("conv_igemm_f32", 2.0 * N * H * W * s.cin * s.ks * s.ks * s.cout)
-                    check(lib.aesr_conv2d_dgrad(ptr(g), ptr(s.packed_t), ptr(mask), ptr(dx), N, H, W, s.cin, s.cout, s.ks,
-                                                s.pad, mask_act, mslope, stream()), "aesr_conv2d_dgrad")
+                    nws = lib.aesr_conv2d_dgrad_workspace_floats(N, H, W, s.cin, s.cout, s.ks, s.pad)
+                    ws = _empty((nws,), g) if nws else None
+                    check(lib.aesr_conv2d_dgrad_ws(ptr(g), ptr(s.packed_t), ptr(mask), ptr(dx), ptr(ws), N, H, W, s.cin, s.cout,
+                                                   s.ks, s.pad, mask_act, mslope, stream()), "aesr_conv2d_dgrad_ws")
                     _pe()
                 elif s.cout == 1 and s.ks == 3 and s.pad == 1 and _thin_channels(s.cin):
                     wsf = _empty((9 * s.cin,), g)
