@@ -86,6 +86,50 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
         float s = 0;
         for (int j = 0; j < 8; ++j) s += acc[j][0];
         out[blockIdx.x * 512 + threadIdx.x] = s;
+    } else if constexpr (V >= 5 && V <= 9) {
+        // igemm-like chunk (NB = 4, MBW = 2): [barrier, 11 ds_write_b128, barrier, 18 block-taps x (ds_read_b128 + 16 MFMA + EXTRA)]
+        // EXTRA per block-tap: V5 none, V6 12 VALU, V7 12 VALU + 6 SALU + 1 uniform not-taken branch, V8 24 VALU, V9 like V7 + buffer load/store pair
+        f32x4 acc[8];
+        for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0, 0, 0, 0};
+        const float* base = lds + lane * 20;
+        f32x4 bq[4];
+        for (int j = 0; j < 4; ++j) bq[j] = (f32x4){b0 + j, b0 + 1, b0 + 2, b0 + 3};
+        f32x4 R = (f32x4){a0, a0, a0, a0};
+        int x0 = lane, x1 = lane * 3;
+        for (int it = 0; it < iters / 9; ++it) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 11; ++j) *(f32x4*)(lds + ((threadIdx.x + 512 * j) & 4095) * 4) = R;
+            __syncthreads();
+            f32x4 acur = *(const f32x4*)base;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    f32x4 anxt = *(const f32x4*)(base + ((tap * 2 + blk + 1) & 7) * 1280);
+                    if (V == 6 || V == 7 || V == 8 || V == 9) {
+#pragma unroll
+                        for (int e = 0; e < (V == 8 ? 24 : 12); ++e) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x0) : "v"(x1));
+                    }
+                    if (V == 7 || V == 9) {
+                        asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
+                        if (iters == 12345) x1 += 1;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[blk * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[j][r], acur[r], acc[blk * 4 + j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acur = anxt;
+                }
+            }
+            R = acc[0];
+            R[0] += (float)x0;
+        }
+        float s = 0;
+        for (int j = 0; j < 8; ++j) s += acc[j][0];
+        out[blockIdx.x * 512 + threadIdx.x] = s;
     } else {
         f32x16 acc[2];
         for (int j = 0; j < 2; ++j)
@@ -116,7 +160,7 @@ void run(const char* name, double flop_per_iter_per_wave, int grid = 1024) {
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    const double fl = flop_per_iter_per_wave * (V == 4 ? (iters / 9) * 9 : iters) * grid * 8;
+    const double fl = flop_per_iter_per_wave * (V >= 4 ? (iters / 9) * 9 : iters) * grid * 8;
     printf("%-44s %8.3f ms  %7.1f TFLOP/s\n", name, ms, fl / (ms * 1e-3) / 1e12);
     hipFree(out);
 }
@@ -130,5 +174,9 @@ int main() {
     run<2>("V2 at 1 wave-pair... grid 512 (2 WG/CU)", 32.0 * 2048, 512);
     run<4>("chunked: barriers + 6 ds_write + 288 MFMA, 4 waves/SIMD", 32.0 * 2048, 1024);
     run<4>("chunked: barriers + 6 ds_write + 288 MFMA, 2 waves/SIMD", 32.0 * 2048, 256);
+    run<5>("igemm-like NB4 MBW2 chunk, no extra, 2 waves/SIMD", 32.0 * 2048, 256);
+    run<6>("  + 12 VALU per block-tap", 32.0 * 2048, 256);
+    run<7>("  + 12 VALU + 6 s_nop + branch per block-tap", 32.0 * 2048, 256);
+    run<8>("  + 24 VALU per block-tap", 32.0 * 2048, 256);
     return 0;
 }
