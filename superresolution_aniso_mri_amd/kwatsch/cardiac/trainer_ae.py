@@ -33,7 +33,9 @@ class CombinedStepMixin(object):
                     d = d * mask[:d.size(0)].to(d.device)
                 return d.mean()
         if use_mask:
-            raise NotImplementedError("masked MSE synthesis loss is outside the ae_combined hot path of this build")
+            # reference :117-120: mean over ALL elements of mse(reduction='none') * mask (rarely used option: plain tensor ops)
+            m = mask[:synthesized.size(0)].to(synthesized.device)
+            return ((reference - synthesized) ** 2 * m).mean()
         return ops.mse_loss(reference, synthesized)
 
     _mask_inputs = True      # cardiac multiplies the images by the mask; brain multiplies the distances

@@ -106,3 +106,24 @@ def test_baseline_config_shapes_vs_oracle(tmp_path, name, B, size, width, latent
     for (k, a), (_, b) in zip(tr.model.state_dict().items(), oracle.state_dict().items()):
         if a.dtype.is_floating_point:
             assert float((a.cpu() - b).abs().max()) <= 2.5e-5 + 1e-5 * float(b.abs().max()), k
+
+
+def test_masked_mse_synthesis_loss(tmp_path):
+    """--get_masks with the MSE synthesis loss (kwatsch/cardiac/trainer_ae.py:117-120): mean(mse_none * mask), in a full
+    training step and as a value against the same expression on the CPU."""
+    from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    torch.manual_seed(0)
+    tr = get_trainer_dynamic(_args(tmp_path, get_masks=True))
+    mask = (torch.rand(3, 1, 32, 32, generator=torch.Generator().manual_seed(1)) > 0.5).float()
+    ref = torch.rand(3, 1, 32, 32).cuda()
+    syn = torch.rand(3, 1, 32, 32).cuda().requires_grad_(True)
+    loss = tr.get_extra_image_loss(ref, syn, mask=mask)
+    want = ((ref.cpu() - syn.detach().cpu()) ** 2 * mask).mean()
+    assert abs(float(loss.detach()) - float(want)) < 1e-6 * float(want)
+    loss.backward()
+    assert float(syn.grad.abs().sum()) > 0
+    batch = synthetic_batch(3, 32, 32, seed=4)
+    batch["loss_mask"] = mask
+    tr.train(batch)
+    assert np.isfinite(tr.losses["loss_ae"][-1])
