@@ -219,6 +219,20 @@ int aesr_act_bwd(const float* dout, const float* y, float* dpre, size_t n, int a
 int aesr_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* state, size_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, void* stream);
 
+/* ---- on-device batch assembly + augmentation of the training triplets (train_cardiac_aesr.py:83-96, datasets/
+ * shared_transforms.py:48-120,224-254,297-363,366-447, datasets/ACDC/data4d_simple.py:327-355) ------------------------------
+ * One descriptor per sample (HOST array, read during the call; B <= 64 per call): the slices z_from / z_to / z_between of the
+ * [Z][H][W] volume at float offset vol_off inside `volumes` are cropped at (oy, ox) (may reach into the zero padding),
+ * passed through 1/(1+exp(gain*(cutoff - v))), rotated by k*90 degrees (np.rot90) and written to image[b], image[B+b]
+ * ([2B,1,width,width]) and between[b] ([B,1,width,width]). */
+typedef struct aesr_triplet_desc {
+    long long vol_off;
+    int H, W, z_from, z_to, z_between, oy, ox, k;
+    float gain, cutoff;
+} aesr_triplet_desc;
+int aesr_triplet_assemble(const float* volumes, const aesr_triplet_desc* desc_host, int B, int width, float* image,
+                          float* between, void* stream);
+
 /* ---- validation metrics on the device (evaluate/metrics.py:111-194: skimage structural_similarity / peak_signal_noise_ratio
  * slice by slice) -------------------------------------------------------------------------------------------------------
  * a, b: [Z][H][W] fp32.  ssim[Z], mse[Z]: fp64 device arrays (mean SSIM with a uniform win x win window, sample covariance,

@@ -298,15 +298,55 @@ def gen_ae_standard_blocks():
         np.savez_compressed(os.path.join(OUT, "ae_standard_blocks_%s.npz" % tag), **rec)
 
 
+def gen_augmentation():
+    """The reference's ACDC training transforms (train_cardiac_aesr.py:83-96) on synthetic triplets: inputs, the seed of the
+    numpy RandomState the transforms draw from, and the outputs.  datasets/shared_transforms.py needs cv2 / batchgenerators /
+    torchvision at import time only (elastic transforms this path never builds): stubbed."""
+    for name in ("cv2", "batchgenerators", "batchgenerators.transforms"):
+        if name not in sys.modules:
+            _stub(name)
+    _stub("batchgenerators.transforms.spatial_transforms", SpatialTransform=object)
+    _stub("batchgenerators.transforms.abstract_transforms", Compose=object)
+    if "torchvision" not in sys.modules:
+        tv = _stub("torchvision")
+        tv.transforms = _stub("torchvision.transforms")
+    import datasets.shared_transforms as st
+    rec = {}
+    cases = {"a": (3, (54, 64), 40, 32, 11), "b": (4, (35, 38), 40, 32, 12), "c": (2, (40, 40), 40, 40, 13),
+             "d": (3, (25, 58), 46, 16, 14)}
+    for tag, (n, (H, W), aug, width, seed) in cases.items():
+        g = np.random.RandomState(1000 + seed)
+        rs = np.random.RandomState(seed)
+        chain = [st.AdjustToPatchSize((aug, aug)), st.CenterCrop((aug, aug)), st.RandomCrop(width, rs=rs), st.RandomIntensity(rs=rs),
+                 st.RandomRotation(rs)]
+        ins, outs = [], []
+        for _ in range(n):
+            trip = g.rand(3, H, W).astype(np.float32)
+            sample = {"image": trip.copy()}
+            for t in chain:
+                sample = t(sample)
+            ins.append(trip)
+            outs.append(np.ascontiguousarray(sample["image"]).astype(np.float32))
+        rec["%s/in" % tag] = np.stack(ins)
+        rec["%s/out" % tag] = np.stack(outs)
+        rec["%s/cfg" % tag] = np.array([aug, width, seed], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "augment_acdc.npz"), **rec)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "augment":
+        import_reference()
+        gen_augmentation()
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "ae_standard":
         import_reference()
         gen_ae_standard_blocks()
         return
     av, avs, avm, nb = import_reference()
     gen_ae_standard_blocks()
+    gen_augmentation()
     gen_ae_small(av, avs, avm)
     m = gen_ae_init(av)
     gen_ae_acdc_probe(m)

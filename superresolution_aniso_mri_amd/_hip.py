@@ -18,6 +18,12 @@ IP = ctypes.POINTER(c_int)
 FP = ctypes.POINTER(c_float)
 DP = ctypes.POINTER(c_double)     # host array of doubles
 
+class TripletDesc(ctypes.Structure):
+    """aesr_triplet_desc of include/aesr_hip.h"""
+    _fields_ = [("vol_off", ctypes.c_longlong), ("H", c_int), ("W", c_int), ("z_from", c_int), ("z_to", c_int), ("z_between", c_int),
+                ("oy", c_int), ("ox", c_int), ("k", c_int), ("gain", c_float), ("cutoff", c_float)]
+
+
 class PackJob(ctypes.Structure):
     """aesr_pack_job of include/aesr_hip.h"""
     _fields_ = [("w", c_void_p), ("packed", c_void_p), ("Cout", c_int), ("Cin", c_int), ("KS", c_int), ("transpose", c_int)]
@@ -74,6 +80,7 @@ SIGNATURES = {
     "aesr_mse_fwd": (c_int, [P, P, P, P, c_size_t, P]),
     "aesr_mse_bwd": (c_int, [P, P, P, P, c_size_t, P]),
     "aesr_act_bwd": (c_int, [P, P, P, c_size_t, c_int, c_float, P]),
+    "aesr_triplet_assemble": (c_int, [P, ctypes.POINTER(TripletDesc), c_int, c_int, P, P, P]),
     "aesr_ssim_workspace_doubles": (c_size_t, [c_int, c_int, c_int]),
     "aesr_ssim_mse": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_double, c_double, c_double, P]),
     "aesr_adam_step": (c_int, [P, P, P, P, P, c_size_t] + [c_float] * 5 + [P]),

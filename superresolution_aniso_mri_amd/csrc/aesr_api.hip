@@ -658,6 +658,23 @@ int aesr_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, 
     return aesr_launch_adam(p, g, exp_avg, exp_avg_sq, state, n, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream);
 }
 
+int aesr_triplet_assemble(const float* volumes, const aesr_triplet_desc* desc_host, int B, int width, float* image,
+                          float* between, void* stream) {
+    AESR_CHECK_ARG(volumes && desc_host && image && between && width > 0, "aesr_triplet_assemble: null pointer or empty shape");
+    AESR_CHECK_ARG(B >= 1 && B <= TRIPLET_MAX, "aesr_triplet_assemble: B=%d must be 1..%d per call", B, TRIPLET_MAX);
+    TripletTable t;
+    memset(&t, 0, sizeof(t));
+    for (int b = 0; b < B; ++b) {
+        const aesr_triplet_desc& s = desc_host[b];
+        AESR_CHECK_ARG(s.H > 0 && s.W > 0 && s.vol_off >= 0 && s.z_from >= 0 && s.z_to >= 0 && s.z_between >= 0 && s.k >= 0 && s.k <= 3,
+                       "aesr_triplet_assemble: bad descriptor %d", b);
+        TripletDesc& d = t.d[b];
+        d.vol_off = s.vol_off; d.H = s.H; d.W = s.W; d.z_from = s.z_from; d.z_to = s.z_to; d.z_between = s.z_between;
+        d.oy = s.oy; d.ox = s.ox; d.k = s.k; d.gain = s.gain; d.cutoff = s.cutoff;
+    }
+    return aesr_launch_triplet_assemble(volumes, t, B, width, image, between, (hipStream_t)stream);
+}
+
 size_t aesr_ssim_workspace_doubles(int Z, int H, int W) { return (size_t)Z * ceil_div(H, 16) * ceil_div(W, 16) * 2; }
 
 int aesr_ssim_mse(const float* a, const float* b, double* workspace, double* ssim, double* mse, int Z, int H, int W, int win,

@@ -141,4 +141,8 @@ int aesr_launch_resample2(const float* x, const float* gout, const float* xsave,
                           int backward, int mask_act, float slope, hipStream_t st);
 int aesr_launch_ssim_mse(const float* a, const float* b, double* partial, double* ssim, double* mse, int Z, int H, int W, int win,
                          double data_range, double k1, double k2, hipStream_t st);
+#define TRIPLET_MAX 64
+struct TripletDesc { long long vol_off; int H, W, z_from, z_to, z_between, oy, ox, k; float gain, cutoff; };
+struct TripletTable { TripletDesc d[TRIPLET_MAX]; };
+int aesr_launch_triplet_assemble(const float* vol, const TripletTable& t, int B, int W, float* image, float* between, hipStream_t st);
 int aesr_launch_s2d(const float* x, float* out, int N, int H, int W, int C, int inverse, hipStream_t st);

@@ -50,6 +50,8 @@ def build_parser():
     # ---- additive (MI355X build) ----
     a("--synthetic", action="store_true", help="train on synthetic triplets (no dataset on disk needed)")
     a("--synthetic_size", type=int, default=None, help="H=W of the synthetic slices (default: --width)")
+    a("--volumes_dir", type=str, default=None, help="train on the volumes (.npy [Z,H,W] / [T,Z,H,W], .nii(.gz), .mha, .mhd) of this "
+                                                  "directory: device-resident cache + on-device triplet assembly / augmentation")
     a("--iters_per_epoch", type=int, default=50, help="iterations per epoch with --synthetic")
     a("--vgg_weights", type=str, default=None, help="local torchvision vgg16 state_dict for LPIPS (offline)")
     a("--use_step_graph", action="store_true", help="capture the training step in a HIP graph")

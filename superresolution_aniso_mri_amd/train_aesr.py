@@ -58,11 +58,11 @@ def main(argv=None, brain=False):
     args, args_dict = parse_args(argv)
     cfg = NetworkConfig(args_dict["model"], dataset=args_dict["dataset"], ae_class=args_dict["ae_class"])
     args_dict = merge_args_architecture(args_dict, cfg.architecture)
-    if not args_dict.get("synthetic"):
+    if not args_dict.get("synthetic") and not args_dict.get("volumes_dir"):
         raise NotImplementedError(
-            "dataset '{}' needs the reference's SimpleITK/NIfTI readers, which are outside this build's hot path; run with "
-            "--synthetic (synthetic triplets in the same batch layout) or feed trainer.train() from your own loader".format(
-                args_dict["dataset"]))
+            "the per-dataset readers of the reference (datasets/*) are outside this build's hot path; run with --volumes_dir DIR "
+            "(volumes as .npy / .nii / .mha: on-device triplet assembly + augmentation), --synthetic (synthetic triplets in the "
+            "same batch layout) or feed trainer.train() from your own loader (dataset '{}')".format(args_dict["dataset"]))
     dp = DataParallelContext()
     if str(args_dict["device"]).startswith("cuda") and dp.world > 1:
         args_dict["device"] = "cuda:%d" % dp.local_rank
@@ -76,8 +76,21 @@ def main(argv=None, brain=False):
     size = args_dict.get("synthetic_size") or args_dict["width"]
     B = args_dict["batch_size"]
 
+    augmenter = None
+    if args_dict.get("volumes_dir"):
+        # device-resident volume cache + ONE kernel per batch (data_device.py); every rank draws the same global batch from
+        # the same RandomState and keeps its own triplets, so the step sees the batch a single process would see
+        from .data_device import TripletAugmenter, load_volume_dir
+        augmenter = TripletAugmenter(load_volume_dir(args_dict["volumes_dir"]), args_dict["width"],
+                                     args_dict.get("aug_patch_size") or args_dict["width"],
+                                     rs=np.random.RandomState(args_dict["seed"]), device=args_dict["device"])
+        step = max(2, int(args_dict.get("slice_step") or 2))
+
     def make_batch(seed, n):
-        b = synthetic_batch(n, size, size, seed=seed, brain=brain)
+        if augmenter is not None:
+            b = augmenter.next_batch(n, step=step)
+        else:
+            b = synthetic_batch(n, size, size, seed=seed, brain=brain)
         return shard_batch(b, dp.rank, dp.world) if dp.active else b
 
     trainer = get_trainer_dynamic(args_dict, model_file=args_dict["model_filename"])

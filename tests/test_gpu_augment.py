@@ -1,0 +1,72 @@
+"""-m gpu: on-device triplet assembly + augmentation (aesr_triplet_assemble, data_device.TripletAugmenter) against the outputs of
+the reference's own transform classes (tests/golden/augment_acdc.npz) and the oracle's numpy restatement.  Tolerance 2e-6
+(float32 exp in the intensity curve; everything else is index arithmetic)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_augmenter_reproduces_reference_transform_outputs(tag):
+    from superresolution_aniso_mri_amd.data_device import TripletAugmenter
+    rec = dict(np.load(os.path.join(GOLDEN, "augment_acdc.npz")))
+    aug, width, seed = [int(v) for v in rec[tag + "/cfg"]]
+    vols = list(rec[tag + "/in"])                                  # every sample is its own 3-slice "volume"
+    ta = TripletAugmenter(vols, width, aug, rs=np.random.RandomState(seed))
+    batch = ta.assemble([(i, 0, 1, 2) for i in range(len(vols))])   # draws the transform parameters in sample order
+    want = rec[tag + "/out"]
+    B = len(vols)
+    assert tuple(batch["image"].shape) == (2 * B, 1, width, width) and tuple(batch["slice_between"].shape) == (B, 1, width, width)
+    img, btw = batch["image"].cpu().numpy(), batch["slice_between"].cpu().numpy()
+    assert np.abs(img[:B, 0] - want[:, 0]).max() < 2e-6            # all "from" slices first
+    assert np.abs(img[B:, 0] - want[:, 1]).max() < 2e-6            # then all "to" slices
+    assert np.abs(btw[:, 0] - want[:, 2]).max() < 2e-6
+
+
+def test_random_batches_match_oracle_pipeline():
+    from oracle import augment_oracle as ao
+    from superresolution_aniso_mri_amd.data_device import TripletAugmenter
+    g = np.random.RandomState(5)
+    vols = [g.rand(9, 70, 64).astype(np.float32), g.rand(12, 40, 90).astype(np.float32), g.rand(7, 48, 48).astype(np.float32)]
+    ta = TripletAugmenter(vols, width=32, aug_patch_size=48, rs=np.random.RandomState(77))
+    ref_rs = np.random.RandomState(77)
+    for _ in range(3):
+        B = 70                                                     # > 64: two launches
+        trips, samples = [], []
+        for _ in range(B):                                         # mirror next_batch's draws on the reference RandomState
+            vid = int(ref_rs.randint(0, len(vols)))
+            sid = int(ref_rs.randint(0, vols[vid].shape[0]))
+            other = __import__("superresolution_aniso_mri_amd.data_device", fromlist=["x"]).get_random_adjacent_slice(sid, vols[vid].shape[0], ref_rs, 2)
+            zb = (sid + other) // 2
+            zf, zt = (sid, other) if ref_rs.choice([0, 1]) == 0 else (other, sid)
+            trips.append((vid, zf, zt, zb))
+        for vid, zf, zt, zb in trips:
+            samples.append(ao.augment_triplet(vols[vid][[zf, zt, zb]], 48, 32, ref_rs)[0])
+        want = ao.assemble_batch(samples)
+        got = ta.next_batch(B, step=2)
+        assert np.abs(got["image"].cpu().numpy() - want["image"]).max() < 2e-6
+        assert np.abs(got["slice_between"].cpu().numpy() - want["slice_between"]).max() < 2e-6
+        assert float(got["alpha_from"][0]) == 0.5
+
+
+def test_assembled_batch_trains():
+    from superresolution_aniso_mri_amd.data_device import TripletAugmenter
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    from superresolution_aniso_mri_amd.networks.net_config import NetworkConfig
+    args = dict(model="ae_combined", dataset="ACDC", device="cuda", lr=1e-4, weight_decay=0.0, epochs=2, width=32, latent_width=8, depth=8,
+                latent=16, ex_loss_weight1=0.05, use_percept_loss=False, get_masks=False, use_loss_annealing=False,
+                use_extra_latent_loss=False, epoch_threshold=0, ae_class="VanillaACAI", image_mix_loss_func="mse")
+    for k, v in NetworkConfig("ae_combined", dataset="ACDC").architecture.items():
+        args.setdefault(k, v)
+    torch.manual_seed(0)
+    tr = get_trainer_dynamic(args)
+    g = np.random.RandomState(1)
+    ta = TripletAugmenter([g.rand(10, 50, 60).astype(np.float32) for _ in range(4)], width=32, aug_patch_size=40)
+    for _ in range(3):
+        tr.train(ta.next_batch(4), keep_predictions=False)
+    assert np.isfinite(tr.losses["loss_ae"][-1])

@@ -45,6 +45,24 @@ def test_train_then_generate(tmp_path):
     assert np.array_equal(back.array, hr)
 
 
+def test_train_from_volume_directory(tmp_path):
+    """--volumes_dir: NIfTI + npy volumes -> device-resident cache -> on-device triplet assembly / augmentation -> training."""
+    from superresolution_aniso_mri_amd import train_aesr, volume_io
+    data = tmp_path / "vols"
+    data.mkdir()
+    g = np.random.RandomState(3)
+    v = (g.rand(9, 44, 52) * 1200).astype(np.float32)
+    volume_io.write_volume(data / "p1.nii.gz", volume_io.Volume(v, (1.4, 1.4, 8.0), "npy", {}), v, (1.4, 1.4, 8.0))
+    np.save(str(data / "p2.npy"), g.rand(2, 8, 40, 40).astype(np.float32))          # 4-D: two frames
+    out = str(tmp_path / "expers")
+    tr = train_aesr.main(["--dataset=ACDC", "--model=ae_combined", "--batch_size=4", "--test_batch_size=4", "--latent=16",
+                          "--latent_width=8", "--width=32", "--depth=8", "--downsample_steps=2", "--epochs=2", "--lr=0.001",
+                          "--ex_loss_weight1=0.05", "--exper_id=v1", "--output_dir=" + out, "--volumes_dir=" + str(data),
+                          "--aug_patch_size=40", "--iters_per_epoch=3", "--image_mix_loss_func=mse", "--epoch_threshold=0"])
+    assert tr.iters == 1 + 6 and np.isfinite(tr.mean_losses["loss_ae"][-1])
+    assert os.path.isfile(os.path.join(out, "v1", "models", "2.models"))
+
+
 def test_config1_mnist_shaped_step_vs_oracle():
     from oracle import ae_oracle, lpips_oracle, step_oracle
     from superresolution_aniso_mri_amd.data_synth import synthetic_batch

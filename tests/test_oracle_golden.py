@@ -162,3 +162,18 @@ def test_ae_standard_blocks_oracle_vs_reference(tag):
     assert np.allclose(x.grad.numpy(), rec["dx"], rtol=1e-4, atol=1e-7)
     for k, p in params.items():
         assert np.allclose(p.grad.numpy(), rec["grad/" + k], rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_augmentation_oracle_vs_reference_transforms(tag):
+    """oracle/augment_oracle.py (pad, centre crop, random crop, sigmoid intensity, rot90; random numbers in the reference's order)
+    reproduces the outputs of the reference's transform classes bit for bit (tests/golden/augment_acdc.npz)."""
+    from oracle import augment_oracle as ao
+    rec = dict(np.load(os.path.join(GOLDEN, "augment_acdc.npz")))
+    aug, width, seed = [int(v) for v in rec[tag + "/cfg"]]
+    rs = np.random.RandomState(seed)
+    outs = [ao.augment_triplet(t, aug, width, rs)[0] for t in rec[tag + "/in"]]
+    assert np.array_equal(np.stack(outs), rec[tag + "/out"])
+    batch = ao.assemble_batch(outs)
+    B = len(outs)
+    assert batch["image"].shape == (2 * B, 1, width, width) and np.array_equal(batch["image"][B:, 0], rec[tag + "/out"][:, 1])
