@@ -21,10 +21,16 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 # algorithmic conv FLOPs per training step (SURVEY.md section 8a / BASELINE.md section 2), B=12, 160x160, scales 2
-STEP_GFLOP = {"c2": 330.8, "c3": 894.5}
+STEP_GFLOP = {"c2": 330.8, "c3": 894.5, "c4": 2223.5, "c5": 1524.4}
+# BASELINE configs[3], configs[4] on ONE rank (secondary numbers; the headline metric is quoted on c2): name -> (dataset, B, H, width, latent_width)
+BRAIN = {"c4": ("OASIS", 16, 220, 64, 16), "c5": ("dHCP", 8, 256, 256, 64)}
 # of which the 32->32 3x3 convolution behind the stem (fwd on 48 images, dgrad + wgrad on 36) is folded with the 1x1 stem into
 # one bandwidth-bound 1->32 convolution and no longer runs on the matrix cores (csrc/conv_thin.hip)
-STEM_FOLDED_GFLOP = 58.05
+STEM_FOLDED_GFLOP = 58.05      # = 7*B * (H+2)^2 * 32*32*9*2 flop at B=12, H=160
+
+
+def stem_folded_gflop(B, H):
+    return 7.0 * B * (H + 2) ** 2 * 32 * 32 * 9 * 2 / 1e9
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 
 
@@ -35,7 +41,10 @@ def build_args(config, device):
                 get_masks=False, use_loss_annealing=False, use_extra_latent_loss=False, epoch_threshold=500,
                 ae_class="VanillaACAI", downsample_steps=2, seed=892372,
                 image_mix_loss_func="mse" if config == "c2" else "perceptual", vgg_weights="synthetic-hash")
-    for k, v in NetworkConfig("ae_combined", dataset="ACDC").architecture.items():
+    if config in BRAIN:
+        ds, B, _, width, lw = BRAIN[config]
+        args.update(dataset=ds, batch_size=B, width=width, latent_width=lw, ex_loss_weight1=0.001)
+    for k, v in NetworkConfig("ae_combined", dataset=args["dataset"]).architecture.items():
         args.setdefault(k, v)
     return args
 
@@ -66,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", choices=["c2", "c3"], default="c2")
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--triplets", type=int, default=12, help="global batch in triplets (12 = the BASELINE workload; other values are for experiments only)")
@@ -86,6 +95,8 @@ def main():
     device = "cuda:%d" % local_rank
     dp = DataParallelContext(device=device)
     B, H = opt.triplets, 160
+    if opt.config in BRAIN:
+        B, H = BRAIN[opt.config][1], BRAIN[opt.config][2]
     torch.manual_seed(892372)
     trainer = get_trainer_dynamic(build_args(opt.config, device))
     if dp.active:
@@ -97,7 +108,7 @@ def main():
     # a small pool of distinct batches, sharded by triplet and resident in HBM before the timed region
     pool = []
     for i in range(4):
-        b = synthetic_batch(B, H, H, seed=892372 + i)
+        b = synthetic_batch(B, H, H, seed=892372 + i, brain=opt.config in BRAIN)
         if dp.active:
             b = shard_batch(b, dp.rank, dp.world)
         pool.append({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items()})
@@ -143,7 +154,7 @@ def main():
         # HBM-side bytes per launch of the same kernel: PMC counters cannot be read from inside this process; they come from the
         # committed rocprofv3 --pmc passes of this very command (scripts/pmc_traffic.py -> profiles/), N=1 and B=12 only
         tpath = os.path.join(ROOT, "profiles", "r01_%s_hbm_traffic.json" % opt.config)
-        if opt.gpus == 1 and B == 12 and os.path.exists(tpath):
+        if opt.gpus == 1 and B == 12 and opt.config in ("c2", "c3") and os.path.exists(tpath):
             tk = json.load(open(tpath))["kernels"]
             ig = [v for name, v in tk.items() if "conv_igemm_f32" in name]
             nl = sum(v["launches_per_step"] for v in ig)
@@ -153,14 +164,17 @@ def main():
 
     if dp.rank != 0:
         return
-    executed = STEP_GFLOP[opt.config] - (STEM_FOLDED_GFLOP if engine.FUSE_STEM else 0.0)
+    executed = STEP_GFLOP[opt.config] - (stem_folded_gflop(B, H) if engine.FUSE_STEM else 0.0)
     line = {
-        "metric": "training slices/sec (ae_combined, 160x160, latent=128)", "value": round(value, 1), "unit": "slices/s",
+        "metric": "training slices/sec (ae_combined, %dx%d, latent=128)" % (H, H), "value": round(value, 1), "unit": "slices/s",
         "n_gpus": opt.gpus, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "ACDC synthetic 12x(3x1x160x160) triplets, ae_combined latent=128 depth=32 scales=2, "
-                               + ("MSE synthesis loss (BASELINE configs[1])" if opt.config == "c2"
-                                  else "LPIPS-VGG synthesis loss lambda=0.05, synthetic backbone weights (BASELINE configs[2])"),
+        "config": {"workload": ("ACDC synthetic 12x(3x1x160x160) triplets, ae_combined latent=128 depth=32 scales=2, "
+                                + ("MSE synthesis loss (BASELINE configs[1])" if opt.config == "c2"
+                                   else "LPIPS-VGG synthesis loss lambda=0.05, synthetic backbone weights (BASELINE configs[2])"))
+                   if opt.config not in BRAIN else
+                   "%s synthetic %dx(3x1x%dx%d) triplets on one rank, ae_combined latent=128 depth=32, LPIPS-VGG synthesis loss lambda=0.001, "
+                   "synthetic backbone weights (BASELINE configs[%d])" % (BRAIN[opt.config][0], B, H, H, 3 if opt.config == "c4" else 4),
                    "global_batch_triplets": B, "slices_per_step": 3 * B, "parallelism": "dp%d" % opt.gpus,
                    "init": "reference Initializer, seed 892372, random weights",
                    "launch": "captured HIP graph replay" if use_graph else "host launches"},
