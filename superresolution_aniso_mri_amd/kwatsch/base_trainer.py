@@ -174,11 +174,17 @@ class BaseTrainer(object):
     def _to_device(self, t):
         return t.to(self.args["device"]).float()
 
-    def _run_eval(self, model, fn, x, eval):
+    def _run_eval(self, model, fn, x, eval, upscale=1):
         model.train(not eval)
         if eval:
+            # eval-mode BatchNorm makes results independent of the batch composition: big batches are cut so that no
+            # activation tensor of a pass exceeds the kernels' 32-bit offset range (reference: chunk_size=16 host loop)
+            full = x.shape[-2] * upscale * x.shape[-1] * upscale
+            n_max = max(1, (1 << 28) // (full * 64))
             with torch.no_grad():
-                return fn(x)
+                if x.shape[0] <= n_max:
+                    return fn(x)
+                return torch.cat([fn(x[i:i + n_max]) for i in range(0, x.shape[0], n_max)], dim=0)
         return fn(x)
 
     def predict(self, x, eval=True, chunk_size=16, clear_cache=False, **kwargs):
@@ -190,7 +196,11 @@ class BaseTrainer(object):
 
     def decode(self, z, eval=True, clear_cache=False, chunk_size=16, **kwargs):
         model = self._use_sr_model(kwargs.get("use_sr_model", False))
-        return self._run_eval(model, model.decode, self._to_device(z), eval)
+        scales = getattr(model, "scales", None)
+        if scales is None:
+            from ..networks.acai_vanilla import num_scales
+            scales = num_scales(self.args)
+        return self._run_eval(model, model.decode, self._to_device(z), eval, upscale=1 << int(scales))
 
     # ---- validation (reference :67-99) -----------------------------------------------------------------------------
     def validate(self, validation_batch, image_dict=None, frame_id=8, generate_images=True):
