@@ -108,3 +108,52 @@ def test_step_graph_replay_equals_eager():
     for (k, a), (_, b) in zip(eager.model.state_dict().items(), graphed.model.state_dict().items()):
         assert torch.equal(a, b), k
     assert float(graphed.opt_ae.dev_state[0]) == 6.0
+
+
+@pytest.mark.parametrize("loss", ["mse", "perceptual"])
+def test_twenty_steps_track_the_oracle(loss):
+    """20 consecutive training steps (lr 1e-4, distinct batches) on the HIP trainer and on the CPU oracle from the same start:
+    loss curve within 1e-3 (MSE) / 1e-2 (LPIPS synthesis loss) relative at every step (Adam turns summation-order noise in near-zero gradients into +-lr parameter
+    differences, so the two fp32 trajectories separate slowly; measured 3e-4 after 20 steps), BatchNorm running variances
+    within 1e-2 and means within 2 % of a standard deviation, reconstruction SSIM within 1e-3 (north_star), parameter drift bounded by the Adam step size."""
+    from oracle import ae_oracle, lpips_oracle, step_oracle
+    from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    from superresolution_aniso_mri_amd.networks.net_config import NetworkConfig
+    cfg = dict(width=32, latent_width=8, depth=8, latent=16, colors=1, use_batchnorm=True, use_sigmoid=True)
+    lr = 1e-4
+    args = dict(model="ae_combined", dataset="ACDC", device="cuda", lr=lr, weight_decay=0.0, epochs=10, ex_loss_weight1=0.05,
+                use_percept_loss=False, get_masks=False, use_loss_annealing=False, use_extra_latent_loss=False, epoch_threshold=100,
+                ae_class="VanillaACAI", image_mix_loss_func=loss, vgg_weights="synthetic-hash", **cfg)
+    for k, v in NetworkConfig("ae_combined", dataset="ACDC").architecture.items():
+        args.setdefault(k, v)
+    torch.manual_seed(3)
+    tr = get_trainer_dynamic(args)
+    oracle = ae_oracle.OracleAE(cfg, init=False).load_state_dict({k: v.detach().cpu() for k, v in tr.model.state_dict().items()})
+    kw = {}
+    if loss == "perceptual":
+        lin = np.load(os.path.join(os.path.dirname(__file__), "..", "superresolution_aniso_mri_amd", "lpips", "weights", "v0.1", "vgg_lin.npz"))
+        kw = dict(vgg_sd=lpips_oracle.hash_vgg16_state(), lin_w=[torch.from_numpy(lin["lin%d" % k]).reshape(1, -1, 1, 1) for k in range(5)])
+    ost = step_oracle.OracleStep(oracle, lr=lr, ex_loss_weight1=0.05, image_mix_loss_func=loss, **kw)
+    worst = 0.0
+    for step in range(20):
+        batch = synthetic_batch(4, 32, 32, seed=100 + step)
+        tr.train(batch, keep_predictions=(step == 19))
+        ref = ost.train(batch["image"], batch["slice_between"])
+        got = tr.losses["loss_ae"][-1]
+        worst = max(worst, abs(got - ref["loss_ae"]) / abs(ref["loss_ae"]))
+    assert worst < (1e-3 if loss == "mse" else 1e-2), worst     # measured: 3e-4 (mse), 4e-3 (LPIPS term: steeper in the weights)
+    sd = tr.model.state_dict()
+    for k, v in oracle.buffers.items():
+        if k.endswith("running_var"):
+            assert rel_l2(sd[k], v) < 1e-2, k
+        elif k.endswith("running_mean"):       # means sit near zero: compare in units of the channel's standard deviation
+            std = oracle.buffers[k.replace("running_mean", "running_var")].sqrt()
+            assert float(((sd[k].cpu() - v).abs() / std).max()) < 2e-2, k
+        elif "num_batches" in k:
+            assert int(sd[k]) == int(v)
+    out = tr.train_predictions["reconstruction"]
+    d_ssim = abs(step_oracle.ssim(out.numpy(), batch["image"].numpy()) - step_oracle.ssim(ref["out"].numpy(), batch["image"].numpy()))
+    assert d_ssim < 1e-3
+    for k, p in tr.model.named_parameters():
+        assert float((p.detach().cpu() - oracle.params[k].detach()).abs().max()) <= 20 * 2 * lr + 1e-6, k     # <= 2 lr per step
