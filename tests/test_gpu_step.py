@@ -157,3 +157,31 @@ def test_twenty_steps_track_the_oracle(loss):
     assert d_ssim < 1e-3
     for k, p in tr.model.named_parameters():
         assert float((p.detach().cpu() - oracle.params[k].detach()).abs().max()) <= 20 * 2 * lr + 1e-6, k     # <= 2 lr per step
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 36, 52), (5, 44, 28), (2, 64, 64)])
+def test_ragged_batch_shapes_vs_oracle(B, H, W):
+    """One triplet, odd batch counts and non-square slices (sizes that leave partial tiles in every kernel): one training step of
+    the HIP trainer against the CPU oracle (losses 2e-5, synthesised slices 1e-5)."""
+    from oracle import ae_oracle, step_oracle
+    from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    from superresolution_aniso_mri_amd.networks.net_config import NetworkConfig
+    cfg = dict(width=32, latent_width=8, depth=16, latent=32, colors=1, use_batchnorm=True, use_sigmoid=True)
+    args = dict(model="ae_combined", dataset="ACDC", device="cuda", lr=1e-4, weight_decay=0.0, epochs=10, ex_loss_weight1=0.05,
+                use_percept_loss=False, get_masks=False, use_loss_annealing=False, use_extra_latent_loss=False, epoch_threshold=100,
+                ae_class="VanillaACAI", image_mix_loss_func="mse", **cfg)
+    for k, v in NetworkConfig("ae_combined", dataset="ACDC").architecture.items():
+        args.setdefault(k, v)
+    torch.manual_seed(B * 100 + H)
+    tr = get_trainer_dynamic(args)
+    oracle = ae_oracle.OracleAE(cfg, init=False).load_state_dict({k: v.detach().cpu() for k, v in tr.model.state_dict().items()})
+    ost = step_oracle.OracleStep(oracle, lr=1e-4, ex_loss_weight1=0.05, image_mix_loss_func="mse")
+    batch = synthetic_batch(B, H, W, seed=B + W)
+    tr.train(batch)
+    ref = ost.train(batch["image"], batch["slice_between"])
+    for key in ("loss_ae", "loss_ae_dist_extra", "loss_latent_1"):
+        assert abs(tr.losses[key][-1] - ref[key]) <= 2e-5 * abs(ref[key]), key
+    assert tuple(tr.train_predictions["reconstruction"].shape) == (2 * B, 1, H, W)
+    assert rel_l2(tr.train_predictions["reconstruction"], ref["out"]) < 1e-5
+    assert rel_l2(tr.train_predictions["slice_inbetween_mix"], ref["s_mix"]) < 1e-5
