@@ -70,18 +70,23 @@ class AEBaseTrainer(BaseTrainer):
             self.opt_sched_ae.step()
 
     # ---- HIP-graph capture of the whole step (forward, backward, Adam) ---------------------------------------------
-    def enable_step_graph(self, eager_steps=3):
+    def enable_step_graph(self, eager_steps=3, dp_segments=False):
         """Replay the training step from ONE captured HIP graph (no per-kernel host launches).  The first ``eager_steps``
-        calls still run eagerly (allocator / plan caches warm up), then the step is captured once per input signature."""
+        calls still run eagerly (allocator / plan caches warm up), then the step is captured once per input signature.
+        ``dp_segments``: under data parallel capture the step as a chain of graphs cut at the (eager) collectives
+        (parallel.SegmentedStepGraph) instead of launching every kernel from the host."""
         self._graph_enabled = True
+        self._graph_dp = bool(dp_segments)
         self._graph_eager_left = int(eager_steps)
         self._graphs = {}
 
     def _graph_ok(self, keep_predictions, eval_mode):
         if not getattr(self, "_graph_enabled", False) or keep_predictions or eval_mode:
             return False
-        if self.opt_sched_ae is not None or (self.dp is not None and self.dp.active) or self.args.get("get_masks"):
-            return False                       # per-step learning rates / collectives / masks are not captured
+        if self.opt_sched_ae is not None or self.args.get("get_masks"):
+            return False                       # per-step learning rates / masks are not captured
+        if self.dp is not None and self.dp.active and not getattr(self, "_graph_dp", False):
+            return False                       # collectives: only through the segmented graph (enable_step_graph(dp_segments=True))
         if self._graph_eager_left > 0:
             self._graph_eager_left -= 1
             return False
@@ -93,8 +98,22 @@ class AEBaseTrainer(BaseTrainer):
         g = self._graphs.get(sig)
         if g is None:
             static = {k: dev_batch[k].clone() for k in keys}
-            graph = torch.cuda.CUDAGraph()
             sink = {}
+            if self.dp is not None and self.dp.active:
+                from ..parallel import SegmentedStepGraph
+                graph = SegmentedStepGraph()
+                self.dp.segments = graph
+                self._capture_sink = sink
+                try:
+                    graph.capture(lambda: self._step_core(static, False))      # runs the step once (segment by segment)
+                finally:
+                    self._capture_sink = None
+                    self.dp.segments = None
+                self._graphs[sig] = (graph, static, sink)
+                for k, v in sink.items():
+                    self.losses[k].append(v.detach().clone())
+                return
+            graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             with torch.cuda.graph(graph):
                 self._capture_sink = sink

@@ -15,6 +15,68 @@ import torch
 import torch.distributed as dist
 
 
+class SegmentedStepGraph(object):
+    """The data-parallel step as a CHAIN of HIP graphs cut at every collective.
+
+    Capturing an RCCL collective into a graph is not possible on this stack (the ProcessGroupNCCL watchdog queries an event
+    while the stream is capturing and the process aborts: scripts/nccl_smoke.py), so the collectives stay eager: during the
+    capture step every ``cut(fn)`` ends the running capture, replays that segment (its results are needed now), runs the
+    collective ``fn`` eagerly and begins the next segment.  Later steps replay segment i, then call collective i on the very
+    tensor it was recorded with (kept alive here; all segments share one memory pool, so addresses repeat).
+    Capture mode is "relaxed": segments end on the autograd thread and the watchdog thread may query events meanwhile."""
+
+    def __init__(self):
+        self.graphs, self.collectives = [], []
+        self._cur, self._pool = None, None
+        self.capturing = False
+
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()          # one memory pool shared by all segments
+        g.capture_begin(pool=self._pool, capture_error_mode="relaxed")
+        self._cur = g
+
+    def _end(self):
+        self._cur.capture_end()
+        self._cur.replay()
+        self.graphs.append(self._cur)
+        self._cur = None
+
+    def capture(self, fn):
+        """Run ``fn()`` (the whole step) once, recording it as graph segments; collectives must go through ``cut``."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            self.capturing = True
+            try:
+                self._begin()
+                fn()
+                self._end()
+            finally:
+                self.capturing = False
+                if self._cur is not None:          # an exception inside a segment: close the capture before propagating
+                    try:
+                        self._cur.capture_end()
+                    except Exception:              # noqa: BLE001
+                        pass
+                    self._cur = None
+        torch.cuda.current_stream().wait_stream(side)
+
+    def cut(self, fn):
+        self._end()
+        fn()
+        self.collectives.append(fn)
+        self._begin()
+
+    def replay(self):
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < len(self.collectives):
+                self.collectives[i]()
+
+
 class DataParallelContext(object):
 
     def __init__(self, backend=None, device=None):
@@ -29,21 +91,37 @@ class DataParallelContext(object):
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
         self.weight = 1.0
         self.global_B = None
+        self.segments = None            # a SegmentedStepGraph while a step is being captured
+        # rehearsal switch: treat a single process as "data parallel" (collectives over a group of one) so that the
+        # NCCL call pattern, incl. the segmented step graph, can be exercised on a one-GPU box
+        self._force = os.environ.get("AESR_FORCE_DP", "0") == "1"
+        if self._force and self.world == 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            dist.init_process_group(backend=backend, rank=0, world_size=1)
 
     @property
     def active(self):
-        return self.world > 1
+        return self.world > 1 or self._force
 
     def _all_reduce(self, t, op=None):
         """In-place all-reduce; with the gloo backend (CPU tests, single-GPU rehearsals) device tensors are staged through
         the host, with nccl (= RCCL over xGMI) they are reduced in place on the device."""
         op = op or dist.ReduceOp.SUM
-        if t.is_cuda and dist.get_backend() == "gloo":
-            h = t.detach().cpu()
-            dist.all_reduce(h, op=op)
-            t.copy_(h)
+
+        def run():
+            if t.is_cuda and dist.get_backend() == "gloo":
+                h = t.detach().cpu()
+                dist.all_reduce(h, op=op)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=op)
+
+        if self.segments is not None and self.segments.capturing:
+            self.segments.cut(run)          # eager, between two graph segments; replayed on this same tensor later
         else:
-            dist.all_reduce(t, op=op)
+            run()
 
     def shard_range(self, B):
         return (B * self.rank) // self.world, (B * (self.rank + 1)) // self.world

@@ -31,7 +31,7 @@ def _args(mix):
     return a
 
 
-def _worker(rank, world, port, B, mix, out):
+def _worker(rank, world, port, B, mix, out, graph=False, steps=2):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import warnings
     warnings.simplefilter("ignore")
@@ -44,7 +44,9 @@ def _worker(rank, world, port, B, mix, out):
     tr = get_trainer_dynamic(_args(mix))
     dp.attach(tr)
     dp.set_batch(B)
-    for step in range(2):
+    if graph:
+        tr.enable_step_graph(eager_steps=1, dp_segments=True)      # step 0 eager, step 1 captured segment by segment, then replays
+    for step in range(steps):
         tr.train(shard_batch(synthetic_batch(B, 32, 32, seed=40 + step, brain=True), rank, world), keep_predictions=False)
     if rank == 0:
         torch.save({"sd": {k: v.cpu() for k, v in tr.model.state_dict().items()},
@@ -79,3 +81,22 @@ def test_two_ranks_equal_single_process(tmp_path, mix):
         # two Adam steps at lr 1e-3: identical up to summation order (sign noise of ~0 gradients allowed on a few elements)
         assert float(diff.max()) <= 2 * 2 * 1e-3 + 1e-6, k
         assert float((diff > 1e-4 + 1e-3 * b.abs()).double().mean()) <= 0.03, k
+
+
+def test_segmented_step_graph_equals_host_launched_data_parallel(tmp_path):
+    """Data parallel with the step captured as a chain of HIP graphs cut at the (eager) collectives
+    (parallel.SegmentedStepGraph) == the host-launched data-parallel step: 5 steps (1 eager, 1 capture, 3 replays), two ranks
+    on one GPU, losses and final weights."""
+    B = 3
+    outs = []
+    for graph in (False, True):
+        out = str(tmp_path / ("dp_%d.pt" % graph))
+        mp.spawn(_worker, args=(2, _free_port(), B, "mse", out, graph, 5), nprocs=2, join=True)
+        outs.append(torch.load(out))
+    eager, seg = outs
+    np.testing.assert_allclose(seg["loss"], eager["loss"], rtol=1e-6)
+    for k, v in eager["sd"].items():
+        if v.dtype.is_floating_point:
+            assert float((seg["sd"][k].double() - v.double()).abs().max()) <= 1e-6 + 1e-5 * float(v.abs().max()), k
+        else:
+            assert int(seg["sd"][k]) == int(v)
