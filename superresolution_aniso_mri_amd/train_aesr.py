@@ -97,6 +97,9 @@ def main(argv=None, brain=False):
     if dp.active:
         dp.attach(trainer)
         dp.set_batch(B)
+    if args_dict.get("use_step_graph"):
+        # single process: one HIP graph per step; data parallel: graph segments between the eager collectives
+        trainer.enable_step_graph(dp_segments=dp.active)
     trainer.init_tensorboard(args_dict["output_dir"])
     validation_batch = make_batch(args_dict["seed"] - 1, args_dict["test_batch_size"])
     num_it_per_epoch = args_dict["iters_per_epoch"]
