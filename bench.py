@@ -71,6 +71,11 @@ def cpu_baseline(B, H, steps=3):
 
 
 def main():
+    # stdout must carry exactly ONE line (the JSON): libraries print banners there (RCCL prints its version block on the first
+    # collective), so file descriptor 1 points at stderr for the whole run and the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -191,7 +196,8 @@ def main():
         line["roofline"] = roofline
     if opt.gpus == 1 and not opt.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(B, H)
-    print(json.dumps(line))
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
 
 if __name__ == "__main__":
