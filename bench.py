@@ -98,6 +98,8 @@ def main():
     if opt.gpus > 1 and world != opt.gpus:
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (opt.gpus, opt.gpus))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("AESR_SINGLE_DEVICE") == "1":       # rehearsal on a one-GPU box: every rank on cuda:0 (with AESR_DIST_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     dp = DataParallelContext(device=device)
@@ -170,6 +172,7 @@ def main():
                 roofline["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_%s_hbm_traffic.json)" % opt.config
 
     if dp.rank != 0:
+        dp.shutdown()
         return
     executed = STEP_GFLOP[opt.config] - (stem_folded_gflop(B, H) if engine.FUSE_STEM else 0.0)
     line = {
@@ -198,6 +201,7 @@ def main():
         line["cpu_baseline"] = cpu_baseline(B, H)
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    dp.shutdown()
 
 
 if __name__ == "__main__":

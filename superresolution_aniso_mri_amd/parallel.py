@@ -87,7 +87,9 @@ class DataParallelContext(object):
         if self.world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            # AESR_DIST_BACKEND=gloo: rehearsal of the N-rank launch on a box with fewer GPUs than ranks (RCCL refuses two ranks
+            # on one device); production = nccl (RCCL over xGMI)
+            backend = backend or os.environ.get("AESR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
         self.weight = 1.0
         self.global_B = None
@@ -194,6 +196,14 @@ class DataParallelContext(object):
     def barrier(self):
         if self.active:
             dist.barrier()
+
+    def shutdown(self):
+        """Tear the process group down (quiet exit under torch.distributed.run)."""
+        if dist.is_available() and dist.is_initialized():
+            try:
+                dist.destroy_process_group()
+            except Exception:              # noqa: BLE001
+                pass
 
     def max_over_ranks(self, v):
         if not self.active:
