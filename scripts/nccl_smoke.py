@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """RCCL sanity on one GPU (world_size 1): the collectives, dtypes and call pattern of parallel.DataParallelContext, eager and
-captured in a HIP graph.  Run: python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 scripts/nccl_smoke.py"""
+captured in a HIP graph (CAPTURE_MODE=global|thread_local|relaxed).  Run: python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 scripts/nccl_smoke.py"""
 import os
 import time
 
@@ -30,7 +30,9 @@ try:
         for _ in range(3):
             dist.all_reduce(a)
     torch.cuda.current_stream().wait_stream(s)
-    with torch.cuda.graph(g):
+    mode = os.environ.get("CAPTURE_MODE", "global")
+    print("capture mode", mode, flush=True)
+    with torch.cuda.graph(g, capture_error_mode=mode):
         a.mul_(2.0)
         dist.all_reduce(a)
         b.add_(1.0)

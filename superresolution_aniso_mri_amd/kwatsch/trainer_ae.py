@@ -70,13 +70,21 @@ class AEBaseTrainer(BaseTrainer):
             self.opt_sched_ae.step()
 
     # ---- HIP-graph capture of the whole step (forward, backward, Adam) ---------------------------------------------
-    def enable_step_graph(self, eager_steps=3, dp_segments=False):
+    def enable_step_graph(self, eager_steps=3, dp_segments=False, dp_mode=None):
         """Replay the training step from ONE captured HIP graph (no per-kernel host launches).  The first ``eager_steps``
         calls still run eagerly (allocator / plan caches warm up), then the step is captured once per input signature.
-        ``dp_segments``: under data parallel capture the step as a chain of graphs cut at the (eager) collectives
-        (parallel.SegmentedStepGraph) instead of launching every kernel from the host."""
+        Under data parallel ``dp_mode`` selects how the collectives are handled:
+          "whole"    -- the RCCL collectives are captured into the one step graph (capture mode "thread_local": the
+                        ProcessGroupNCCL watchdog thread may query events while this thread captures; nccl backend only);
+          "segments" -- (= ``dp_segments=True``) a chain of graphs cut at the collectives, which stay eager
+                        (parallel.SegmentedStepGraph; any backend);
+          None       -- every kernel is launched from the host."""
+        if dp_mode is None and dp_segments:
+            dp_mode = "segments"
+        if dp_mode not in (None, "whole", "segments"):
+            raise ValueError("dp_mode must be None, 'whole' or 'segments', got %r" % (dp_mode,))
         self._graph_enabled = True
-        self._graph_dp = bool(dp_segments)
+        self._graph_dp = dp_mode
         self._graph_eager_left = int(eager_steps)
         self._graphs = {}
 
@@ -86,7 +94,7 @@ class AEBaseTrainer(BaseTrainer):
         if self.opt_sched_ae is not None or self.args.get("get_masks"):
             return False                       # per-step learning rates / masks are not captured
         if self.dp is not None and self.dp.active and not getattr(self, "_graph_dp", False):
-            return False                       # collectives: only through the segmented graph (enable_step_graph(dp_segments=True))
+            return False                       # collectives: only with an explicit enable_step_graph(dp_mode=...)
         if self._graph_eager_left > 0:
             self._graph_eager_left -= 1
             return False
@@ -99,7 +107,8 @@ class AEBaseTrainer(BaseTrainer):
         if g is None:
             static = {k: dev_batch[k].clone() for k in keys}
             sink = {}
-            if self.dp is not None and self.dp.active:
+            dp_active = self.dp is not None and self.dp.active
+            if dp_active and self._graph_dp == "segments":
                 from ..parallel import SegmentedStepGraph
                 graph = SegmentedStepGraph()
                 self.dp.segments = graph
@@ -115,7 +124,7 @@ class AEBaseTrainer(BaseTrainer):
                 return
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if dp_active else "global"):
                 self._capture_sink = sink
                 try:
                     self._step_core(static, False)
