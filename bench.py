@@ -85,8 +85,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--triplets", type=int, default=12, help="global batch in triplets (12 = the BASELINE workload; other values are for experiments only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured step")
-    ap.add_argument("--dp-graph", action="store_true", help="N > 1: replay the step as a chain of HIP graphs cut at the (eager) collectives "
-                    "(parallel.SegmentedStepGraph; rehearsed on one GPU only: scripts/dp_graph_smoke.py, tests/test_gpu_dp.py)")
+    ap.add_argument("--dp-graph", nargs="?", const="segments", default=None, choices=("segments", "whole"),
+                    help="N > 1: replay the step from HIP graphs instead of host launches -- 'segments' = a chain of graphs cut at the "
+                    "(eager) collectives, 'whole' = one graph with the RCCL collectives captured (both rehearsed on one GPU only: "
+                    "scripts/dp_graph_smoke.py, tests/test_gpu_dp.py)")
     opt = ap.parse_args()
 
     from superresolution_aniso_mri_amd import engine
@@ -113,7 +115,7 @@ def main():
         dp.set_batch(B)
     use_graph = not opt.no_graph and (not dp.active or opt.dp_graph)
     if use_graph:
-        trainer.enable_step_graph(eager_steps=2, dp_segments=dp.active)
+        trainer.enable_step_graph(eager_steps=2, dp_mode=opt.dp_graph if dp.active else None)
     # a small pool of distinct batches, sharded by triplet and resident in HBM before the timed region
     pool = []
     for i in range(4):
@@ -187,7 +189,9 @@ def main():
                    "synthetic backbone weights (BASELINE configs[%d])" % (BRAIN[opt.config][0], B, H, H, 3 if opt.config == "c4" else 4),
                    "global_batch_triplets": B, "slices_per_step": 3 * B, "parallelism": "dp%d" % opt.gpus,
                    "init": "reference Initializer, seed 892372, random weights",
-                   "launch": ("captured HIP graph replay" if not dp.active else "HIP graph segments between eager collectives") if use_graph
+                   "launch": ("captured HIP graph replay" if not dp.active else
+                              "HIP graph segments between eager collectives" if opt.dp_graph == "segments" else
+                              "one HIP graph per step with the RCCL collectives captured") if use_graph
                    else "host launches"},
         "step_algorithmic_gflop": STEP_GFLOP[opt.config],
         "step_executed_mfma_gflop": round(executed, 2),
