@@ -268,6 +268,60 @@ def gen_supervolume(av):
     np.savez_compressed(os.path.join(OUT, "supervolume.npz"), **rec)
 
 
+def gen_supervolume_eval(av):
+    """evaluate/common.py:134-235 ``create_super_volume`` -- the evaluation protocol (keep every ``downsample_steps``-th slice,
+    synthesise the ones in between, append the remainder slices) -- run as the reference's OWN function on the CPU: its
+    ``latent_space_interp`` default device ('cuda') is bound to 'cpu', nothing else is touched.  SimpleITK / imageio are
+    import-time only for this function: stubbed."""
+    import functools
+    for name in ("SimpleITK", "imageio"):
+        if name not in sys.modules:
+            _stub(name, sitkLanczosWindowedSinc=0, Image=object, imsave=None)
+    import evaluate.common as ec
+    ec.latent_space_interp = functools.partial(ec.latent_space_interp, device="cpu")
+
+    class _Trainer(object):                 # the three methods the function calls (kwatsch/base_trainer.py:216-336 on CPU)
+        def __init__(self, model):
+            self.model = model
+
+        def encode(self, x, use_sr_model=False, **kw):
+            with torch.no_grad():
+                return self.model.encode(x.float())
+
+        def decode(self, z, use_sr_model=False, **kw):
+            with torch.no_grad():
+                return self.model.decode(z)
+
+        def predict(self, x, **kw):
+            return self.decode(self.encode(x))
+
+    torch.manual_seed(78)
+    model = av.VanillaACAI(small_args())
+    model.train()
+    with torch.no_grad():
+        model(torch.rand(4, 1, 32, 32))
+    model.eval()
+    tr = _Trainer(model)
+    rec = {"p/" + k: v for k, v in np_state(model.state_dict()).items()}
+    cases = [("default", 5, dict()),
+             ("inbetween_rem", 8, dict(alpha_range=np.linspace(0, 1, 4)[1:-1], generate_inbetween_slices=True)),
+             ("inbetween_even", 7, dict(alpha_range=np.array([0.5]), generate_inbetween_slices=True, downsample_steps=2)),
+             ("downsample_only", 9, dict(alpha_range=np.array([0.3, 0.6]), downsample_steps=4))]
+    for tag, z, kw in cases:
+        vol = torch.rand(z, 16, 20, generator=torch.Generator().manual_seed(10 + z)) * 1.2 - 0.1
+        out = ec.create_super_volume(tr, vol.clone(), use_original=True, **kw)
+        rec[tag + "/vol"] = vol.numpy()
+        rec[tag + "/hr"] = out["upsampled_image"].numpy()
+        rec[tag + "/pred_alphas_shape"] = np.array(out["pred_alphas"].shape)
+        rec[tag + "/pred_alphas_first"] = out["pred_alphas"][:, 0, 0, 0].numpy()
+        if "alpha_range" in kw:
+            rec[tag + "/alpha_range"] = np.asarray(kw["alpha_range"], dtype=np.float64)
+        rec[tag + "/downsample_steps"] = np.array(-1 if kw.get("downsample_steps") is None else kw["downsample_steps"])
+        rec[tag + "/generate_inbetween_slices"] = np.array(int(kw.get("generate_inbetween_slices", False)))
+    rec["determine_last_slice"] = np.array([[n, d, ec.determine_last_slice(n, d)] for n in (5, 8, 9, 12) for d in (2, 3, 4)])
+    np.savez_compressed(os.path.join(OUT, "supervolume_eval.npz"), **rec)
+
+
 def gen_ae_standard_blocks():
     """networks/ae_standard.py:34-80: one BasicEncoderBlock (conv, LReLU, conv, LReLU, AvgPool2d; no BatchNorm) followed by
     one BasicDecoderBlock (conv, LReLU, conv, LReLU, bilinear Upsample x2): forward, input gradient, parameter gradients.
@@ -344,7 +398,11 @@ def main():
         import_reference()
         gen_ae_standard_blocks()
         return
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "supervolume_eval":
+        gen_supervolume_eval(import_reference()[0])
+        return
     av, avs, avm, nb = import_reference()
+    gen_supervolume_eval(av)
     gen_ae_standard_blocks()
     gen_augmentation()
     gen_ae_small(av, avs, avm)

@@ -78,6 +78,30 @@ def create_super_volume(ae, images, alpha_range, use_original=True):
         return torch.clamp(torch.cat(parts, dim=0), min=0, max=1.)
 
 
+def create_super_volume_eval(ae, images, alpha_range=None, use_original=True, downsample_steps=None,
+                             generate_inbetween_slices=False):
+    """evaluate/common.py:134-235, the evaluation protocol around the same synthesis: images [z,H,W].
+    :156-169 keep every ``downsample_steps``-th slice (default len(alpha_range)+1 when in-between slices are generated) after
+    cutting the (z-1) % steps remainder slices; :178-179 default alphas; :220-231 the remainder slices of the ORIGINAL
+    volume are appended after the synthesised stack; pred_alphas = each alpha repeated for the z'-1 pairs (:206-207)."""
+    if alpha_range is None:
+        alpha_range = [0.25, 0.5, 0.75]
+    if generate_inbetween_slices and downsample_steps is None:
+        downsample_steps = int(len(alpha_range) + 1)
+    orig = images
+    rem = 0
+    if downsample_steps is not None or generate_inbetween_slices:
+        rem = (orig.shape[0] - 1) % downsample_steps
+        if rem:
+            images = images[:-rem]
+        images = images[::downsample_steps]
+    hr = create_super_volume(ae, images[:, None], alpha_range, use_original=use_original)
+    if generate_inbetween_slices and rem:
+        hr = torch.clamp(torch.cat([hr, orig[-rem:].float()]), min=0, max=1.)
+    alphas = torch.tensor([float(a) for a in alpha_range], dtype=torch.float32).repeat_interleave(images.shape[0] - 1)
+    return hr, alphas
+
+
 def synthetic_triplets(B, H, W, seed, device="cpu"):
     """Smooth, correlated (from, to, between) triplets in [0,1]: sum of 8 Gaussian blobs
     + low-pass noise; between = 0.5(from+to) + N(0, 0.02)."""

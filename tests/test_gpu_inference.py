@@ -70,3 +70,34 @@ def test_patch_tiled_interpolation_matches_whole_image_on_tiles():
     # each 32x32 tile is an independent image for the network: compare the top-left tile
     whole = latent_space_interp(0.75, tr, a[:, :, :32, :32], b[:, :, :32, :32])["inter_image"]     # alpha*enc(a)+(1-alpha)*enc(b)
     np.testing.assert_allclose(tiled[:, :, :32, :32].numpy(), whole.numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["default", "inbetween_rem", "inbetween_even", "downsample_only"])
+def test_evaluation_protocol_super_volume_vs_reference_function(tag):
+    """evaluate/common.create_super_volume (sub-sampling by downsample_steps, remainder slices, default alphas, pred_alphas)
+    against outputs of the reference's own function (tests/golden/supervolume_eval.npz)."""
+    from evaluate.common import create_super_volume
+    rec = dict(np.load(os.path.join(GOLDEN, "supervolume_eval.npz")))
+    tr = _trainer(dict(width=32, latent_width=8, depth=8, latent=16), {k[2:]: torch.from_numpy(v) for k, v in rec.items() if k.startswith("p/")})
+    ds = int(rec[tag + "/downsample_steps"])
+    res = create_super_volume(tr, torch.from_numpy(rec[tag + "/vol"]), alpha_range=rec.get(tag + "/alpha_range"), use_original=True,
+                              downsample_steps=None if ds < 0 else ds,
+                              generate_inbetween_slices=bool(rec[tag + "/generate_inbetween_slices"]))
+    hr = res["upsampled_image"]
+    assert hr.shape == rec[tag + "/hr"].shape and not hr.is_cuda
+    np.testing.assert_allclose(hr.numpy(), rec[tag + "/hr"], rtol=1e-5, atol=2e-6)
+    assert tuple(res["pred_alphas"].shape) == tuple(rec[tag + "/pred_alphas_shape"])
+    assert np.array_equal(res["pred_alphas"][:, 0, 0, 0].numpy(), rec[tag + "/pred_alphas_first"])
+
+
+def test_patch_tiled_reconstruction_equals_per_tile_predict():
+    from evaluate.common import create_recon_from_diff_psize, eval_on_different_patch_size
+    torch.manual_seed(5)
+    tr = _trainer(dict(width=32, latent_width=8, depth=8, latent=16))
+    vol = torch.rand(3, 70, 64)                                      # 70 rows: the last 6 are not covered by 32x32 tiles
+    rec = eval_on_different_patch_size(tr, vol, 32)
+    assert rec.shape == (3, 64, 64) and not rec.is_cuda
+    tile = tr.predict(vol[1:2, None, 32:64, 0:32]).cpu()
+    np.testing.assert_allclose(rec[1, 32:64, 0:32].numpy(), tile[0, 0].numpy(), rtol=1e-5, atol=1e-6)
+    one = create_recon_from_diff_psize(tr, vol[2], (32, 32))
+    np.testing.assert_allclose(one.numpy(), rec[2].numpy(), rtol=1e-6, atol=1e-7)

@@ -188,3 +188,20 @@ def test_original_slice_ids_for_subsampled_volumes():
     assert list(f(np.zeros((11, 4, 4)), 3)) == [0, 3, 6, 9, 10]
     assert list(f(np.zeros((11, 4, 4)), 3, conv_interpol=True)) == [0, 3, 6, 9, 10]
     assert list(f(np.zeros((12, 4, 4)), 4, conv_interpol=True)) == [0, 4, 8, 9, 10, 11]
+
+
+def test_evaluate_common_host_helpers(tmp_path):
+    """evaluate/common.py:11-38: result file naming, last kept slice, stripping of conventionally expanded volumes."""
+    from evaluate import common as ec
+    rec = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "supervolume_eval.npz"))
+    for n, d, v in rec["determine_last_slice"]:
+        assert ec.determine_last_slice(n, d) == v
+    sr, orig = np.arange(10)[:, None, None] * np.ones((1, 2, 2)), 100 + np.arange(4)[:, None, None] * np.ones((1, 2, 2))
+    out = ec.strip_conventional_interpolation_results(sr, orig, 3)
+    assert out.shape == (8, 2, 2) and out[-1, 0, 0] == 103 and out[-2, 0, 0] == 6
+    ec.save_metrics(str(tmp_path), "ACDC", {"ssim": np.array([0.5])}, 2, "ae_combined", 0)
+    assert os.path.isfile(str(tmp_path / "results" / "ACDC_ae_combined_2x.npz"))
+    ec.save_metrics(str(tmp_path), None, {"ssim": np.array([0.5])}, 3, "linear", 1)
+    assert os.path.isfile(str(tmp_path / "results" / "linear_3x_axis1.npz"))
+    with pytest.raises(NotImplementedError):
+        ec.create_simple_interpolation(np.zeros((2, 2, 2)), np.ones(3), expand_factor=2)

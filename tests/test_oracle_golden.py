@@ -144,6 +144,22 @@ def test_supervolume():
     np.testing.assert_allclose(hr.numpy(), rec["hr"], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("tag", ["default", "inbetween_rem", "inbetween_even", "downsample_only"])
+def test_supervolume_eval_protocol(tag):
+    """oracle restatement of evaluate/common.py:134-235 (sub-sampling, remainder slices, alphas) against outputs of the
+    reference's own function (tests/golden/supervolume_eval.npz, oracle/make_golden.py:gen_supervolume_eval)."""
+    rec = _load("supervolume_eval.npz")
+    ae = ae_oracle.OracleAE(SMALL, init=False).load_state_dict(_sd(rec, "p/"))
+    ds = int(rec[tag + "/downsample_steps"])
+    hr, alphas = step_oracle.create_super_volume_eval(
+        ae, torch.from_numpy(rec[tag + "/vol"]), rec[tag + "/alpha_range"] if tag + "/alpha_range" in rec else None,
+        use_original=True, downsample_steps=None if ds < 0 else ds,
+        generate_inbetween_slices=bool(rec[tag + "/generate_inbetween_slices"]))
+    assert hr.shape == rec[tag + "/hr"].shape
+    np.testing.assert_allclose(hr.numpy(), rec[tag + "/hr"], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(alphas.numpy(), rec[tag + "/pred_alphas_first"])
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_ae_standard_blocks_oracle_vs_reference(tag):
     """The oracle's restatement of the ae_standard encoder/decoder blocks (AvgPool without BatchNorm, bilinear x2 upsample,
