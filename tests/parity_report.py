@@ -1,0 +1,131 @@
+#!/usr/bin/env python
+"""Parity report at the BASELINE configurations (SURVEY section 8d "Parity report"): the HIP trainer against the CPU oracle from
+the same initial parameters on the same synthetic batches.  Test infrastructure (it imports oracle/), not collected by pytest:
+
+    python tests/parity_report.py [c1 c2 c3 c4 c5] > profiles/rNN_parity_report.txt
+
+Per configuration: after ONE step -- rel-L2 of the latents / reconstructions / synthesised slices, relative loss differences,
+rel-L2 of the first-step gradients; SSIM and PSNR of reconstruction-vs-input and synthesis-vs-target on both sides and their
+deltas (north_star: SSIM within 1e-3); then K further steps -- loss-curve deviation, BatchNorm running statistics, largest
+parameter difference in units of the Adam step (lr).  Tolerances are the ones stated in DESIGN.md section 2."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ae_oracle, lpips_oracle, step_oracle  # noqa: E402
+from superresolution_aniso_mri_amd.data_synth import synthetic_batch  # noqa: E402
+from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic  # noqa: E402
+from superresolution_aniso_mri_amd.networks.net_config import NetworkConfig  # noqa: E402
+
+#          dataset     B   H    width lat_w latent lambda  loss          extra steps
+CONFIGS = {
+    "c1": ("MNISTRoto", 32, 28, 28, 7, 16, 0.05, "perceptual", 19),
+    "c2": ("ACDC", 12, 160, 128, 32, 128, 0.05, "mse", 19),
+    "c3": ("ACDC", 12, 160, 128, 32, 128, 0.05, "perceptual", 9),
+    "c4": ("OASIS", 16, 220, 64, 16, 128, 0.001, "perceptual", 2),
+    "c5": ("dHCP", 8, 256, 256, 64, 128, 0.001, "perceptual", 2),
+}
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def run(tag):
+    ds, B, H, width, lw, latent, lam, loss, more = CONFIGS[tag]
+    lr = 1e-5
+    cfg = dict(width=width, latent_width=lw, depth=32, latent=latent, colors=1, use_batchnorm=True, use_sigmoid=True)
+    args = dict(model="ae_combined", dataset=ds, device="cuda", lr=lr, weight_decay=0.0, epochs=10, ex_loss_weight1=lam,
+                use_percept_loss=False, get_masks=False, use_loss_annealing=False, use_extra_latent_loss=False, epoch_threshold=100,
+                ae_class="VanillaACAI", image_mix_loss_func=loss, vgg_weights="synthetic-hash", **cfg)
+    for k, v in NetworkConfig("ae_combined", dataset=ds).architecture.items():
+        args.setdefault(k, v)
+    torch.manual_seed(892372)
+    tr = get_trainer_dynamic(args)
+    oracle = ae_oracle.OracleAE(cfg, init=False).load_state_dict({k: v.detach().cpu() for k, v in tr.model.state_dict().items()})
+    kw = {}
+    if loss == "perceptual":
+        lin = np.load(os.path.join(ROOT, "superresolution_aniso_mri_amd", "lpips", "weights", "v0.1", "vgg_lin.npz"))
+        kw = dict(vgg_sd=lpips_oracle.hash_vgg16_state(), lin_w=[torch.from_numpy(lin["lin%d" % k]).reshape(1, -1, 1, 1) for k in range(5)])
+    ost = step_oracle.OracleStep(oracle, lr=lr, ex_loss_weight1=lam, image_mix_loss_func=loss, **kw)
+    # the same oracle evaluated in fp64: tells the two fp32 gradient evaluations' own rounding apart from a real difference
+    o64 = ae_oracle.OracleAE(cfg, init=False).load_state_dict({k: v.detach().cpu() for k, v in tr.model.state_dict().items()})
+    o64.params = type(o64.params)((k, v.detach().double().requires_grad_(True)) for k, v in o64.params.items())
+    o64.buffers = type(o64.buffers)((k, v.double() if v.is_floating_point() else v) for k, v in o64.buffers.items())
+    kw64 = {k: ({n: t.double() for n, t in v.items()} if isinstance(v, dict) else [t.double() for t in v]) for k, v in kw.items()}
+    ost64 = step_oracle.OracleStep(o64, lr=lr, ex_loss_weight1=lam, image_mix_loss_func=loss, **kw64)
+    brain = ds not in ("ACDC",)
+    print("== %s: %s, %d triplets of %dx%d (%d slices/step), latent %d, synthesis loss %s (lambda %g), trainer %s, lr %g"
+          % (tag, ds, B, H, H, 3 * B, latent, loss, lam, type(tr).__name__, lr))
+
+    def both(step, keep):
+        batch = synthetic_batch(B, H, H, seed=892372 + step, brain=brain)
+        tr.train(batch, keep_predictions=keep)
+        t0 = time.perf_counter()
+        ref = ost.train(batch["image"], batch["slice_between"], batch.get("alpha_from"), batch.get("alpha_to"))
+        return batch, ref, time.perf_counter() - t0
+
+    batch, ref, dt = both(0, True)
+    ost64.train(batch["image"].double(), batch["slice_between"].double(),
+                None if "alpha_from" not in batch else batch["alpha_from"].double(),
+                None if "alpha_to" not in batch else batch["alpha_to"].double())
+    pred = tr.train_predictions
+    print("   step 1 (oracle: %.1f s on %d CPU threads)" % (dt, torch.get_num_threads()))
+    print("     rel-L2   reconstruction %.2e   synthesised slices %.2e   mixed latents %.2e      (tolerance 1e-5)"
+          % (rel_l2(pred["reconstruction"], ref["out"]), rel_l2(pred["slice_inbetween_mix"], ref["s_mix"]), rel_l2(pred["z_mix"], ref["z_mix"])))
+    print("     losses   " + "   ".join("%s %.6e (rel diff %.1e)" % (k, tr.losses[k][-1], abs(tr.losses[k][-1] - ref[k]) / abs(ref[k]))
+                                        for k in ("loss_ae", "loss_ae_dist", "loss_ae_dist_extra", "loss_latent_1")) + "      (tolerance 2e-5)")
+    num = den = n64h = n64o = d64 = 0.0
+    worst = (0.0, "")
+    for k, p in tr.model.named_parameters():
+        g, r, t = p.grad.detach().double().cpu(), oracle.params[k].grad.double(), o64.params[k].grad
+        num += float((g - r).pow(2).sum())
+        den += float(r.pow(2).sum())
+        n64h += float((g - t).pow(2).sum())
+        n64o += float((r - t).pow(2).sum())
+        d64 += float(t.pow(2).sum())
+        worst = max(worst, (rel_l2(g, r), k))
+        if os.environ.get("PARITY_VERBOSE"):
+            print("         %-16s |g| %.3e   hip-vs-fp64 %.2e   oracle32-vs-fp64 %.2e" % (k, float(t.norm()), rel_l2(g, t), rel_l2(r, t)))
+    print("     first-step gradients: rel-L2 over all %d parameters %.2e, worst tensor %s %.2e      (tolerance 1e-4, 2e-4 through LPIPS)"
+          % (sum(p.numel() for p in tr.model.parameters()), (num / den) ** 0.5, worst[1], worst[0]))
+    print("       against the oracle evaluated in fp64: hip %.2e, fp32 oracle %.2e (rel-L2 over all parameters: each fp32 side's own rounding)"
+          % ((n64h / d64) ** 0.5, (n64o / d64) ** 0.5))
+    x, btw = batch["image"], batch["slice_between"]
+    for name, got, want, tgt in (("reconstruction vs input", pred["reconstruction"], ref["out"], x),
+                                 ("synthesis vs slice_between", pred["slice_inbetween_mix"], ref["s_mix"], btw)):
+        sg, so = step_oracle.ssim(got.numpy(), tgt.numpy()), step_oracle.ssim(want.numpy(), tgt.numpy())
+        pg, po = step_oracle.psnr(got.numpy(), tgt.numpy()), step_oracle.psnr(want.numpy(), tgt.numpy())
+        print("     %-27s SSIM hip %.6f oracle %.6f delta %.1e | PSNR hip %.4f dB oracle %.4f dB delta %.1e dB | hip-vs-oracle SSIM %.7f PSNR %.1f dB"
+              % (name, sg, so, abs(sg - so), pg, po, abs(pg - po), step_oracle.ssim(got.numpy(), want.numpy()), step_oracle.psnr(got.numpy(), want.numpy())))
+    curve = 0.0
+    for step in range(1, more + 1):
+        batch, ref, _ = both(step, step == more)
+        curve = max(curve, abs(tr.losses["loss_ae"][-1] - ref["loss_ae"]) / abs(ref["loss_ae"]))
+    sd = tr.model.state_dict()
+    rv = max(rel_l2(sd[k], v) for k, v in oracle.buffers.items() if k.endswith("running_var"))
+    rm = max(float(((sd[k].cpu() - v).abs() / oracle.buffers[k.replace("running_mean", "running_var")].sqrt()).max())
+             for k, v in oracle.buffers.items() if k.endswith("running_mean"))
+    dp = max(float((p.detach().cpu() - oracle.params[k].detach()).abs().max()) for k, p in tr.model.named_parameters())
+    cs_h = sum(float(p.detach().double().sum()) for p in tr.model.parameters())
+    cs_o = sum(float(p.detach().double().sum()) for p in oracle.params.values())
+    sg = step_oracle.ssim(tr.train_predictions["reconstruction"].numpy(), batch["image"].numpy())
+    so = step_oracle.ssim(ref["out"].numpy(), batch["image"].numpy())
+    print("   after %d steps: loss curve max rel deviation %.1e | BN running_var rel-L2 %.1e, running_mean max |diff|/std %.1e | "
+          "largest parameter difference %.2e = %.2f lr (Adam bound 2 lr per step) | parameter sum hip %.6f oracle %.6f | "
+          "reconstruction SSIM delta %.1e" % (more + 1, curve, rv, rm, dp, dp / lr, cs_h, cs_o, abs(sg - so)))
+    sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    print("parity report: HIP trainer (cuda:0, %s) vs oracle/ (PyTorch-CPU fp32), synthetic batches of superresolution_aniso_mri_amd.data_synth, "
+          "synthetic-hash VGG backbone for LPIPS" % torch.cuda.get_device_name(0))
+    for t in (sys.argv[1:] or ["c1", "c2", "c3", "c4", "c5"]):
+        run(t)
