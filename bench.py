@@ -185,7 +185,7 @@ def main():
                                 + ("MSE synthesis loss (BASELINE configs[1])" if opt.config == "c2"
                                    else "LPIPS-VGG synthesis loss lambda=0.05, synthetic backbone weights (BASELINE configs[2])"))
                    if opt.config not in BRAIN else
-                   "%s synthetic %dx(3x1x%dx%d) triplets on one rank, ae_combined latent=128 depth=32, LPIPS-VGG synthesis loss lambda=0.001, "
+                   "%s synthetic %dx(3x1x%dx%d) triplets (global batch), ae_combined latent=128 depth=32, LPIPS-VGG synthesis loss lambda=0.001, "
                    "synthetic backbone weights (BASELINE configs[%d])" % (BRAIN[opt.config][0], B, H, H, 3 if opt.config == "c4" else 4),
                    "global_batch_triplets": B, "slices_per_step": 3 * B, "parallelism": "dp%d" % opt.gpus,
                    "init": "reference Initializer, seed 892372, random weights",
