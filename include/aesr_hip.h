@@ -211,6 +211,16 @@ int aesr_lerp_bwd(const float* dzmix, const float* a_from, const float* a_to, fl
 int aesr_mse_fwd(const float* a, const float* b, double* partial, float* loss, size_t n, void* stream);
 /* da = 2*(a-b)*gloss[0]/n */
 int aesr_mse_bwd(const float* a, const float* b, const float* gloss, float* da, size_t n, void* stream);
+/* loss[0] = mean |a-b| (F.l1_loss of kwatsch/lap_pyramid_loss.py:65); partial: AESR_MSE_NPART doubles.  da = sign(a-b)*gloss[0]/n. */
+int aesr_l1_fwd(const float* a, const float* b, double* partial, float* loss, size_t n, void* stream);
+int aesr_l1_bwd(const float* a, const float* b, const float* gloss, float* da, size_t n, void* stream);
+/* Laplacian-pyramid pieces on planes [P][H][W] (kwatsch/lap_pyramid_loss.py:23-40):
+ * blur5: out = (add ? add : 0) + gain * G(in), G = 5x5 binomial filter /256 with reflect padding (conv_gauss, :37-40); adjoint != 0
+ *        applies the transposed operator (gradient of G).  upsample() of the reference = blur5(zero_insert2(x), gain 4).
+ * down2: out[P][ceil(H/2)][ceil(W/2)] = in[:, ::2, ::2] (:23-24).  zero_insert2: its transpose, out[P][H][W] (:27-34). */
+int aesr_lap_blur5(const float* in, const float* add, float* out, int P, int H, int W, float gain, int adjoint, void* stream);
+int aesr_lap_down2(const float* in, float* out, int P, int H, int W, void* stream);
+int aesr_lap_zero_insert2(const float* in, float* out, int P, int h, int w, int H, int W, void* stream);
 /* dpre = dout * act'(y) from the saved activation output (sigmoid of networks/acai_vanilla.py:98). */
 int aesr_act_bwd(const float* dout, const float* y, float* dpre, size_t n, int act, float slope, void* stream);
 

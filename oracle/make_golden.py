@@ -322,6 +322,26 @@ def gen_supervolume_eval(av):
     np.savez_compressed(os.path.join(OUT, "supervolume_eval.npz"), **rec)
 
 
+def gen_laploss():
+    """kwatsch/lap_pyramid_loss.py (imports torch only): pyramid levels, loss and input gradient of the reference's LapLoss on
+    1-channel (the trainers' use, base_trainer.py:54) and 2-channel inputs."""
+    import kwatsch.lap_pyramid_loss as lp
+    rec = {}
+    for tag, shape in (("a", (3, 1, 32, 32)), ("b", (2, 2, 24, 24))):      # square only: upsample() :27-34 mixes H and W
+        g = torch.Generator().manual_seed(sum(shape))
+        x = torch.rand(shape, generator=g).requires_grad_(True)
+        t = torch.rand(shape, generator=g)
+        crit = lp.LapLoss(max_levels=3, channels=shape[1], device="cpu")
+        pyr = lp.laplacian_pyramid(x, crit.gauss_kernel, 3)
+        loss = crit(x, t)
+        loss.backward()
+        rec.update({tag + "/x": x.detach().numpy(), tag + "/t": t.numpy(), tag + "/loss": np.float64(loss.item()),
+                    tag + "/dx": x.grad.numpy()})
+        for k, p in enumerate(pyr):
+            rec["%s/pyr%d" % (tag, k)] = p.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "laploss.npz"), **rec)
+
+
 def gen_ae_standard_blocks():
     """networks/ae_standard.py:34-80: one BasicEncoderBlock (conv, LReLU, conv, LReLU, AvgPool2d; no BatchNorm) followed by
     one BasicDecoderBlock (conv, LReLU, conv, LReLU, bilinear Upsample x2): forward, input gradient, parameter gradients.
@@ -398,11 +418,16 @@ def main():
         import_reference()
         gen_ae_standard_blocks()
         return
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "laploss":
+        import_reference()
+        gen_laploss()
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "supervolume_eval":
         gen_supervolume_eval(import_reference()[0])
         return
     av, avs, avm, nb = import_reference()
     gen_supervolume_eval(av)
+    gen_laploss()
     gen_ae_standard_blocks()
     gen_augmentation()
     gen_ae_small(av, avs, avm)

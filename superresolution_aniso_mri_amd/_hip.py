@@ -79,6 +79,11 @@ SIGNATURES = {
     "aesr_lerp_bwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
     "aesr_mse_fwd": (c_int, [P, P, P, P, c_size_t, P]),
     "aesr_mse_bwd": (c_int, [P, P, P, P, c_size_t, P]),
+    "aesr_l1_fwd": (c_int, [P, P, P, P, c_size_t, P]),
+    "aesr_l1_bwd": (c_int, [P, P, P, P, c_size_t, P]),
+    "aesr_lap_blur5": (c_int, [P, P, P, c_int, c_int, c_int, c_float, c_int, P]),
+    "aesr_lap_down2": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "aesr_lap_zero_insert2": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "aesr_act_bwd": (c_int, [P, P, P, c_size_t, c_int, c_float, P]),
     "aesr_triplet_assemble": (c_int, [P, ctypes.POINTER(TripletDesc), c_int, c_int, P, P, P]),
     "aesr_ssim_workspace_doubles": (c_size_t, [c_int, c_int, c_int]),

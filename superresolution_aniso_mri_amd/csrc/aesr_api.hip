@@ -647,6 +647,33 @@ int aesr_mse_bwd(const float* a, const float* b, const float* gloss, float* da, 
     return aesr_launch_mse_bwd(a, b, gloss, da, n, (hipStream_t)stream);
 }
 
+int aesr_l1_fwd(const float* a, const float* b, double* partial, float* loss, size_t n, void* stream) {
+    AESR_CHECK_ARG(a && b && partial && loss && n > 0, "aesr_l1_fwd: bad arguments");
+    return aesr_launch_l1_fwd(a, b, partial, AESR_MSE_NPART, loss, n, (hipStream_t)stream);
+}
+
+int aesr_l1_bwd(const float* a, const float* b, const float* gloss, float* da, size_t n, void* stream) {
+    AESR_CHECK_ARG(a && b && gloss && da && n > 0, "aesr_l1_bwd: bad arguments");
+    return aesr_launch_l1_bwd(a, b, gloss, da, n, (hipStream_t)stream);
+}
+
+int aesr_lap_blur5(const float* in, const float* add, float* out, int P, int H, int W, float gain, int adjoint, void* stream) {
+    AESR_CHECK_ARG(in && out && P > 0 && H >= 3 && W >= 3, "aesr_lap_blur5: bad arguments (reflect padding by 2 needs H, W >= 3)");
+    AESR_CHECK_ARG(in != out, "aesr_lap_blur5: in-place filtering is not supported");
+    return aesr_launch_lap_blur5(in, add, out, P, H, W, gain, adjoint ? 1 : 0, (hipStream_t)stream);
+}
+
+int aesr_lap_down2(const float* in, float* out, int P, int H, int W, void* stream) {
+    AESR_CHECK_ARG(in && out && P > 0 && H > 0 && W > 0, "aesr_lap_down2: bad arguments");
+    return aesr_launch_lap_down2(in, out, P, H, W, (hipStream_t)stream);
+}
+
+int aesr_lap_zero_insert2(const float* in, float* out, int P, int h, int w, int H, int W, void* stream) {
+    AESR_CHECK_ARG(in && out && P > 0 && h > 0 && w > 0 && (H + 1) / 2 == h && (W + 1) / 2 == w,
+                   "aesr_lap_zero_insert2: need h == ceil(H/2), w == ceil(W/2)");
+    return aesr_launch_lap_zero_insert2(in, out, P, h, w, H, W, (hipStream_t)stream);
+}
+
 int aesr_act_bwd(const float* dout, const float* y, float* dpre, size_t n, int act, float slope, void* stream) {
     AESR_CHECK_ARG(dout && y && dpre && n > 0, "aesr_act_bwd: bad arguments");
     return aesr_launch_act_bwd(dout, y, dpre, n, act, slope, (hipStream_t)stream);

@@ -146,3 +146,10 @@ struct TripletDesc { long long vol_off; int H, W, z_from, z_to, z_between, oy, o
 struct TripletTable { TripletDesc d[TRIPLET_MAX]; };
 int aesr_launch_triplet_assemble(const float* vol, const TripletTable& t, int B, int W, float* image, float* between, hipStream_t st);
 int aesr_launch_s2d(const float* x, float* out, int N, int H, int W, int C, int inverse, hipStream_t st);
+
+// ---- Laplacian-pyramid loss (lap.hip) ----
+int aesr_launch_lap_blur5(const float* in, const float* add, float* out, int P, int H, int W, float gain, int adjoint, hipStream_t st);
+int aesr_launch_lap_down2(const float* in, float* out, int P, int H, int W, hipStream_t st);
+int aesr_launch_lap_zero_insert2(const float* in, float* out, int P, int h, int w, int H, int W, hipStream_t st);
+int aesr_launch_l1_fwd(const float* a, const float* b, double* partial, int np, float* out, size_t n, hipStream_t st);
+int aesr_launch_l1_bwd(const float* a, const float* b, const float* g, float* da, size_t n, hipStream_t st);

@@ -66,8 +66,9 @@ class BaseTrainer(object):
 
     def _init_laploss(self):
         self.laploss = None
-        if not self.eval_model and self.args.get("use_laploss"):
-            raise NotImplementedError("LapLoss (kwatsch/lap_pyramid_loss.py) is outside the ae_combined hot path of this build")
+        if not self.eval_model and self.args.get("use_laploss"):          # reference :47-56
+            from .lap_pyramid_loss import LapLoss
+            self.laploss = LapLoss(channels=1, device=self.args["device"])
 
     def determine_image_mix_loss_func(self):
         f = self.args.get("image_mix_loss_func")
@@ -134,9 +135,14 @@ class BaseTrainer(object):
                 dist = self.percept_criterion(recons, reference, normalize=True).mean()
         else:
             dist = ops.mse_loss(recons, reference)
+        lap = 0
+        if self.laploss is not None:                                       # reference :183-196
+            lap = self.laploss(recons, reference)
         if store_loss:
             self._log("loss_ae_dist", dist, is_test)
-        return {"loss_ae": dist, "loss_ae_dist": dist, "loss_laploss": 0}
+            if self.laploss is not None:
+                self._log("loss_laploss", lap, is_test)
+        return {"loss_ae": dist + lap if self.laploss is not None else dist, "loss_ae_dist": dist, "loss_laploss": lap}
 
     def _mix_coefficients(self, batch_item, B):
         """(alpha_from, alpha_to) for the latent lerp: 0.5/0.5 here (reference :348-351, trainer_ae.py:51)."""

@@ -35,8 +35,12 @@ class CombinedStepMixin(object):
         if use_mask:
             # reference :117-120: mean over ALL elements of mse(reduction='none') * mask (rarely used option: plain tensor ops)
             m = mask[:synthesized.size(0)].to(synthesized.device)
-            return ((reference - synthesized) ** 2 * m).mean()
-        return ops.mse_loss(reference, synthesized)
+            loss_image = ((reference - synthesized) ** 2 * m).mean()
+        else:
+            loss_image = ops.mse_loss(reference, synthesized)
+        if getattr(self, "laploss", None) is not None:                      # reference :124-125 (MSE branch only)
+            loss_image = self.laploss(synthesized, reference) + loss_image
+        return loss_image
 
     _mask_inputs = True      # cardiac multiplies the images by the mask; brain multiplies the distances
 

@@ -161,6 +161,19 @@ def test_supervolume_eval_protocol(tag):
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
+def test_laploss_oracle_vs_reference(tag):
+    """oracle/lap_oracle.py against the reference's LapLoss (tests/golden/laploss.npz: pyramid levels, loss, input gradient)."""
+    from oracle import lap_oracle
+    rec = _load("laploss.npz")
+    x, t = torch.from_numpy(rec[tag + "/x"]).requires_grad_(True), torch.from_numpy(rec[tag + "/t"])
+    for k, p in enumerate(lap_oracle.laplacian_pyramid(x)):
+        assert np.array_equal(p.detach().numpy(), rec["%s/pyr%d" % (tag, k)])
+    loss = lap_oracle.lap_loss(x, t)
+    loss.backward()
+    assert float(loss.detach()) == float(rec[tag + "/loss"]) and np.array_equal(x.grad.numpy(), rec[tag + "/dx"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
 def test_ae_standard_blocks_oracle_vs_reference(tag):
     """The oracle's restatement of the ae_standard encoder/decoder blocks (AvgPool without BatchNorm, bilinear x2 upsample,
     networks/ae_standard.py:34-80) against vectors produced by the reference's own block modules."""
