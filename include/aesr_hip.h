@@ -221,6 +221,9 @@ int aesr_l1_bwd(const float* a, const float* b, const float* gloss, float* da, s
 int aesr_lap_blur5(const float* in, const float* add, float* out, int P, int H, int W, float gain, int adjoint, void* stream);
 int aesr_lap_down2(const float* in, float* out, int P, int H, int W, void* stream);
 int aesr_lap_zero_insert2(const float* in, float* out, int P, int h, int w, int H, int W, void* stream);
+/* Discriminator head (networks/acai_vanilla.py:146-150): out[n] = mean of the M elements of row n; dx[n][:] = g[n] / M. */
+int aesr_row_mean_fwd(const float* x, float* out, int N, size_t M, void* stream);
+int aesr_row_mean_bwd(const float* g, float* dx, int N, size_t M, void* stream);
 /* dpre = dout * act'(y) from the saved activation output (sigmoid of networks/acai_vanilla.py:98). */
 int aesr_act_bwd(const float* dout, const float* y, float* dpre, size_t n, int act, float slope, void* stream);
 

@@ -322,6 +322,72 @@ def gen_supervolume_eval(av):
     np.savez_compressed(os.path.join(OUT, "supervolume_eval.npz"), **rec)
 
 
+def gen_acai_steps(av):
+    """kwatsch/trainer_acai.py:46-127 (ACAITrainer.train / get_loss_disc) restated around the reference's OWN VanillaACAI and
+    Discriminator modules (the trainer class itself needs CUDA): two steps of ``acai_combined`` (MSE synthesis loss) and one of
+    plain ``acai``; alpha drawn as the reference draws it (torch.rand(B,1,1,1)/2 after torch.manual_seed)."""
+    import torch.nn.functional as F
+    for tag, combined, nsteps in (("acai_combined", True, 2), ("acai", False, 1)):
+        torch.manual_seed(41)
+        model = av.VanillaACAI(small_args())
+        disc = av.Discriminator(small_args())
+        lr, lamb, lam, gamma, B = 1e-3, 0.5, 0.05, 0.2, 3
+        opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0.0, betas=(0.9, 0.999))
+        opt_d = torch.optim.Adam(disc.parameters(), lr=lr, weight_decay=0.0, betas=(0.9, 0.999))
+        rec = {"p0/" + k: v for k, v in np_state(model.state_dict()).items()}
+        rec.update({"d0/" + k: v for k, v in np_state(disc.state_dict()).items()})
+        g = torch.Generator().manual_seed(7)
+        af = torch.tensor([0.25, 0.5, 0.75])[:, None]
+        rec["alpha_from"], rec["alpha_to"] = af.numpy(), (1 - af).numpy()
+        losses = []
+        model.train()
+        for step in range(nsteps):
+            x = torch.rand(2 * B, 1, 32, 32, generator=g)
+            btw = torch.rand(B, 1, 32, 32, generator=g)
+            torch.manual_seed(100 + step)
+            alpha = torch.rand(B, 1, 1, 1) / 2
+            z = model.encode(x)
+            out = model.decode(z)
+            loss_ae_dist = F.mse_loss(out, x, reduction="mean")
+            loss_disc_l2 = torch.mean(disc(out + gamma * (x - out)) ** 2)
+            out_mix = model.decode(alpha * z[:B] + (1 - alpha) * z[B:])
+            disc_mix = disc(out_mix)
+            loss_ae_l2 = torch.mean(disc_mix ** 2)
+            loss_disc_dist = F.mse_loss(disc_mix, alpha.reshape(-1), reduction="mean")
+            loss_ae = loss_ae_dist + lamb * loss_ae_l2
+            loss_disc = loss_disc_dist + loss_disc_l2
+            z_mix = af[:, :, None, None] * z[:B] + (1 - af)[:, :, None, None] * z[B:]
+            if combined:
+                s_mix = model.decode(z_mix)
+                z_ref = model.encode(btw)
+                loss_extra = lam * F.mse_loss(btw, s_mix)
+                loss_ae = loss_ae + loss_extra
+            else:
+                model.eval()
+                with torch.no_grad():
+                    s_mix = model.decode(z_mix)
+                    z_ref = model.encode(btw)
+                    loss_extra = lam * F.mse_loss(btw, s_mix)
+                model.train()
+            loss_latent = F.mse_loss(z_mix, z_ref)
+            opt.zero_grad()
+            opt_d.zero_grad()
+            loss_ae.backward(retain_graph=True)
+            loss_disc.backward()
+            if step == 0:
+                rec.update({"grad0/" + k: p.grad.numpy().copy() for k, p in model.named_parameters()})
+                rec.update({"dgrad0/" + k: p.grad.numpy().copy() for k, p in disc.named_parameters()})
+                rec["out_0"], rec["s_mix_0"], rec["out_mix_0"] = out.detach().numpy(), s_mix.detach().numpy(), out_mix.detach().numpy()
+            opt.step()
+            opt_d.step()
+            rec["image_%d" % step], rec["between_%d" % step], rec["alpha_%d" % step] = x.numpy(), btw.numpy(), alpha.reshape(-1).numpy()
+            losses.append([loss_ae.item(), loss_disc.item(), loss_ae_dist.item(), loss_extra.item(), loss_latent.item()])
+        rec["losses"] = np.array(losses, dtype=np.float64)
+        rec.update({"p1/" + k: v for k, v in np_state(model.state_dict()).items()})
+        rec.update({"d1/" + k: v for k, v in np_state(disc.state_dict()).items()})
+        np.savez_compressed(os.path.join(OUT, "step_%s.npz" % tag), **rec)
+
+
 def gen_laploss():
     """kwatsch/lap_pyramid_loss.py (imports torch only): pyramid levels, loss and input gradient of the reference's LapLoss on
     1-channel (the trainers' use, base_trainer.py:54) and 2-channel inputs."""
@@ -418,6 +484,9 @@ def main():
         import_reference()
         gen_ae_standard_blocks()
         return
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "acai":
+        gen_acai_steps(import_reference()[0])
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "laploss":
         import_reference()
         gen_laploss()
@@ -427,6 +496,7 @@ def main():
         return
     av, avs, avm, nb = import_reference()
     gen_supervolume_eval(av)
+    gen_acai_steps(av)
     gen_laploss()
     gen_ae_standard_blocks()
     gen_augmentation()

@@ -60,6 +60,60 @@ class OracleStep:
                     s_mix=s_mix.detach())
 
 
+class OracleACAIStep:
+    """kwatsch/trainer_acai.py:34-127 on the oracle networks: ``critic`` is an OracleAE whose ENCODER program/parameters are the
+    Discriminator's (networks/acai_vanilla.py:140-153: encoder, then the mean over all latent elements per sample).
+    Two Adam optimisers (:42-43), gamma = 0.2 (:44), both backward calls of :78-79 without detaching anything."""
+
+    def __init__(self, ae, critic, lr=1e-5, weight_decay=0.0, momentum=0.9, lamb_reg_acai=0.5, ex_loss_weight1=0.001, combined=True,
+                 image_mix_loss_func="mse", vgg_sd=None, lin_w=None):
+        self.ae, self.critic = ae, critic
+        self.opt = torch.optim.Adam(ae.parameters(), lr=lr, weight_decay=weight_decay, betas=(momentum, 0.999))
+        self.opt_disc = torch.optim.Adam(critic.parameters(), lr=lr, weight_decay=weight_decay, betas=(0.9, 0.999))
+        self.lamb, self.lam, self.combined, self.gamma = lamb_reg_acai, ex_loss_weight1, combined, 0.2
+        self._extra = OracleStep(ae, lr=lr, ex_loss_weight1=ex_loss_weight1, image_mix_loss_func=image_mix_loss_func, vgg_sd=vgg_sd,
+                                 lin_w=lin_w).extra_image_loss
+
+    def disc(self, img):
+        return self.critic.encode(img, train=True).reshape(img.shape[0], -1).mean(-1)
+
+    def train(self, image, slice_between, alpha_from, alpha_to, alpha):
+        """alpha: the [B] tensor the reference draws with torch.rand(B,1,1,1)/2 (:107)."""
+        ae, B = self.ae, image.shape[0] // 2
+        z = ae.encode(image, train=True)
+        out = ae.decode(z, train=True)
+        loss_ae_dist = F.mse_loss(out, image)
+        loss_disc_l2 = torch.mean(self.disc(out + self.gamma * (image - out)) ** 2)                    # :100-105
+        a4 = alpha.reshape(-1, 1, 1, 1)
+        out_mix = ae.decode(a4 * z[:B] + (1 - a4) * z[B:], train=True)                                 # :108,:116
+        disc_mix = self.disc(out_mix)
+        loss_ae_l2 = torch.mean(disc_mix ** 2)
+        loss_disc_dist = F.mse_loss(disc_mix, alpha.reshape(-1))
+        loss_ae = loss_ae_dist + self.lamb * loss_ae_l2                                                # :64
+        loss_disc = loss_disc_dist + loss_disc_l2                                                      # :65
+        z_mix = alpha_from[:, :, None, None] * z[:B] + alpha_to[:, :, None, None] * z[B:]
+        if self.combined:
+            s_mix = ae.decode(z_mix, train=True)
+            z_ref = ae.encode(slice_between, train=True)
+            loss_extra = self.lam * self._extra(slice_between, s_mix)
+            loss_ae = loss_ae + loss_extra
+        else:
+            with torch.no_grad():
+                s_mix = ae.decode(z_mix, train=False)
+                z_ref = ae.encode(slice_between, train=False)
+                loss_extra = self.lam * self._extra(slice_between, s_mix)
+        loss_latent = F.mse_loss(z_mix, z_ref)
+        self.opt.zero_grad()
+        self.opt_disc.zero_grad()
+        loss_ae.backward(retain_graph=True)
+        loss_disc.backward()
+        self.opt.step()
+        self.opt_disc.step()
+        return dict(loss_ae=float(loss_ae.detach()), loss_disc=float(loss_disc.detach()), loss_ae_dist=float(loss_ae_dist.detach()),
+                    loss_ae_dist_extra=float(loss_extra.detach()), loss_latent_1=float(loss_latent.detach()), out=out.detach(),
+                    s_mix=s_mix.detach(), out_mix=out_mix.detach())
+
+
 def create_super_volume(ae, images, alpha_range, use_original=True):
     """generate_hr_volumes.py:12-69 with the reference's per-alpha re-encoding collapsed (eval-mode BN
     makes results batch-composition independent).  images [z,1,H,W] -> [(z-1)(n+1)+1, H, W]."""

@@ -79,6 +79,8 @@ SIGNATURES = {
     "aesr_lerp_bwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
     "aesr_mse_fwd": (c_int, [P, P, P, P, c_size_t, P]),
     "aesr_mse_bwd": (c_int, [P, P, P, P, c_size_t, P]),
+    "aesr_row_mean_fwd": (c_int, [P, P, c_int, c_size_t, P]),
+    "aesr_row_mean_bwd": (c_int, [P, P, c_int, c_size_t, P]),
     "aesr_l1_fwd": (c_int, [P, P, P, P, c_size_t, P]),
     "aesr_l1_bwd": (c_int, [P, P, P, P, c_size_t, P]),
     "aesr_lap_blur5": (c_int, [P, P, P, c_int, c_int, c_int, c_float, c_int, P]),

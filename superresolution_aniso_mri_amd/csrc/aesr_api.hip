@@ -657,6 +657,16 @@ int aesr_l1_bwd(const float* a, const float* b, const float* gloss, float* da, s
     return aesr_launch_l1_bwd(a, b, gloss, da, n, (hipStream_t)stream);
 }
 
+int aesr_row_mean_fwd(const float* x, float* out, int N, size_t M, void* stream) {
+    AESR_CHECK_ARG(x && out && N > 0 && M > 0, "aesr_row_mean_fwd: bad arguments");
+    return aesr_launch_row_mean_fwd(x, out, N, M, (hipStream_t)stream);
+}
+
+int aesr_row_mean_bwd(const float* g, float* dx, int N, size_t M, void* stream) {
+    AESR_CHECK_ARG(g && dx && N > 0 && M > 0, "aesr_row_mean_bwd: bad arguments");
+    return aesr_launch_row_mean_bwd(g, dx, N, M, (hipStream_t)stream);
+}
+
 int aesr_lap_blur5(const float* in, const float* add, float* out, int P, int H, int W, float gain, int adjoint, void* stream) {
     AESR_CHECK_ARG(in && out && P > 0 && H >= 3 && W >= 3, "aesr_lap_blur5: bad arguments (reflect padding by 2 needs H, W >= 3)");
     AESR_CHECK_ARG(in != out, "aesr_lap_blur5: in-place filtering is not supported");

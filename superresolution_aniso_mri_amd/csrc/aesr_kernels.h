@@ -153,3 +153,5 @@ int aesr_launch_lap_down2(const float* in, float* out, int P, int H, int W, hipS
 int aesr_launch_lap_zero_insert2(const float* in, float* out, int P, int h, int w, int H, int W, hipStream_t st);
 int aesr_launch_l1_fwd(const float* a, const float* b, double* partial, int np, float* out, size_t n, hipStream_t st);
 int aesr_launch_l1_bwd(const float* a, const float* b, const float* g, float* da, size_t n, hipStream_t st);
+int aesr_launch_row_mean_fwd(const float* x, float* out, int N, size_t M, hipStream_t st);
+int aesr_launch_row_mean_bwd(const float* g, float* dx, int N, size_t M, hipStream_t st);

@@ -110,6 +110,28 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a
     }
 }
 
+// ---- per-row mean (the Discriminator head of networks/acai_vanilla.py:146-150: x.reshape(N,-1).mean(-1)) ----
+__global__ __launch_bounds__(1024) void row_mean_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, size_t M) {
+    __shared__ double red[16];
+    const float* row = x + (size_t)blockIdx.x * M;
+    double s = 0.0;
+    for (size_t i = threadIdx.x; i < M; i += 1024) s += (double)row[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        out[blockIdx.x] = (float)(t / (double)M);
+    }
+}
+
+__global__ __launch_bounds__(256) void row_mean_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, size_t M, size_t total,
+                                                           float inv_m) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) dx[i] = g[i / M] * inv_m;
+}
+
 static inline int lap_grid(size_t n) {
     const size_t g = (n + 255) / 256;
     return (int)(g > 4096 ? 4096 : (g ? g : 1));
@@ -145,5 +167,17 @@ int aesr_launch_l1_fwd(const float* a, const float* b, double* partial, int np, 
 int aesr_launch_l1_bwd(const float* a, const float* b, const float* g, float* da, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(l1_bwd_kernel, dim3(lap_grid(n)), dim3(256), 0, st, a, b, g, da, n, (float)(1.0 / (double)n));
     AESR_LAUNCH_CHECK("l1_bwd");
+    return AESR_OK;
+}
+
+int aesr_launch_row_mean_fwd(const float* x, float* out, int N, size_t M, hipStream_t st) {
+    hipLaunchKernelGGL(row_mean_fwd_kernel, dim3(N), dim3(1024), 0, st, x, out, M);
+    AESR_LAUNCH_CHECK("row_mean_fwd");
+    return AESR_OK;
+}
+
+int aesr_launch_row_mean_bwd(const float* g, float* dx, int N, size_t M, hipStream_t st) {
+    hipLaunchKernelGGL(row_mean_bwd_kernel, dim3(lap_grid((size_t)N * M)), dim3(256), 0, st, g, dx, M, (size_t)N * M, (float)(1.0 / (double)M));
+    AESR_LAUNCH_CHECK("row_mean_bwd");
     return AESR_OK;
 }

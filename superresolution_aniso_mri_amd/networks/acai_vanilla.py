@@ -163,6 +163,31 @@ class VanillaACAI(HipAE):
                            upsample_mode=args.get("upsample_mode", "nearest")).to(args["device"])
 
 
+class Discriminator(HipAE):
+    """ACAI critic (reference :140-153): an ``Encoder`` of the auto-encoder's shape followed by the mean over all latent elements
+    of each sample; ``use_sigmoid`` is hard-wired off as in the reference.  The input may require a gradient (the critic's
+    opinion of decoded mixes regularises the auto-encoder), so its first layers run unfolded."""
+
+    def __init__(self, args):
+        super().__init__()
+        self._fill_defaults(args)
+        self.use_sigmoid = False
+        self.encoder = Encoder(num_scales(args), args["depth"], args["latent"], args["colors"], n_res_block=args["n_res_block"],
+                               use_batchnorm=args["use_batchnorm"]).to(args["device"])
+
+    def set_sync_bn(self, fn, count_scale=1.0):
+        r = self._runner("encoder")
+        r.sync_bn, r.count_scale = fn, float(count_scale)
+
+    def forward_multi(self, images):
+        """One critic value per image for several sub-batches with independent BatchNorm statistics: list of [N_i] tensors."""
+        from .. import ops
+        return [ops.row_mean(f) for f in self._pass("encoder", images)]
+
+    def forward(self, x):
+        return self.forward_multi([x])[0]
+
+
 def create_decoder(args):
     return Decoder(num_scales(args), args["depth"], args["latent"], args["colors"], n_res_block=args["n_res_block"],
                    use_batchnorm=args["use_batchnorm"], use_sigmoid=args["use_sigmoid"]).to(args["device"])
@@ -175,3 +200,7 @@ def lerp(start, end, weights):
 def swap_halves(x):
     a, b = x.split(x.shape[0] // 2)
     return torch.cat([b, a])
+
+
+def L2(x):
+    return torch.mean(x ** 2)

@@ -89,6 +89,30 @@ def mse_loss(a, b):
     return _MseFn.apply(an, bn)
 
 
+class _RowMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, M = x.shape[0], x[0].numel()
+        out = torch.empty(N, device=x.device, dtype=torch.float32)
+        check(lib.aesr_row_mean_fwd(ptr(x), ptr(out), N, M, stream()), "aesr_row_mean_fwd")
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().float()
+        dx = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        check(lib.aesr_row_mean_bwd(ptr(g), ptr(dx), ctx.shape[0], dx[0].numel(), stream()), "aesr_row_mean_bwd")
+        return dx
+
+
+def row_mean(x):
+    """Mean over everything but the first dimension, [N, ...] -> [N] (element order is irrelevant, so NHWC memory is used as is)."""
+    xn = engine.to_nhwc(x) if x.dim() == 4 else x.contiguous().float()
+    _hip.require_gpu_tensor(xn, "row_mean input")
+    return _RowMeanFn.apply(xn)
+
+
 class HipAdam(torch.optim.Adam):
     """``torch.optim.Adam`` whose step is ONE fused HIP kernel over a flat parameter buffer.
 

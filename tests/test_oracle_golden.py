@@ -160,6 +160,28 @@ def test_supervolume_eval_protocol(tag):
     assert np.array_equal(alphas.numpy(), rec[tag + "/pred_alphas_first"])
 
 
+@pytest.mark.parametrize("tag", ["acai_combined", "acai"])
+def test_acai_step_oracle_vs_reference_modules(tag):
+    """oracle/step_oracle.OracleACAIStep (kwatsch/trainer_acai.py:46-127) against the step restated around the reference's own
+    VanillaACAI / Discriminator modules (tests/golden/step_acai*.npz): losses, first-step gradients of both networks, parameters."""
+    rec = _load("step_%s.npz" % tag)
+    ae = ae_oracle.OracleAE(SMALL, init=False).load_state_dict(_sd(rec, "p0/"))
+    critic = ae_oracle.OracleAE(SMALL, init=False).load_state_dict({k.replace("encoder.", "enc."): v for k, v in _sd(rec, "d0/").items()})
+    st = step_oracle.OracleACAIStep(ae, critic, lr=1e-3, lamb_reg_acai=0.5, ex_loss_weight1=0.05, combined=(tag == "acai_combined"),
+                                    image_mix_loss_func="mse")
+    af, at = torch.from_numpy(rec["alpha_from"]), torch.from_numpy(rec["alpha_to"])
+    for step in range(len(rec["losses"])):
+        r = st.train(torch.from_numpy(rec["image_%d" % step]), torch.from_numpy(rec["between_%d" % step]), af, at,
+                     torch.from_numpy(rec["alpha_%d" % step]))
+        got = [r["loss_ae"], r["loss_disc"], r["loss_ae_dist"], r["loss_ae_dist_extra"], r["loss_latent_1"]]
+        np.testing.assert_allclose(got, rec["losses"][step], rtol=1e-5 if step == 0 else 2e-3)
+        if step == 0:
+            for k, p in ae.params.items():
+                np.testing.assert_allclose(p.grad.numpy(), rec["grad0/" + k], rtol=1e-4, atol=1e-7, err_msg=k)
+            for k, p in critic.params.items():
+                np.testing.assert_allclose(p.grad.numpy(), rec["dgrad0/" + k.replace("enc.", "encoder.")], rtol=1e-4, atol=1e-7, err_msg=k)
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_laploss_oracle_vs_reference(tag):
     """oracle/lap_oracle.py against the reference's LapLoss (tests/golden/laploss.npz: pyramid levels, loss, input gradient)."""
