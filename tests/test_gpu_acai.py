@@ -93,3 +93,23 @@ def test_discriminator_module_and_checkpoint(tmp_path):
     ck = torch.load(f, map_location="cpu")
     assert set(ck.keys()) == {"model_dict_ae", "optimizer_dict_ae", "model_disc", "optimizer_disc", "epoch"} and ck["epoch"] == 3
     assert "encoder.5.running_mean" in ck["model_disc"]
+
+
+def test_acai_cli_train_and_reload(tmp_path):
+    """train_aesr --model acai_combined on synthetic brain-style triplets (per-sample alphas): settings.yaml + .models with the critic,
+    reloaded through get_trainer_dynamic(src_path=..., model_nbr=...) as the evaluation scripts do."""
+    from superresolution_aniso_mri_amd import train_aesr
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    out = str(tmp_path / "expers")
+    tr = train_aesr.main(["--dataset=OASIS", "--model=acai_combined", "--batch_size=4", "--test_batch_size=4", "--latent=16",
+                          "--latent_width=8", "--width=32", "--depth=8", "--downsample_steps=2", "--epochs=1", "--lr=0.001",
+                          "--ex_loss_weight1=0.05", "--exper_id=a1", "--output_dir=" + out, "--synthetic", "--iters_per_epoch=3",
+                          "--image_mix_loss_func=mse", "--epoch_threshold=0"], brain=True)
+    assert type(tr).__name__ == "ACAITrainer" and tr.iters == 4 and len(tr.losses["loss_disc"]) + len(tr.mean_losses["loss_disc"]) >= 1
+    src = os.path.join(out, "a1")
+    ck = torch.load(os.path.join(src, "models", "1.models"), map_location="cpu")
+    assert "model_disc" in ck and "optimizer_disc" in ck
+    ev, args = get_trainer_dynamic(src_path=src, model_nbr=1, eval_mode=True)
+    assert type(ev).__name__ == "ACAITrainer" and args["trainer_class"] == "ACAITrainer"
+    x = torch.rand(3, 1, 32, 32)
+    assert rel_l2(ev.predict(x), tr.predict(x)) < 1e-6
