@@ -473,9 +473,29 @@ def gen_augmentation():
     np.savez_compressed(os.path.join(OUT, "augment_acdc.npz"), **rec)
 
 
+def gen_eval_crop():
+    """AdjustToPatchSize + CenterCrop as the evaluation uses them (evaluate/find_best_model.py:26-33) on small volumes."""
+    for name in ("cv2", "batchgenerators", "batchgenerators.transforms"):
+        if name not in sys.modules:
+            _stub(name)
+    _stub("batchgenerators.transforms.spatial_transforms", SpatialTransform=object)
+    _stub("batchgenerators.transforms.abstract_transforms", Compose=object)
+    import datasets.shared_transforms as st
+    rec = {}
+    for i, (shape, ps) in enumerate((((2, 20, 28), 32), ((2, 40, 52), 32), ((2, 33, 31), 32), ((1, 64, 64), 48), ((2, 29, 40), 32))):
+        v = np.random.RandomState(50 + i).rand(*shape).astype(np.float32)
+        out = st.CenterCrop(ps)(st.AdjustToPatchSize((ps, ps))({"image": v.copy()}))["image"]
+        rec["%d/in" % i], rec["%d/out" % i], rec["%d/ps" % i] = v, np.ascontiguousarray(out), np.array(ps)
+    np.savez_compressed(os.path.join(OUT, "eval_crop.npz"), **rec)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "eval_crop":
+        import_reference()
+        gen_eval_crop()
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "augment":
         import_reference()
         gen_augmentation()
@@ -500,6 +520,7 @@ def main():
     gen_laploss()
     gen_ae_standard_blocks()
     gen_augmentation()
+    gen_eval_crop()
     gen_ae_small(av, avs, avm)
     m = gen_ae_init(av)
     gen_ae_acdc_probe(m)

@@ -205,3 +205,19 @@ def test_evaluate_common_host_helpers(tmp_path):
     assert os.path.isfile(str(tmp_path / "results" / "linear_3x_axis1.npz"))
     with pytest.raises(NotImplementedError):
         ec.create_simple_interpolation(np.zeros((2, 2, 2)), np.ones(3), expand_factor=2)
+
+
+def test_evaluation_crop_and_masks_vs_reference_transforms():
+    """evaluate/find_best_model.adjust_and_center_crop == CenterCrop(AdjustToPatchSize(.)) of the reference's transform classes
+    (tests/golden/eval_crop.npz, incl. the padding rule that uses patch_size[0] for both axes); synthesis / reconstruction masks."""
+    from evaluate.find_best_model import adjust_and_center_crop, generate_synth_slices_mask, get_transforms, store_top_scores
+    rec = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eval_crop.npz"))
+    for i in range(5):
+        got = adjust_and_center_crop(rec["%d/in" % i], int(rec["%d/ps" % i]))
+        assert got.shape == rec["%d/out" % i].shape and np.array_equal(got, rec["%d/out" % i]), i
+    t = get_transforms(32, to_tensor=True)({"image": rec["0/in"], "patient_id": 7})
+    assert torch.is_tensor(t["image"]) and t["patient_id"] == 7 and tuple(t["image"].shape) == (2, 32, 32)
+    r_mask, s_mask = generate_synth_slices_mask(9, 3)           # 9 slices, every 3rd kept: last paired slice = 6
+    assert r_mask.tolist() == [True, False, False, True, False, False, True] and (r_mask ^ s_mask).all()
+    top = store_top_scores("3", {}, [0.5, 0.7], [20.0, 30.0], [float("nan")] * 2)
+    assert top["3"][0] == pytest.approx(0.6) and top["3"][1] == 25.0 and np.isnan(top["3"][2])
