@@ -56,7 +56,7 @@ def get_trainer(args_dict=None, src_path=None, model_nbr=None, eval_mode=False, 
     if src_path is not None:
         _, args_dict = get_trainer_dynamic(src_path=src_path, model_nbr=model_nbr, args_only=True)
     model = (args_dict or {}).get("model", "").lower()
-    if model not in ("ae", "ae_combined"):
+    if model not in ("ae", "ae_combined", "acai", "acai_combined"):
         raise ValueError("Error - get trainer - no trainer available for model {}".format(model))
     from ..networks.net_config import NetworkConfig
     cfg = NetworkConfig(model, dataset=args_dict.get("dataset", "ACDC"), ae_class="VanillaACAI").architecture
