@@ -11,7 +11,9 @@ Rank 0 prints ONE JSON line (see DESIGN.md section "Measurement").
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -70,6 +72,64 @@ def cpu_baseline(B, H, steps=3):
                       "oracle/step_oracle.py on PyTorch-CPU fp32" % (steps, B, H, H), "s_per_step": round(dt, 3)}
 
 
+def make_line(opt, B, H, elapsed, launch, loss, roofline, engine):
+    """The JSON line of the contract for ``opt.steps`` steps that took ``elapsed`` seconds (max over ranks)."""
+    ms_per_step = 1e3 * elapsed / opt.steps
+    executed = STEP_GFLOP[opt.config] - (stem_folded_gflop(B, H) if engine.FUSE_STEM else 0.0)
+    line = {
+        "metric": "training slices/sec (ae_combined, %dx%d, latent=128)" % (H, H), "value": round(3 * B * opt.steps / elapsed, 1),
+        "unit": "slices/s", "n_gpus": opt.gpus, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": ("ACDC synthetic 12x(3x1x160x160) triplets, ae_combined latent=128 depth=32 scales=2, "
+                                + ("MSE synthesis loss (BASELINE configs[1])" if opt.config == "c2"
+                                   else "LPIPS-VGG synthesis loss lambda=0.05, synthetic backbone weights (BASELINE configs[2])"))
+                   if opt.config not in BRAIN else
+                   "%s synthetic %dx(3x1x%dx%d) triplets (global batch), ae_combined latent=128 depth=32, LPIPS-VGG synthesis loss lambda=0.001, "
+                   "synthetic backbone weights (BASELINE configs[%d])" % (BRAIN[opt.config][0], B, H, H, 3 if opt.config == "c4" else 4),
+                   "global_batch_triplets": B, "slices_per_step": 3 * B, "parallelism": "dp%d" % opt.gpus,
+                   "init": "reference Initializer, seed 892372, random weights", "launch": launch},
+        "step_algorithmic_gflop": STEP_GFLOP[opt.config],
+        "step_executed_mfma_gflop": round(executed, 2),
+        "step_tflops": round(executed / ms_per_step, 2),
+        "step_frac_of_f32_mfma_peak": round(executed / ms_per_step / PEAK_F32_MFMA_TFLOPS, 4),
+        "final_loss": round(float(loss), 6),
+    }
+    if roofline is not None:
+        line["roofline"] = roofline
+    return line
+
+
+_KEEPER_SRC = (
+    "import sys\n"
+    "last = None\n"
+    "for line in sys.stdin:\n"
+    "    if line.strip():\n"
+    "        last = line\n"
+    "if last is not None:\n"
+    "    sys.stdout.write(last if last.endswith('\\n') else last + '\\n')\n"
+    "    sys.stdout.flush()\n")
+
+
+class LineKeeper(object):
+    """Rank 0 under N > 1: a tiny child process that owns the real stdout and prints the LAST JSON line it was handed once its
+    stdin closes.  The bench first measures the host-launched data-parallel step (always available) and hands that line over,
+    then tries the graph-replayed step; if that attempt takes the process down, the child still prints the first line."""
+
+    def __init__(self, fd):
+        self.p = subprocess.Popen([sys.executable, "-c", _KEEPER_SRC], stdin=subprocess.PIPE, stdout=fd, close_fds=True)
+
+    def put(self, line):
+        self.p.stdin.write((json.dumps(line) + "\n").encode())
+        self.p.stdin.flush()
+
+    def close(self):
+        try:
+            self.p.stdin.close()
+            self.p.wait(timeout=30)
+        except Exception:              # noqa: BLE001
+            pass
+
+
 def main():
     # stdout must carry exactly ONE line (the JSON): libraries print banners there (RCCL prints its version block on the first
     # collective), so file descriptor 1 points at stderr for the whole run and the JSON line goes to the saved descriptor
@@ -85,10 +145,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--triplets", type=int, default=12, help="global batch in triplets (12 = the BASELINE workload; other values are for experiments only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured step")
-    ap.add_argument("--dp-graph", nargs="?", const="segments", default=None, choices=("segments", "whole"),
-                    help="N > 1: replay the step from HIP graphs instead of host launches -- 'segments' = a chain of graphs cut at the "
-                    "(eager) collectives, 'whole' = one graph with the RCCL collectives captured (both rehearsed on one GPU only: "
-                    "scripts/dp_graph_smoke.py, tests/test_gpu_dp.py)")
+    ap.add_argument("--dp-graph", nargs="?", const="segments", default="auto", choices=("auto", "off", "segments", "whole"),
+                    help="N > 1: 'auto' (default) times the host-launched step, then the graph-replayed step ('whole' = one graph "
+                    "with the RCCL collectives captured on the nccl backend, 'segments' = a chain of graphs cut at the eager "
+                    "collectives otherwise) and reports the faster; 'off' = host launches only; 'segments' / 'whole' = that form only")
     opt = ap.parse_args()
 
     from superresolution_aniso_mri_amd import engine
@@ -99,6 +159,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if opt.gpus > 1 and world != opt.gpus:
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (opt.gpus, opt.gpus))
+    # rank 0 of a multi-rank run: the child that will print the line (started before this process touches the GPU)
+    keeper = LineKeeper(real_stdout) if (world > 1 and int(os.environ.get("RANK", "0")) == 0) else None
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("AESR_SINGLE_DEVICE") == "1":       # rehearsal on a one-GPU box: every rank on cuda:0 (with AESR_DIST_BACKEND=gloo)
         local_rank = 0
@@ -113,9 +175,11 @@ def main():
     if dp.active:
         dp.attach(trainer)
         dp.set_batch(B)
-    use_graph = not opt.no_graph and (not dp.active or opt.dp_graph)
+    auto_dp = dp.active and opt.dp_graph == "auto" and not opt.no_graph
+    dp_mode = opt.dp_graph if (dp.active and opt.dp_graph in ("segments", "whole")) else None
+    use_graph = not opt.no_graph and (not dp.active or dp_mode is not None)
     if use_graph:
-        trainer.enable_step_graph(eager_steps=2, dp_mode=opt.dp_graph if dp.active else None)
+        trainer.enable_step_graph(eager_steps=2, dp_mode=dp_mode)
     # a small pool of distinct batches, sharded by triplet and resident in HBM before the timed region
     pool = []
     for i in range(4):
@@ -128,20 +192,53 @@ def main():
         for i in range(n):
             trainer.train(pool[(first + i) % len(pool)], keep_predictions=False)
 
-    run(opt.warmup)
-    dp.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(opt.steps, opt.warmup)
-    torch.cuda.synchronize()
-    dp.barrier()
-    elapsed = dp.max_over_ranks(time.perf_counter() - t0)
-    ms_per_step = 1e3 * elapsed / opt.steps
-    value = 3 * B * opt.steps / elapsed
+    def measure():
+        """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; max over ranks."""
+        run(opt.warmup)
+        dp.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(opt.steps, opt.warmup)
+        torch.cuda.synchronize()
+        dp.barrier()
+        return dp.max_over_ranks(time.perf_counter() - t0)
+
+    elapsed = measure()
+    launch = ("captured HIP graph replay" if not dp.active else
+              "HIP graph segments between eager collectives" if dp_mode == "segments" else
+              "one HIP graph per step with the RCCL collectives captured") if use_graph else "host launches"
+    graph_failed = False
+    if auto_dp:
+        # data parallel, default: the host-launched number is safe in the keeper before the graph-replayed step is attempted
+        import torch.distributed as dist
+        if keeper is not None:
+            keeper.put(make_line(opt, B, H, elapsed, "host launches", trainer.losses["loss_ae"][-1], None, engine))
+        mode = "whole" if dist.get_backend() == "nccl" else "segments"
+
+        def on_hang():           # every rank has its own timer: a stuck collective must not hold the job forever
+            sys.stderr.write("bench: the graph-replayed data-parallel step did not finish; reporting the host-launched step\n")
+            if keeper is not None:
+                keeper.close()
+            os._exit(0)
+        guard = threading.Timer(float(os.environ.get("AESR_DP_GRAPH_TIMEOUT", "120")), on_hang)
+        guard.daemon = True
+        guard.start()
+        try:
+            trainer.enable_step_graph(eager_steps=0, dp_mode=mode)
+            e2 = measure()
+            if e2 < elapsed:
+                elapsed = e2
+                launch = ("one HIP graph per step with the RCCL collectives captured" if mode == "whole"
+                          else "HIP graph segments between eager collectives")
+                use_graph = True
+        except Exception as exc:           # noqa: BLE001
+            sys.stderr.write("bench: graph-replayed data-parallel step failed (%r); reporting the host-launched step\n" % (exc,))
+            graph_failed = True
+        guard.cancel()
     loss = trainer.losses["loss_ae"][-1]
 
     roofline = None
-    if not opt.no_roofline:
+    if not opt.no_roofline and not graph_failed:
         # same steps again with one HIP-event pair around every MFMA convolution launch (on the launching stream)
         trainer._graph_enabled = False          # event pairs need host-side launches
         engine.PROFILER = engine.KernelProfiler()
@@ -176,35 +273,15 @@ def main():
     if dp.rank != 0:
         dp.shutdown()
         return
-    executed = STEP_GFLOP[opt.config] - (stem_folded_gflop(B, H) if engine.FUSE_STEM else 0.0)
-    line = {
-        "metric": "training slices/sec (ae_combined, %dx%d, latent=128)" % (H, H), "value": round(value, 1), "unit": "slices/s",
-        "n_gpus": opt.gpus, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("ACDC synthetic 12x(3x1x160x160) triplets, ae_combined latent=128 depth=32 scales=2, "
-                                + ("MSE synthesis loss (BASELINE configs[1])" if opt.config == "c2"
-                                   else "LPIPS-VGG synthesis loss lambda=0.05, synthetic backbone weights (BASELINE configs[2])"))
-                   if opt.config not in BRAIN else
-                   "%s synthetic %dx(3x1x%dx%d) triplets (global batch), ae_combined latent=128 depth=32, LPIPS-VGG synthesis loss lambda=0.001, "
-                   "synthetic backbone weights (BASELINE configs[%d])" % (BRAIN[opt.config][0], B, H, H, 3 if opt.config == "c4" else 4),
-                   "global_batch_triplets": B, "slices_per_step": 3 * B, "parallelism": "dp%d" % opt.gpus,
-                   "init": "reference Initializer, seed 892372, random weights",
-                   "launch": ("captured HIP graph replay" if not dp.active else
-                              "HIP graph segments between eager collectives" if opt.dp_graph == "segments" else
-                              "one HIP graph per step with the RCCL collectives captured") if use_graph
-                   else "host launches"},
-        "step_algorithmic_gflop": STEP_GFLOP[opt.config],
-        "step_executed_mfma_gflop": round(executed, 2),
-        "step_tflops": round(executed / ms_per_step, 2),
-        "step_frac_of_f32_mfma_peak": round(executed / ms_per_step / PEAK_F32_MFMA_TFLOPS, 4),
-        "final_loss": round(float(loss), 6),
-    }
-    if roofline is not None:
-        line["roofline"] = roofline
+    line = make_line(opt, B, H, elapsed, launch, loss, roofline, engine)
     if opt.gpus == 1 and not opt.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(B, H)
     sys.stdout.flush()
-    os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if keeper is not None:
+        keeper.put(line)
+        keeper.close()
+    else:
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     dp.shutdown()
 
 

@@ -134,7 +134,15 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """The current HIP stream of the current device as a void*.  ``torch.cuda.current_stream()`` builds a Stream object per call
+    (~9 us, several hundred calls per host-launched step); the raw accessor behind it takes ~0.5 us."""
+    if _raw_stream is not None and _cur_device is not None:
+        return c_void_p(_raw_stream(_cur_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -90,6 +90,12 @@ class BaseTrainer(object):
 
     _capture_sink = None      # dict while a step is being captured into a HIP graph (see AEBaseTrainer._train_graphed)
 
+    def _set_mode(self, training):
+        """``self.model.train(training)`` without walking ~35 sub-modules on every step when the mode is already set."""
+        m = self.model
+        if m.training != bool(training) or any(c.training != bool(training) for c in m.children()):
+            m.train(bool(training))
+
     def _log(self, key, value, is_test=False):
         if self._capture_sink is not None and not is_test:
             self._capture_sink[key] = value

@@ -107,7 +107,7 @@ class CombinedStepMixin(object):
     def train(self, batch_item, keep_predictions=True, eval_mode=False):
         dev_batch = {k: (self._to_device(v) if k in ("image", "slice_between", "alpha_from", "alpha_to") else v)
                      for k, v in batch_item.items()}
-        self.model.train(not eval_mode)
+        self._set_mode(not eval_mode)
         self._iters += 1
         self._lambda_tensor()
         if self._graph_ok(keep_predictions, eval_mode):

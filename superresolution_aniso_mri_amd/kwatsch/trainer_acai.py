@@ -87,7 +87,7 @@ class ACAITrainer(AETrainerExtension1Brain):
         dev = self.args["device"]
         x = self._to_device(batch_item["image"])
         between = self._to_device(batch_item["slice_between"])
-        self.model.train(not eval_mode)
+        self._set_mode(not eval_mode)
         self._iters += 1
         B = x.shape[0] // 2
         if self.train_combined:
@@ -114,7 +114,7 @@ class ACAITrainer(AETrainerExtension1Brain):
             with torch.no_grad():
                 r = self.synthesize_batch_images(batch_item=batch_item, z=z.detach(), compute_latent_loss=True, slice_between=between,
                                                  is_eval=True)
-                self.model.train(not eval_mode)
+                self._set_mode(not eval_mode)
                 s_mix, z_mix, loss_latent = r["s_between_mix"], r["z_mix"], r["loss_latent"]
                 self.get_extra_loss(between, s_mix, z_mix, z=z, mask=mask, is_test=True)
         self.opt_ae.zero_grad()

@@ -141,7 +141,7 @@ class AEBaseTrainer(BaseTrainer):
     def train(self, batch_item, keep_predictions=True, eval_mode=False):
         """Plain ``ae`` step (reference :71-109): reconstruction loss only; latent loss and the 0.5-mix are logged."""
         x = self._to_device(batch_item["image"])
-        self.model.train(not eval_mode)
+        self._set_mode(not eval_mode)
         self._iters += 1
         z = self.model.encode(x)
         out = self.model.decode(z)
@@ -149,7 +149,7 @@ class AEBaseTrainer(BaseTrainer):
         a_from, a_to = self._mix_coefficients(batch_item, x.shape[0] // 2)
         lat = self.get_latent_loss(reference=self._to_device(batch_item["slice_between"]), alpha_from=a_from, alpha_to=a_to,
                                    z=z.detach(), no_grad=True)
-        self.model.train(not eval_mode)
+        self._set_mode(not eval_mode)
         self._backward_and_step(loss_ae, eval_mode)
         self._log("loss_ae", loss_ae)
         self._log("loss_latent_1", lat["loss_latent"])
