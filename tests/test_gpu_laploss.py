@@ -124,3 +124,29 @@ def test_trainer_with_laploss_vs_oracle(loss):
     assert abs(tr.losses["loss_ae"][-1] - float(total)) < 2e-5 * float(total)
     for k, p in tr.model.named_parameters():
         assert rel_l2(p.grad, o.params[k].grad) < 5e-4, k
+
+
+def test_laploss_step_replays_from_graph():
+    """The LapLoss kernels are capture-safe: the step with ``use_laploss`` replayed from a HIP graph equals the host-launched step."""
+    from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    from superresolution_aniso_mri_amd.networks.net_config import NetworkConfig
+    args = dict(model="ae_combined", dataset="ACDC", device="cuda", lr=1e-4, weight_decay=0.0, epochs=10, ex_loss_weight1=0.05,
+                use_percept_loss=False, get_masks=False, use_loss_annealing=False, use_extra_latent_loss=False, epoch_threshold=100,
+                ae_class="VanillaACAI", image_mix_loss_func="mse", use_laploss=True, width=32, latent_width=8, depth=8, latent=16)
+    for k, v in NetworkConfig("ae_combined", dataset="ACDC").architecture.items():
+        args.setdefault(k, v)
+    torch.manual_seed(5)
+    eager = get_trainer_dynamic(dict(args))
+    graphed = get_trainer_dynamic(dict(args))
+    graphed.model.load_state_dict(eager.model.state_dict())
+    graphed.enable_step_graph(eager_steps=1)
+    for step in range(5):
+        batch = synthetic_batch(3, 32, 32, seed=40 + step)
+        eager.train(batch, keep_predictions=False)
+        graphed.train(batch, keep_predictions=False)
+    assert len(graphed._graphs) == 1
+    for key in ("loss_ae", "loss_laploss", "loss_ae_dist_extra"):
+        assert graphed.losses[key].floats() == eager.losses[key].floats(), key
+    for (k, a), (_, b) in zip(eager.model.state_dict().items(), graphed.model.state_dict().items()):
+        assert torch.equal(a, b), k
