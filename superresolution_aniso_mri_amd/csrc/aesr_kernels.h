@@ -105,6 +105,8 @@ struct BnBwdArgs {
     int N, H, W, C, Ho, Wo, mode, act;
     float slope;
     BnGroups gr;
+    unsigned long long m_hw, m_w;   // exact-division constants for H*W and W (filled by the bn_bwd_reduce launcher)
+    int k_hw, k_w;
 };
 int aesr_launch_bn_stats(const float* y, float* partial, int HW, int C, const BnGroups& gr, int nwg, hipStream_t st);
 int aesr_launch_bn_reduce(const float* partial, double* sums, int nwg, int C, int G, hipStream_t st);

@@ -197,13 +197,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
 
 // ---- backward --------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ f32x4 bn_gather_g(const BnBwdArgs& a, int n, int yy, int x, int c4) {
+// MODE < 0: decided at run time (apply pass); MODE >= 0: compile-time mode, branch-free loads (reduce pass: a divergent bounds
+// branch in front of the load kept the compiler from batching the loads of the unrolled pixels)
+template <int MODE>
+__device__ __forceinline__ f32x4 bn_gather_g_t(const BnBwdArgs& a, int n, int yy, int x, int c4) {
     // gradient w.r.t. the BN output at full-resolution BN pixel (yy, x)
-    if (a.mode == BN_MODE_POOL) {
+    const int mode = MODE < 0 ? a.mode : MODE;
+    if (mode == BN_MODE_POOL) {
         const int py = yy >> 1, px = x >> 1;
-        if (py >= a.Ho || px >= a.Wo) return (f32x4){0.f, 0.f, 0.f, 0.f};
-        return *(const f32x4*)(a.gout + (((size_t)n * a.Ho + py) * a.Wo + px) * a.C + c4 * 4) * 0.25f;
-    } else if (a.mode == BN_MODE_UP) {
+        if (MODE < 0) {
+            if (py >= a.Ho || px >= a.Wo) return (f32x4){0.f, 0.f, 0.f, 0.f};
+            return *(const f32x4*)(a.gout + (((size_t)n * a.Ho + py) * a.Wo + px) * a.C + c4 * 4) * 0.25f;
+        }
+        const float w = (py < a.Ho && px < a.Wo) ? 0.25f : 0.f;          // odd H / W: the last row / column is not pooled
+        return *(const f32x4*)(a.gout + (((size_t)n * a.Ho + min(py, a.Ho - 1)) * a.Wo + min(px, a.Wo - 1)) * a.C + c4 * 4) * w;
+    } else if (mode == BN_MODE_UP) {
         const float* b = a.gout + (((size_t)n * a.Ho + 2 * yy) * a.Wo + 2 * x) * a.C + c4 * 4;
         return (*(const f32x4*)b + *(const f32x4*)(b + a.C)) +
                (*(const f32x4*)(b + (size_t)a.Wo * a.C) + *(const f32x4*)(b + (size_t)a.Wo * a.C + a.C));
@@ -211,7 +219,15 @@ __device__ __forceinline__ f32x4 bn_gather_g(const BnBwdArgs& a, int n, int yy, 
     return *(const f32x4*)(a.gout + (((size_t)n * a.H + yy) * a.W + x) * a.C + c4 * 4);
 }
 
+__device__ __forceinline__ f32x4 bn_gather_g(const BnBwdArgs& a, int n, int yy, int x, int c4) { return bn_gather_g_t<-1>(a, n, yy, x, c4); }
+
+// exact floor(p / d) for p < 2^31 with the host's (m, k) = (ceil(2^k / d), 31 + ceil(log2 d)): one 64-bit multiply and a shift
+__device__ __forceinline__ unsigned bn_fastdiv(unsigned p, unsigned long long m, int k) {
+    return (unsigned)(((unsigned long long)p * m) >> k);
+}
+
 // grid = (nwg, G)
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int C4 = a.C >> 2, PL = 256 / C4;
@@ -223,14 +239,44 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
     const f32x4 iv = *(const f32x4*)(a.invstd + g * a.C + c4 * 4);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     if (pl < PL) {
-        for (unsigned p = p0 + blockIdx.x * PL + pl; p < p1; p += gridDim.x * PL) {
-            const unsigned n = p / HW;
+        // BNR_U pixels per trip: their loads (y and the 1..4 gathered gradient pieces each) are independent, which multiplies the
+        // bytes in flight per thread -- one pixel per trip left the kernel latency-bound (2.2-3.6 TB/s with 8 waves per CU)
+        constexpr int U = 2;
+        const unsigned S = gridDim.x * PL;
+        unsigned p = p0 + blockIdx.x * PL + pl;
+        f32x4 a1[U], a2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a1[u] = a2[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (; p + (U - 1) * S < p1; p += U * S) {
+            f32x4 v[U], gq[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned q = p + u * S;
+                const unsigned n = bn_fastdiv(q, a.m_hw, a.k_hw);          // q / HW, q % HW, rem / W without ~40-instruction
+                const unsigned rem = q - n * HW;                            // divisions (C/4 threads repeat them per pixel)
+                const unsigned yy = bn_fastdiv(rem, a.m_w, a.k_w);
+                v[u] = *(const f32x4*)(a.y + (size_t)q * a.C + c4 * 4);
+                gq[u] = bn_gather_g_t<MODE>(a, n, yy, rem - yy * a.W, c4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                a1[u] += gq[u];
+                a2[u] += gq[u] * ((v[u] - mu) * iv);
+            }
+        }
+        for (; p < p1; p += S) {
+            const unsigned n = bn_fastdiv(p, a.m_hw, a.k_hw);
             const unsigned rem = p - n * HW;
-            const unsigned yy = rem / (unsigned)a.W, x = rem - yy * a.W;
-            const f32x4 gg = bn_gather_g(a, n, yy, x, c4);
+            const unsigned yy = bn_fastdiv(rem, a.m_w, a.k_w), x = rem - yy * a.W;
+            const f32x4 gg = bn_gather_g_t<MODE>(a, n, yy, x, c4);
             const f32x4 xh = (*(const f32x4*)(a.y + (size_t)p * a.C + c4 * 4) - mu) * iv;
             s1 += gg;
             s2 += gg * xh;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s1 += a1[u];
+            s2 += a2[u];
         }
         *(f32x4*)(red + (pl * 2 + 0) * a.C + c4 * 4) = s1;
         *(f32x4*)(red + (pl * 2 + 1) * a.C + c4 * 4) = s2;
@@ -389,10 +435,25 @@ int aesr_launch_bn_apply(const BnApplyArgs& a, hipStream_t st) {
     return AESR_OK;
 }
 
-int aesr_launch_bn_bwd_reduce(const BnBwdArgs& a, int nwg, hipStream_t st) {
+static void bn_magic(unsigned d, unsigned long long* m, int* k) {
+    int L = 0;
+    while ((1u << L) < d) ++L;
+    *k = 31 + L;
+    const unsigned __int128 one = (unsigned __int128)1 << *k;
+    *m = (unsigned long long)((one + d - 1) / d);
+}
+
+int aesr_launch_bn_bwd_reduce(const BnBwdArgs& a_in, int nwg, hipStream_t st) {
+    BnBwdArgs a = a_in;
+    bn_magic((unsigned)(a.H * a.W), &a.m_hw, &a.k_hw);
+    bn_magic((unsigned)a.W, &a.m_w, &a.k_w);
     if (int e = bn_check_c(a.C, "bn_bwd_reduce")) return e;
     const int PL = 256 / (a.C / 4);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nwg, a.gr.G), dim3(256), (size_t)PL * 2 * a.C * sizeof(float), st, a);
+    const dim3 grid(nwg, a.gr.G);
+    const size_t shm = (size_t)PL * 2 * a.C * sizeof(float);
+    if (a.mode == BN_MODE_POOL) hipLaunchKernelGGL(bn_bwd_reduce_kernel<BN_MODE_POOL>, grid, dim3(256), shm, st, a);
+    else if (a.mode == BN_MODE_UP) hipLaunchKernelGGL(bn_bwd_reduce_kernel<BN_MODE_UP>, grid, dim3(256), shm, st, a);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, grid, dim3(256), shm, st, a);
     AESR_LAUNCH_CHECK("bn_bwd_reduce");
     return AESR_OK;
 }
