@@ -31,8 +31,17 @@ for name, N, H, C, mode in CASES:
     def apply():
         hip.check(L.aesr_bn_bwd_apply(hip.ptr(g), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(scale), hip.ptr(sums), counts, hip.ptr(coef),
                                       hip.ptr(dg), hip.ptr(db), hip.ptr(dpre), N, H, H, C, mode, 1, 0.01, 1, ns, hip.stream()), "apply")
+    out = torch.empty_like(g)
+    shift = torch.zeros(1, C, device="cuda")
+
+    def fwd_apply():
+        hip.check(L.aesr_bn_apply(hip.ptr(y), hip.ptr(scale), hip.ptr(shift), hip.ptr(out), N, H, H, C, mode, 1, ns, hip.stream()), "fwd apply")
+
+    def fwd_stats():
+        hip.check(L.aesr_bn_stats(hip.ptr(y), hip.ptr(partial), hip.ptr(sums), H * H, C, 1, ns, hip.stream()), "fwd stats")
     yb, gb = y.numel() * 4 / 1e6, g.numel() * 4 / 1e6
-    for fn, mb, label in ((reduce, yb + gb, "bwd_reduce(+sum kernel)"), (apply, 2 * yb + gb, "bwd_apply(+finalize)")):
+    for fn, mb, label in ((fwd_stats, yb, "fwd_stats(+sum kernel)"), (fwd_apply, yb + gb, "fwd_apply"),
+                          (reduce, yb + gb, "bwd_reduce(+sum kernel)"), (apply, 2 * yb + gb, "bwd_apply(+finalize)")):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()

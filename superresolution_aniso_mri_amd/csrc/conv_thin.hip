@@ -212,9 +212,11 @@ __global__ __launch_bounds__(256) void thin_collapse_kernel(const float* __restr
     const float b0 = bias ? bias[0] : 0.f;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const float* base = x + ((size_t)n * H * W + (live ? xc : 0)) * C + c4 * 4;
+    // branch-free: every lane loads from a clamped (always valid) row and the value is zeroed afterwards, so the 4 loads of a
+    // chunk are issued back to back (a bounds branch in front of each load serialised them: 3.2 TB/s)
     auto load1 = [&](int yy) -> f32x4 {
-        if (live && yy >= 0 && yy < H) return *(const f32x4*)(base + (size_t)yy * W * C);
-        return zero;
+        const f32x4 v = *(const f32x4*)(base + (size_t)min(max(yy, 0), H - 1) * W * C);
+        return (live && yy >= 0 && yy < H) ? v : zero;
     };
     f32x4 r[6];
     r[0] = load1(y0 - 1);
