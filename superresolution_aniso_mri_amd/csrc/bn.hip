@@ -150,19 +150,52 @@ __device__ __forceinline__ double bn_column_total(const float* __restrict__ base
     return red[0][col];
 }
 
+
+// All 2*G column totals of a block's 16 channels with ONE wait on global memory: the 64 row-lanes of the block are split over the
+// 2*G quantities (q = 2*g + {0: first sum, 1: second sum}), each thread strides its quantity's nwg partial rows, the partial
+// sums meet in LDS and 2*G*16 threads add them up in a fixed order.  (Four bn_column_total calls = four dependent rounds of
+// global latency + 32 barriers: 10 us for a few KB.)  tot[q][col] is valid for every thread after the call.  G <= 4.
+__device__ __forceinline__ void bn_all_totals(const float* __restrict__ partial, int nwg, int C, int G, int c, bool live,
+                                              double (*red)[BNR_COLS], double (*tot)[BNR_COLS], int col, int slot) {
+    const int NQ = 2 * G, RLQ = BNR_RL / NQ;
+    const int q = slot % NQ, rl = slot / NQ;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (live && rl < RLQ) {
+        const float* base = partial + ((size_t)(q >> 1) * nwg * 2 + (q & 1)) * C + c;      // partial[g][k][s][c], row stride 2*C
+        const size_t rs = (size_t)2 * C;
+        int k = rl;
+        for (; k + 7 * RLQ < nwg; k += 8 * RLQ) {          // 8 independent loads in flight per thread
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base[(k + u * RLQ) * rs];
+            s0 += (double)v[0] + (double)v[4];
+            s1 += (double)v[1] + (double)v[5];
+            s2 += (double)v[2] + (double)v[6];
+            s3 += (double)v[3] + (double)v[7];
+        }
+        for (; k < nwg; k += RLQ) s0 += (double)base[k * rs];
+    }
+    red[slot][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slot < NQ) {
+        double t = 0.0;
+        for (int r = 0; r < RLQ; ++r) t += red[r * NQ + slot][col];
+        tot[slot][col] = t;
+    }
+    __syncthreads();
+}
+
 // Statistics partials -> finalize in ONE launch (no SyncBN exchange in between).  block = 16 channels x 64 row-lanes.
 __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ partial, int nwg, BnFinArgs f) {
     __shared__ double red[BNR_RL][BNR_COLS];
+    __shared__ double tot[8][BNR_COLS];
     const int col = threadIdx.x % BNR_COLS, rl = threadIdx.x / BNR_COLS;
     const int c = blockIdx.x * BNR_COLS + col;
     const bool live = c < f.C;
     if (c == 0 && rl == 0 && f.update_running && f.nbt) *f.nbt += f.G;
-    for (int g = 0; g < f.G; ++g) {
-        const float* base = partial + (size_t)g * nwg * 2 * f.C + c;
-        const double s0 = bn_column_total(base, nwg, 2 * f.C, live, red, col, rl);
-        const double s1 = bn_column_total(base + f.C, nwg, 2 * f.C, live, red, col, rl);
-        if (rl == 0 && live) bn_finalize_one(f, c, g, s0, s1);
-    }
+    bn_all_totals(partial, nwg, f.C, f.G, c, live, red, tot, col, rl);
+    if (rl == 0 && live)
+        for (int g = 0; g < f.G; ++g) bn_finalize_one(f, c, g, tot[2 * g][col], tot[2 * g + 1][col]);      // group order: running stats
 }
 
 // ---- forward apply (+pool / +upsample) ----------------------------------------------------------------
@@ -315,19 +348,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_finalize_kernel(const floa
     const int col = threadIdx.x % BNR_COLS, rl = threadIdx.x / BNR_COLS;
     const int c = blockIdx.x * BNR_COLS + col;
     const bool live = c < C;
-    double dg = 0.0, db = 0.0;
-    for (int g = 0; g < G; ++g) {
-        const float* base = partial + (size_t)g * nwg * 2 * C + c;
-        const double s1 = bn_column_total(base, nwg, 2 * C, live, red, col, rl);
-        const double s2 = bn_column_total(base + C, nwg, 2 * C, live, red, col, rl);
-        if (rl == 0 && live) {
+    __shared__ double tot[8][BNR_COLS];
+    bn_all_totals(partial, nwg, C, G, c, live, red, tot, col, rl);
+    if (rl == 0 && live) {
+        double dg = 0.0, db = 0.0;
+        for (int g = 0; g < G; ++g) {
+            const double s1 = tot[2 * g][col], s2 = tot[2 * g + 1][col];
             coef[(g * 2 + 0) * C + c] = (float)(s1 / counts.c[g]);
             coef[(g * 2 + 1) * C + c] = (float)(s2 / counts.c[g]);
             db += s1;
             dg += s2;
         }
-    }
-    if (rl == 0 && live) {
         dgamma[c] = (float)dg;
         dbeta[c] = (float)db;
     }
