@@ -121,40 +121,14 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, BnFinArgs f)
         bn_finalize_one(f, c, g, f.train ? sums[(g * 2 + 0) * f.C + c] : 0.0, f.train ? sums[(g * 2 + 1) * f.C + c] : 0.0);
 }
 
-// column sums of partial[g][wg][2][C] for one channel column: BNR_RL row-lanes x 4 independent accumulators, fixed
-// order.  Returns the total in the rl == 0 threads.  red: [BNR_RL][BNR_COLS] doubles.
+// block layout of the finalize kernels: 16 channels x 64 row-lanes
 #define BNR_COLS 16
 #define BNR_RL 64
-__device__ __forceinline__ double bn_column_total(const float* __restrict__ base, int nwg, int rowstride, bool live,
-                                                  double (*red)[BNR_COLS], int col, int rl) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    if (live) {
-        int k = rl;
-        for (; k + 3 * BNR_RL < nwg; k += 4 * BNR_RL) {
-            const float v0 = base[(size_t)k * rowstride], v1 = base[(size_t)(k + BNR_RL) * rowstride];
-            const float v2 = base[(size_t)(k + 2 * BNR_RL) * rowstride], v3 = base[(size_t)(k + 3 * BNR_RL) * rowstride];
-            s0 += (double)v0;
-            s1 += (double)v1;
-            s2 += (double)v2;
-            s3 += (double)v3;
-        }
-        for (; k < nwg; k += BNR_RL) s0 += (double)base[(size_t)k * rowstride];
-    }
-    __syncthreads();
-    red[rl][col] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    for (int h = BNR_RL / 2; h > 0; h >>= 1) {
-        if (rl < h) red[rl][col] += red[rl + h][col];
-        __syncthreads();
-    }
-    return red[0][col];
-}
-
 
 // All 2*G column totals of a block's 16 channels with ONE wait on global memory: the 64 row-lanes of the block are split over the
 // 2*G quantities (q = 2*g + {0: first sum, 1: second sum}), each thread strides its quantity's nwg partial rows, the partial
-// sums meet in LDS and 2*G*16 threads add them up in a fixed order.  (Four bn_column_total calls = four dependent rounds of
-// global latency + 32 barriers: 10 us for a few KB.)  tot[q][col] is valid for every thread after the call.  G <= 4.
+// sums meet in LDS and 2*G*16 threads add them up in a fixed order.  (One total at a time = four dependent rounds of global
+// latency + 32 barriers: 10 us for a few KB.)  tot[q][col] is valid for every thread after the call.  G <= 4.
 __device__ __forceinline__ void bn_all_totals(const float* __restrict__ partial, int nwg, int C, int G, int c, bool live,
                                               double (*red)[BNR_COLS], double (*tot)[BNR_COLS], int col, int slot) {
     const int NQ = 2 * G, RLQ = BNR_RL / NQ;
