@@ -37,6 +37,24 @@ class _LerpFn(torch.autograd.Function):
         return dz, None, None
 
 
+_CONST_VECS = {}
+
+
+def _const_vec(n, value, device):
+    """[n] fp32 tensor filled with ``value``, cached per (device, n, value): the scalar mixing coefficients (0.5 / 0.5) are the same
+    every step, so no fill kernel runs per call.  While a stream is capturing, a fresh tensor is made instead (a tensor born in a
+    graph's private pool must not outlive the graph through this cache)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.full((n,), float(value), dtype=torch.float32, device=device)
+    key = (str(device), int(n), float(value))
+    t = _CONST_VECS.get(key)
+    if t is None:
+        if len(_CONST_VECS) > 64:
+            _CONST_VECS.clear()
+        t = _CONST_VECS[key] = torch.full((n,), float(value), dtype=torch.float32, device=device)
+    return t
+
+
 def lerp_mix(z, alpha_from, alpha_to):
     """z: logical NCHW [2B,C,H,W] (rows i and i+B are a pair).  alpha_*: [B] or [B,1] or scalar.
     Returns z_mix [B,C,H,W] = alpha_from*z[:B] + alpha_to*z[B:]."""
@@ -50,7 +68,7 @@ def lerp_mix(z, alpha_from, alpha_to):
 
     def coef(a):
         if isinstance(a, (int, float)):
-            return torch.full((B,), float(a), dtype=torch.float32, device=z.device)     # fill kernel: graph-capture safe
+            return _const_vec(B, a, z.device)
         a = torch.as_tensor(a, dtype=torch.float32, device=z.device).reshape(-1)
         if a.numel() == 1:
             a = a.expand(B)
@@ -75,10 +93,14 @@ class _MseFn(torch.autograd.Function):
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         g = g.reshape(1).contiguous().float()
+        need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if need_b and not need_a:            # d/db = 2(b-a)g/n: the same kernel with the operands swapped, no negation pass
+            db = torch.empty_like(b)
+            check(lib.aesr_mse_bwd(ptr(b), ptr(a), ptr(g), ptr(db), b.numel(), stream()), "aesr_mse_bwd")
+            return None, db
         da = torch.empty_like(a)
         check(lib.aesr_mse_bwd(ptr(a), ptr(b), ptr(g), ptr(da), a.numel(), stream()), "aesr_mse_bwd")
-        db = -da if ctx.needs_input_grad[1] else None
-        return (da if ctx.needs_input_grad[0] else None), db
+        return (da if need_a else None), (-da if need_b else None)
 
 
 def mse_loss(a, b):
