@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
 
 // ---- backward --------------------------------------------------------------------------------------------
 
-// MODE < 0: decided at run time (apply pass); MODE >= 0: compile-time mode, branch-free loads (reduce pass: a divergent bounds
-// branch in front of the load kept the compiler from batching the loads of the unrolled pixels)
+// MODE >= 0: compile-time mode with branch-free loads (a divergent bounds branch in front of the load kept the compiler from
+// batching the loads of the unrolled pixels); MODE < 0 keeps the run-time form
 template <int MODE>
 __device__ __forceinline__ f32x4 bn_gather_g_t(const BnBwdArgs& a, int n, int yy, int x, int c4) {
     // gradient w.r.t. the BN output at full-resolution BN pixel (yy, x)
@@ -225,8 +225,6 @@ __device__ __forceinline__ f32x4 bn_gather_g_t(const BnBwdArgs& a, int n, int yy
     }
     return *(const f32x4*)(a.gout + (((size_t)n * a.H + yy) * a.W + x) * a.C + c4 * 4);
 }
-
-__device__ __forceinline__ f32x4 bn_gather_g(const BnBwdArgs& a, int n, int yy, int x, int c4) { return bn_gather_g_t<-1>(a, n, yy, x, c4); }
 
 // exact floor(p / d) for p < 2^31 with the host's (m, k) = (ceil(2^k / d), 31 + ceil(log2 d)): one 64-bit multiply and a shift
 __device__ __forceinline__ unsigned bn_fastdiv(unsigned p, unsigned long long m, int k) {
@@ -338,6 +336,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_finalize_kernel(const floa
     }
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     const int C4 = a.C >> 2;
     const size_t total = (size_t)a.N * a.H * a.W * C4;
@@ -355,7 +354,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
         const f32x4 k1 = *(const f32x4*)(a.coef + (g * 2 + 0) * a.C + c4 * 4);
         const f32x4 k2 = *(const f32x4*)(a.coef + (g * 2 + 1) * a.C + c4 * 4);
         const f32x4 yv = *(const f32x4*)(a.y + idx * 4);
-        const f32x4 gg = bn_gather_g(a, n, yy, x, c4);
+        const f32x4 gg = bn_gather_g_t<MODE>(a, n, yy, x, c4);
         const f32x4 xh = (yv - mu) * iv;
         f32x4 d = sc * (gg - k1 - xh * k2);
 #pragma unroll
@@ -477,7 +476,9 @@ int aesr_launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t st) {
     const size_t total = (size_t)a.N * a.H * a.W * (a.C / 4);
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, a);
+    if (a.mode == BN_MODE_POOL) hipLaunchKernelGGL(bn_bwd_apply_kernel<BN_MODE_POOL>, dim3(grid), dim3(256), 0, st, a);
+    else if (a.mode == BN_MODE_UP) hipLaunchKernelGGL(bn_bwd_apply_kernel<BN_MODE_UP>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(grid), dim3(256), 0, st, a);
     AESR_LAUNCH_CHECK("bn_bwd_apply");
     return AESR_OK;
 }
