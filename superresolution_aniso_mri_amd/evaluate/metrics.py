@@ -7,7 +7,8 @@ is smaller than 8 pixels in a dimension, as the reference does for long-axis vie
 covariance, mean over the fully covered windows; PSNR = 10 log10(R^2 / mse).  ``data_range`` R is explicit here
 (default 1.0: images are normalised to [0, 1]); skimage releases older than 0.19 silently used R = 2 for float input --
 pass ``data_range=2.0`` to reproduce numbers produced with such an installation.
-Not covered: VIF, LPIPS-per-slice and HD metrics of the same file (outside the ae_combined path)."""
+``compute_lpips_for_batch`` (:210-243) scores all kept slices with ONE batched LPIPS pass instead of a criterion call and a host
+sync per slice.  Not covered: VIF and HD metrics of the same file (outside the ae_combined path)."""
 import numpy as np
 import torch
 
@@ -108,3 +109,23 @@ def compute_psnr_for_batch(l_images, l_reconstructions, eval_axis=0, normalize=F
     if a.shape[0] == 1:
         return float(psnr[0])
     return float(np.mean(psnr[keep]))
+
+
+def compute_lpips_for_batch(l_images, l_reconstructions, eval_axis=0, normalize=False, downsample_steps=None, conv_interpol=False,
+                            criterion=None, device="cuda"):
+    """Mean LPIPS distance over the slices of a volume (original slices skipped when ``downsample_steps`` is given), reference
+    evaluate/metrics.py:210-243.  ``criterion``: a ``PerceptualLoss`` (built with the reference's arguments when omitted)."""
+    _check_axis(eval_axis)
+    if criterion is None:
+        from ..lpips.perceptual import PerceptualLoss
+        criterion = PerceptualLoss(model="net-lin", net="vgg", use_gpu=True, gpu_ids=[0], device=device)
+    a, b = _as_volume(l_images, device), _as_volume(l_reconstructions, device)
+    if normalize:
+        b = rescale_intensities(b, percs=(0, 100))
+    keep = np.ones(a.shape[0], dtype=bool)
+    if downsample_steps is not None and a.shape[0] > 1:
+        keep[determine_original_sliceids(a, downsample_steps, conv_interpol)] = False
+    idx = torch.from_numpy(np.nonzero(keep)[0]).to(a.device)
+    with torch.no_grad():
+        d = criterion(a[idx][:, None].contiguous(), b[idx][:, None].contiguous(), normalize=True)
+    return float(d.double().mean())

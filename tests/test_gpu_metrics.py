@@ -56,3 +56,18 @@ def test_bad_window_fails_loudly():
     rc = hip.lib.aesr_ssim_mse(hip.ptr(a), hip.ptr(a), hip.ptr(ws), hip.ptr(out[0:1]), hip.ptr(out[1:2]), 1, 4, 4, 7, 1.0, 0.01, 0.03,
                                hip.stream())
     assert rc != 0 and "win" in hip.last_error()
+
+
+def test_lpips_for_batch_equals_per_slice_calls():
+    """compute_lpips_for_batch (evaluate/metrics.py:210-243): one batched pass == the reference's per-slice loop, original slices of
+    a sub-sampled volume skipped."""
+    from evaluate.metrics import compute_lpips_for_batch, determine_original_sliceids
+    from superresolution_aniso_mri_amd.lpips.perceptual import PerceptualLoss
+    g = torch.Generator().manual_seed(4)
+    a, b = torch.rand(7, 32, 32, generator=g), torch.rand(7, 32, 32, generator=g)
+    crit = PerceptualLoss(model="net-lin", net="vgg", use_gpu=True, gpu_ids=[0], device="cuda", vgg_weights="synthetic-hash")
+    with torch.no_grad():
+        per_slice = [float(crit(a[z][None, None].cuda(), b[z][None, None].cuda(), normalize=True)) for z in range(7)]
+    assert abs(compute_lpips_for_batch(a, b.numpy(), criterion=crit) - np.mean(per_slice)) < 1e-6
+    keep = [z for z in range(7) if z not in set(determine_original_sliceids(a, 3).tolist())]
+    assert abs(compute_lpips_for_batch(a, b, downsample_steps=3, criterion=crit) - np.mean([per_slice[z] for z in keep])) < 1e-6
