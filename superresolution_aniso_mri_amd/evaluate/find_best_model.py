@@ -61,8 +61,9 @@ def generate_synth_slices_mask(orig_num_slices, downsample_steps):
     return ~s_mask, s_mask
 
 
-def compute_metrics(images_ref, new_images, downsample_steps, data_range=1.0):
-    """{'ssim','psnr','ssim_synth','psnr_synth','ssim_recon','psnr_recon'} of one volume (create_HR_images.py:121-178)."""
+def compute_metrics(images_ref, new_images, downsample_steps, data_range=1.0, compute_percept_loss=False, percept_loss=None):
+    """{'ssim','psnr','ssim_synth','psnr_synth','ssim_recon','psnr_recon'[,'lpips']} of one volume (create_HR_images.py:121-178;
+    LPIPS over all scored slices only, as there: the masked calls pass compute_percept_loss=False)."""
     last = _common.determine_last_slice(images_ref.shape[0], downsample_steps) + 1
     r_mask, s_mask = generate_synth_slices_mask(images_ref.shape[0], downsample_steps)
     ssim, psnr, _ = _metrics.slice_ssim_psnr(images_ref[:last], new_images[:last], data_range=data_range)
@@ -71,9 +72,12 @@ def compute_metrics(images_ref, new_images, downsample_steps, data_range=1.0):
         v = psnr[sel]
         return float(np.mean(v[np.isfinite(v)]))
     everything = np.ones(last, dtype=bool)
-    return {"ssim": float(np.mean(ssim)), "psnr": mean_psnr(everything),
-            "ssim_synth": float(np.mean(ssim[s_mask])), "psnr_synth": mean_psnr(s_mask),
-            "ssim_recon": float(np.mean(ssim[r_mask])), "psnr_recon": mean_psnr(r_mask)}
+    out = {"ssim": float(np.mean(ssim)), "psnr": mean_psnr(everything),
+           "ssim_synth": float(np.mean(ssim[s_mask])), "psnr_synth": mean_psnr(s_mask),
+           "ssim_recon": float(np.mean(ssim[r_mask])), "psnr_recon": mean_psnr(r_mask)}
+    if compute_percept_loss:
+        out["lpips"] = _metrics.compute_lpips_for_batch(images_ref[:last], new_images[:last], criterion=percept_loss)
+    return out
 
 
 def _as_list(data_generator):
@@ -83,7 +87,7 @@ def _as_list(data_generator):
 
 
 def evaluate_interpolation_performance(trainer, myargs, data_generator, transform=None, downsample_steps=None, file_suffix=None,
-                                       patient_id=None, eval_axis=0):
+                                       patient_id=None, eval_axis=0, compute_percept_loss=False, percept_loss=None):
     """evaluate/evaluate_interpolations.py:45-63 -> create_hr_images(generate_inbetween_slices=True, use_original_slice=False,
     num_interpolations = downsample_steps - 1): result lists per volume."""
     if eval_axis != 0:
@@ -102,9 +106,12 @@ def evaluate_interpolation_performance(trainer, myargs, data_generator, transfor
         ref = batch.get("image_hr")
         out = _common.create_super_volume(trainer, images, alpha_range=alpha_range, use_original=False,
                                           downsample_steps=downsample_steps, generate_inbetween_slices=True)
-        m = compute_metrics(images if ref is None else ref, out["upsampled_image"], downsample_steps)
+        m = compute_metrics(images if ref is None else ref, out["upsampled_image"], downsample_steps,
+                            compute_percept_loss=compute_percept_loss, percept_loss=percept_loss)
         for k in keys:
             res[k].append(m[k])
+        if compute_percept_loss:
+            res["lpips"].append(m["lpips"])
         for k in ("vif", "vif_synth", "vif_recon"):
             res[k].append(float("nan"))
     return res

@@ -54,3 +54,10 @@ def test_find_best_val_model(tmp_path):
     assert abs(scores["2"][0] - np.mean(want_s)) < 1e-6 and abs(scores["2"][1] - np.mean(want_p)) < 1e-4
     with pytest.raises(ValueError):
         find_best_val_model(vols, src, epoch_range=[77], ps_evaluate=32, downsample_steps=3)
+    # optional LPIPS of the scored slices (create_hr_images(compute_percept_loss=True)); synthetic backbone here
+    from evaluate.find_best_model import evaluate_interpolation_performance, get_transforms
+    from superresolution_aniso_mri_amd.lpips.perceptual import PerceptualLoss
+    crit = PerceptualLoss(model="net-lin", net="vgg", use_gpu=True, gpu_ids=[0], device="cuda", vgg_weights="synthetic-hash")
+    r = evaluate_interpolation_performance(ev, e_args, vols, transform=get_transforms(32, to_tensor=False), downsample_steps=3,
+                                           compute_percept_loss=True, percept_loss=crit)
+    assert len(r["lpips"]) == 2 and all(np.isfinite(v) and v > 0 for v in r["lpips"]) and len(r["ssim"]) == 2
