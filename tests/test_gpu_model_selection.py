@@ -61,3 +61,35 @@ def test_find_best_val_model(tmp_path):
     r = evaluate_interpolation_performance(ev, e_args, vols, transform=get_transforms(32, to_tensor=False), downsample_steps=3,
                                            compute_percept_loss=True, percept_loss=crit)
     assert len(r["lpips"]) == 2 and all(np.isfinite(v) and v > 0 for v in r["lpips"]) and len(r["ssim"]) == 2
+
+
+def test_evaluate_image_and_stats():
+    """evaluate/evaluate_image.py mirror: per-frame held-out-slice synthesis of a 4-D image, its statistics and the comparison grid."""
+    from evaluate.evaluate_image import compute_stats, create_compare_image, evaluate_image
+    from oracle import step_oracle
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    from superresolution_aniso_mri_amd.networks.net_config import NetworkConfig
+    args = dict(model="ae_combined", dataset="ACDC", device="cuda", lr=1e-4, weight_decay=0.0, epochs=2, ex_loss_weight1=0.05,
+                use_percept_loss=False, get_masks=False, use_loss_annealing=False, use_extra_latent_loss=False, epoch_threshold=100,
+                ae_class="VanillaACAI", image_mix_loss_func="perceptual", vgg_weights="synthetic-hash", width=32, latent_width=8,
+                depth=8, latent=16)
+    for k, v in NetworkConfig("ae_combined", dataset="ACDC").architecture.items():
+        args.setdefault(k, v)
+    torch.manual_seed(2)
+    tr = get_trainer_dynamic(args)
+    g = np.random.RandomState(1)
+    img4d = g.rand(3, 7, 40, 36).astype(np.float32)
+    res = evaluate_image(tr, {"image": img4d, "patient_id": "patient007", "spacing": np.array([8.0, 1.4, 1.4])}, eval_patch_size=32,
+                         downsample_steps=2)
+    assert sorted(res["orig_images"].keys()) == [0, 1, 2] and res["synth_images"][1].shape == (7, 32, 32)
+    assert float(res["pred_alphas"][0].min()) == 0.5 and res["orig_images"][2].shape == (7, 32, 32)
+    one = evaluate_image(tr, {"image": img4d, "patient_id": "patient007", "spacing": np.array([8.0, 1.4, 1.4])}, frame_id=9,
+                         eval_patch_size=32, downsample_steps=2)
+    assert list(one["synth_images"].keys()) == [2] and np.array_equal(one["synth_images"][2], res["synth_images"][2])
+    ssim, psnr, vif, lp = compute_stats(tr, res["orig_images"][0], res["synth_images"][0], normalize=False, downsample_steps=2)
+    keep = [1, 3, 5]            # slices 0, 2, 4, 6 are originals at downsample_steps 2
+    assert abs(ssim - np.mean([step_oracle.ssim(res["orig_images"][0][z], res["synth_images"][0][z]) for z in keep])) < 1e-6
+    assert abs(psnr - np.mean([step_oracle.psnr(res["orig_images"][0][z], res["synth_images"][0][z]) for z in keep])) < 1e-4
+    assert np.isnan(vif) and lp > 0
+    grid = create_compare_image(res["orig_images"][0], res["synth_images"][0], downsample_steps=2)
+    assert grid.shape == (1, 7 * (32 + 2) + 2, 3 * (32 + 2) + 2)
