@@ -49,13 +49,16 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
         const int n = pix / H;
         const f32x4 xv = *(const f32x4*)(x + (size_t)idx * 4);
         f32x4 g = gadd ? *(const f32x4*)(gadd + (size_t)idx * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int yo = yy >> 1, xo = xx >> 1;
-        if (yo < Ho && xo < Wo) {
+        // branch-free: the window of an unpooled last row / column (odd H or W) is clamped onto a valid one and its contribution
+        // zeroed, so the five loads are issued together (a bounds branch in front of them serialises the loads)
+        const bool pooled = (yy >> 1) < Ho && (xx >> 1) < Wo;
+        const int yo = min(yy >> 1, Ho - 1), xo = min(xx >> 1, Wo - 1);
+        {
             const float* b = x + ((size_t)(n * H + 2 * yo) * W + 2 * xo) * C + c4 * 4;
             const f32x4 v00 = *(const f32x4*)b, v01 = *(const f32x4*)(b + C);
             const f32x4 v10 = *(const f32x4*)(b + (size_t)W * C), v11 = *(const f32x4*)(b + (size_t)W * C + C);
             const f32x4 go = *(const f32x4*)(gout + ((size_t)(n * Ho + yo) * Wo + xo) * C + c4 * 4);
-            const int me = (yy & 1) * 2 + (xx & 1);
+            const int me = pooled ? (yy & 1) * 2 + (xx & 1) : -1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 // first maximum in scan order (00, 01, 10, 11)
