@@ -204,6 +204,10 @@ int aesr_lpips_finalize(const float* const* partials_host, const int* hw_host, i
 /* z [2B][per], zmix [B][per]: zmix[b] = a_from[b]*z[b] + a_to[b]*z[B+b]; per % 4 == 0. */
 int aesr_lerp_fwd(const float* z, const float* a_from, const float* a_to, float* zmix, int B, size_t per, void* stream);
 int aesr_lerp_bwd(const float* dzmix, const float* a_from, const float* a_to, float* dz, int B, size_t per, void* stream);
+/* The decoder input of the step in one pass (kwatsch/cardiac/trainer_ae.py:20-30: dec(z) and dec(z_mix) run as one batch here):
+ * zcat[3B][per] = [z | a_from*z[:B] + a_to*z[B:]];  gradient dz[2B][per] = g[:2B] + (a_from, a_to) * g[2B:]. */
+int aesr_lerp_cat_fwd(const float* z, const float* a_from, const float* a_to, float* zcat, int B, size_t per, void* stream);
+int aesr_lerp_cat_bwd(const float* g, const float* a_from, const float* a_to, float* dz, int B, size_t per, void* stream);
 
 /* ---- losses (kwatsch/base_trainer.py:177; kwatsch/cardiac/trainer_ae.py:181) ------------------------------ */
 #define AESR_MSE_NPART 512

@@ -77,6 +77,8 @@ SIGNATURES = {
     "aesr_lpips_finalize": (c_int, [ctypes.POINTER(c_void_p), IP, c_int, P, c_int, P]),
     "aesr_lerp_fwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
     "aesr_lerp_bwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
+    "aesr_lerp_cat_fwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
+    "aesr_lerp_cat_bwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
     "aesr_mse_fwd": (c_int, [P, P, P, P, c_size_t, P]),
     "aesr_mse_bwd": (c_int, [P, P, P, P, c_size_t, P]),
     "aesr_row_mean_fwd": (c_int, [P, P, c_int, c_size_t, P]),

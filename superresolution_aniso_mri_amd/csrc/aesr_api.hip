@@ -637,6 +637,16 @@ int aesr_lerp_bwd(const float* dzmix, const float* a_from, const float* a_to, fl
     return aesr_launch_lerp_bwd(dzmix, a_from, a_to, dz, B, per, (hipStream_t)stream);
 }
 
+int aesr_lerp_cat_fwd(const float* z, const float* a_from, const float* a_to, float* zcat, int B, size_t per, void* stream) {
+    AESR_CHECK_ARG(z && a_from && a_to && zcat && z != zcat && B > 0 && per % 4 == 0, "aesr_lerp_cat_fwd: bad arguments (per %% 4 == 0)");
+    return aesr_launch_lerp_cat_fwd(z, a_from, a_to, zcat, B, per, (hipStream_t)stream);
+}
+
+int aesr_lerp_cat_bwd(const float* g, const float* a_from, const float* a_to, float* dz, int B, size_t per, void* stream) {
+    AESR_CHECK_ARG(g && a_from && a_to && dz && g != dz && B > 0 && per % 4 == 0, "aesr_lerp_cat_bwd: bad arguments (per %% 4 == 0)");
+    return aesr_launch_lerp_cat_bwd(g, a_from, a_to, dz, B, per, (hipStream_t)stream);
+}
+
 int aesr_mse_fwd(const float* a, const float* b, double* partial, float* loss, size_t n, void* stream) {
     AESR_CHECK_ARG(a && b && partial && loss && n > 0, "aesr_mse_fwd: bad arguments");
     return aesr_launch_mse_fwd(a, b, partial, AESR_MSE_NPART, loss, n, (hipStream_t)stream);

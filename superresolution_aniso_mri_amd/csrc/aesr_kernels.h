@@ -126,6 +126,8 @@ int aesr_launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t st);
 
 int aesr_launch_lerp_fwd(const float* z, const float* af, const float* at, float* zmix, int B, size_t per, hipStream_t st);
 int aesr_launch_lerp_bwd(const float* dmix, const float* af, const float* at, float* dz, int B, size_t per, hipStream_t st);
+int aesr_launch_lerp_cat_fwd(const float* z, const float* af, const float* at, float* zcat, int B, size_t per, hipStream_t st);
+int aesr_launch_lerp_cat_bwd(const float* g, const float* af, const float* at, float* dz, int B, size_t per, hipStream_t st);
 int aesr_launch_mse_fwd(const float* a, const float* b, double* partial, int np, float* out, size_t n, hipStream_t st);
 int aesr_launch_mse_bwd(const float* a, const float* b, const float* g, float* da, size_t n, hipStream_t st);
 int aesr_launch_act_bwd(const float* dout, const float* y, float* dpre, size_t n, int act, float slope, hipStream_t st);

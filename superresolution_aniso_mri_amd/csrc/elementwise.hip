@@ -30,6 +30,32 @@ __global__ __launch_bounds__(256) void lerp_bwd_kernel(const float* __restrict__
     }
 }
 
+// the decoder's input of the ae_combined step in one pass: zcat = [z (2B rows) | z_mix (B rows)] -- the lerp and the
+// concatenation that feeds dec([z | z_mix]) (kwatsch/cardiac/trainer_ae.py:20-30) -- and its gradient
+// dz[b] = g[b] + a_from[b]*g[2B+b], dz[B+b] = g[B+b] + a_to[b]*g[2B+b]
+__global__ __launch_bounds__(256) void lerp_cat_fwd_kernel(const float* __restrict__ z, const float* __restrict__ af,
+                                                           const float* __restrict__ at, float* __restrict__ zcat, int B, size_t per4) {
+    const size_t total = (size_t)B * per4;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int b = idx / per4;
+        const f32x4 v0 = ((const f32x4*)z)[idx], v1 = ((const f32x4*)z)[idx + total];
+        ((f32x4*)zcat)[idx] = v0;
+        ((f32x4*)zcat)[idx + total] = v1;
+        ((f32x4*)zcat)[idx + 2 * total] = v0 * af[b] + v1 * at[b];
+    }
+}
+
+__global__ __launch_bounds__(256) void lerp_cat_bwd_kernel(const float* __restrict__ g, const float* __restrict__ af,
+                                                           const float* __restrict__ at, float* __restrict__ dz, int B, size_t per4) {
+    const size_t total = (size_t)B * per4;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int b = idx / per4;
+        const f32x4 gm = ((const f32x4*)g)[idx + 2 * total];
+        ((f32x4*)dz)[idx] = ((const f32x4*)g)[idx] + gm * af[b];
+        ((f32x4*)dz)[idx + total] = ((const f32x4*)g)[idx + total] + gm * at[b];
+    }
+}
+
 // ---- mse -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sqdiff_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                              double* __restrict__ partial, size_t n) {
@@ -152,6 +178,18 @@ int aesr_launch_lerp_fwd(const float* z, const float* af, const float* at, float
 int aesr_launch_lerp_bwd(const float* dmix, const float* af, const float* at, float* dz, int B, size_t per, hipStream_t st) {
     hipLaunchKernelGGL(lerp_bwd_kernel, dim3(grid_for((size_t)B * per / 4, 4096)), dim3(256), 0, st, dmix, af, at, dz, B, per / 4);
     AESR_LAUNCH_CHECK("lerp_bwd");
+    return AESR_OK;
+}
+
+int aesr_launch_lerp_cat_fwd(const float* z, const float* af, const float* at, float* zcat, int B, size_t per, hipStream_t st) {
+    hipLaunchKernelGGL(lerp_cat_fwd_kernel, dim3(grid_for((size_t)B * per / 4, 4096)), dim3(256), 0, st, z, af, at, zcat, B, per / 4);
+    AESR_LAUNCH_CHECK("lerp_cat_fwd");
+    return AESR_OK;
+}
+
+int aesr_launch_lerp_cat_bwd(const float* g, const float* af, const float* at, float* dz, int B, size_t per, hipStream_t st) {
+    hipLaunchKernelGGL(lerp_cat_bwd_kernel, dim3(grid_for((size_t)B * per / 4, 4096)), dim3(256), 0, st, g, af, at, dz, B, per / 4);
+    AESR_LAUNCH_CHECK("lerp_cat_bwd");
     return AESR_OK;
 }
 

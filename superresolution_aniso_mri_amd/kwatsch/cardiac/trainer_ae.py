@@ -92,9 +92,10 @@ class CombinedStepMixin(object):
         # enc(x[2B]) and the logging-only enc(slice_between[B]): one batched pass, two BatchNorm statistic groups
         z, z_ref = self.model.encode_multi([x, between], needs_grad=[True, False])
         a_from, a_to = self._mix_coefficients(batch_item, B)
-        z_mix = ops.lerp_mix(z, a_from, a_to)
-        # dec(z[2B]) and dec(z_mix[B]): one batched pass, two statistic groups
-        out, s_mix = self.model.decode_multi([z, z_mix])
+        # dec(z[2B]) and dec(z_mix[B]): one batched pass, two statistic groups; its input [z | z_mix] comes from one kernel
+        zcat = ops.lerp_cat(z, a_from, a_to)
+        z_mix = zcat[2 * B:]
+        out, s_mix = self.model.decode_cat(zcat, [2 * B, B])
         loss_ae = self.get_loss(x, out, is_test=False)["loss_ae"]
         loss_latent = ops.mse_loss(z_mix.detach(), z_ref.detach())
         mask = batch_item["loss_mask"] if self.args.get("get_masks") else None

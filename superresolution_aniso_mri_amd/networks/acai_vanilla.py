@@ -120,14 +120,24 @@ class HipAE(nn.Module):
             raise ValueError("sub-batches that need gradients must come first")
         xs = [engine.to_nhwc(t) for t in tensors]
         x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=0)
+        return self._pass_batched(name, x, [t.shape[0] for t in xs], needs_grad)
+
+    def _pass_batched(self, name, x_nhwc, splits, needs_grad):
         nstart = [0]
-        for t in xs:
-            nstart.append(nstart[-1] + t.shape[0])
-        ngrad = sum(t.shape[0] for t, g in zip(xs, needs_grad) if g)
+        for n in splits:
+            nstart.append(nstart[-1] + int(n))
+        ngrad = sum(int(n) for n, g in zip(splits, needs_grad) if g)
         if not self.training:
             nstart = [0, nstart[-1]]          # eval: running statistics, groups are irrelevant
             ngrad = nstart[-1] if ngrad > 0 else 0
-        return engine.run_pass_groups(self._runner(name), x, [t.shape[0] for t in xs], nstart, ngrad, train=self.training)
+        return engine.run_pass_groups(self._runner(name), x_nhwc, list(splits), nstart, ngrad, train=self.training)
+
+    def decode_cat(self, zcat, splits, needs_grad=None):
+        """``decode_multi`` on sub-batches that already sit in one tensor (``ops.lerp_cat``): no concatenation pass."""
+        needs_grad = [True] * len(splits) if needs_grad is None else needs_grad
+        if sum(int(n) for n in splits) != zcat.shape[0]:
+            raise ValueError("splits %s do not add up to the batch size %d" % (list(splits), zcat.shape[0]))
+        return self._pass_batched("dec", engine.to_nhwc(zcat), splits, needs_grad)
 
     def encode_multi(self, images, needs_grad=None):
         return self._pass("enc", images, needs_grad)

@@ -37,6 +37,27 @@ class _LerpFn(torch.autograd.Function):
         return dz, None, None
 
 
+class _LerpCatFn(torch.autograd.Function):
+    """zcat = [z | a_from*z[:B] + a_to*z[B:]] in one kernel; backward folds the mix gradient back onto both halves."""
+
+    @staticmethod
+    def forward(ctx, z, a_from, a_to):
+        B = z.shape[0] // 2
+        zcat = torch.empty((3 * B,) + tuple(z.shape[1:]), device=z.device, dtype=torch.float32)
+        check(lib.aesr_lerp_cat_fwd(ptr(z), ptr(a_from), ptr(a_to), ptr(zcat), B, z[0].numel(), stream()), "aesr_lerp_cat_fwd")
+        ctx.save_for_backward(a_from, a_to)
+        return zcat
+
+    @staticmethod
+    def backward(ctx, g):
+        a_from, a_to = ctx.saved_tensors
+        g = g.contiguous()
+        B = g.shape[0] // 3
+        dz = torch.empty((2 * B,) + tuple(g.shape[1:]), device=g.device, dtype=torch.float32)
+        check(lib.aesr_lerp_cat_bwd(ptr(g), ptr(a_from), ptr(a_to), ptr(dz), B, g[0].numel(), stream()), "aesr_lerp_cat_bwd")
+        return dz, None, None
+
+
 _CONST_VECS = {}
 
 
@@ -55,9 +76,7 @@ def _const_vec(n, value, device):
     return t
 
 
-def lerp_mix(z, alpha_from, alpha_to):
-    """z: logical NCHW [2B,C,H,W] (rows i and i+B are a pair).  alpha_*: [B] or [B,1] or scalar.
-    Returns z_mix [B,C,H,W] = alpha_from*z[:B] + alpha_to*z[B:]."""
+def _lerp_args(z, alpha_from, alpha_to):
     B = z.shape[0] // 2
     if z.shape[0] != 2 * B or B == 0:
         raise ValueError("lerp_mix needs an even, non-empty batch (got %d)" % z.shape[0])
@@ -75,8 +94,22 @@ def lerp_mix(z, alpha_from, alpha_to):
         if a.numel() != B:
             raise ValueError("need one mixing coefficient per pair (%d), got %d" % (B, a.numel()))
         return a.contiguous()
+    return zn, coef(alpha_from), coef(alpha_to)
 
-    out = _LerpFn.apply(zn, coef(alpha_from), coef(alpha_to))
+
+def lerp_mix(z, alpha_from, alpha_to):
+    """z: logical NCHW [2B,C,H,W] (rows i and i+B are a pair).  alpha_*: [B] or [B,1] or scalar.
+    Returns z_mix [B,C,H,W] = alpha_from*z[:B] + alpha_to*z[B:]."""
+    zn, af, at = _lerp_args(z, alpha_from, alpha_to)
+    out = _LerpFn.apply(zn, af, at)
+    return engine.to_nchw_view(out) if z.dim() == 4 else out
+
+
+def lerp_cat(z, alpha_from, alpha_to):
+    """[z | lerp_mix(z)] as ONE [3B,...] tensor written by one kernel: the decoder input of the ae_combined step (its rows 2B.. are
+    z_mix).  Saves the separate concatenation pass and, in backward, the accumulation of the two gradient paths into z."""
+    zn, af, at = _lerp_args(z, alpha_from, alpha_to)
+    out = _LerpCatFn.apply(zn, af, at)
     return engine.to_nchw_view(out) if z.dim() == 4 else out
 
 

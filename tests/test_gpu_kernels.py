@@ -397,6 +397,21 @@ def test_lerp_mse_act_adam(hip):
     dz = torch.empty(2 * B, per, device="cuda")
     hip.check(L.aesr_lerp_bwd(hip.ptr(D(d)), hip.ptr(D(af)), hip.ptr(D(at)), hip.ptr(dz), B, per, hip.stream()), "lerp_bwd")
     assert torch.equal(dz.cpu(), torch.cat([af[:, None] * d, at[:, None] * d]))
+    # the decoder-input form: [z | mix] in one pass and the folded gradient
+    zc = torch.empty(3 * B, per, device="cuda")
+    hip.check(L.aesr_lerp_cat_fwd(hip.ptr(D(z)), hip.ptr(D(af)), hip.ptr(D(at)), hip.ptr(zc), B, per, hip.stream()), "lerp_cat")
+    assert torch.equal(zc.cpu(), torch.cat([z, af[:, None] * z[:B] + at[:, None] * z[B:]]))
+    g3 = torch.randn(3 * B, per, generator=g)
+    dz2 = torch.empty(2 * B, per, device="cuda")
+    hip.check(L.aesr_lerp_cat_bwd(hip.ptr(D(g3)), hip.ptr(D(af)), hip.ptr(D(at)), hip.ptr(dz2), B, per, hip.stream()), "lerp_cat_bwd")
+    assert torch.equal(dz2.cpu(), torch.cat([g3[:B] + g3[2 * B:] * af[:, None], g3[B:2 * B] + g3[2 * B:] * at[:, None]]))
+    from superresolution_aniso_mri_amd import ops
+    zz = torch.randn(2 * B, 8, 5, 4, generator=g).cuda().requires_grad_(True)
+    cat = ops.lerp_cat(zz, 0.5, 0.5)
+    assert cat.shape == (3 * B, 8, 5, 4) and torch.equal(cat[2 * B:], ops.lerp_mix(zz.detach(), 0.5, 0.5))
+    (cat * torch.arange(3 * B, device="cuda").float()[:, None, None, None]).sum().backward()
+    want = torch.cat([torch.arange(B) + 0.5 * (2 * B + torch.arange(B)), B + torch.arange(B) + 0.5 * (2 * B + torch.arange(B))]).float()
+    assert torch.equal(zz.grad.cpu(), want[:, None, None, None].expand(2 * B, 8, 5, 4))
     a = torch.rand(24 * 160 * 160, generator=g).requires_grad_(True)
     b = torch.rand(24 * 160 * 160, generator=g)
     ref = F.mse_loss(a, b)
