@@ -26,13 +26,16 @@ import torch  # noqa: E402
 STEP_GFLOP = {"c2": 330.8, "c3": 894.5, "c4": 2223.5, "c5": 1524.4}
 # BASELINE configs[3], configs[4] on ONE rank (secondary numbers; the headline metric is quoted on c2): name -> (dataset, B, H, width, latent_width)
 BRAIN = {"c4": ("OASIS", 16, 220, 64, 16), "c5": ("dHCP", 8, 256, 256, 64)}
-# of which the 32->32 3x3 convolution behind the stem (fwd on 48 images, dgrad + wgrad on 36) is folded with the 1x1 stem into
-# one bandwidth-bound 1->32 convolution and no longer runs on the matrix cores (csrc/conv_thin.hip)
-STEM_FOLDED_GFLOP = 58.05      # = 7*B * (H+2)^2 * 32*32*9*2 flop at B=12, H=160
 
 
 def stem_folded_gflop(B, H):
+    """MFMA flops of the reference's op count that no longer run on the matrix cores: the 32->32 3x3 convolution behind the
+    encoder stem is folded with the 1x1 stem into one bandwidth-bound 1->32 convolution (csrc/conv_thin.hip).  That layer ran
+    forward on 3B images (x[2B] and the logging-only slice_between[B]) and its data and weight gradients on 2B images each:
+    7B image passes x (H+2)^2 x 32*32*9*2 flop = 40.63 GF at B=12, H=160 (330.8 -> 290.17 GF executed)."""
     return 7.0 * B * (H + 2) ** 2 * 32 * 32 * 9 * 2 / 1e9
+
+
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 
 

@@ -9,6 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AESR_ERR_ARG 1
 #define AESR_ERR_HIP 2
 #define AESR_ERR_UNSUPPORTED 3
+#define AESR_MAX_DEVICES 16      // per-device one-time state (function attributes)
 
 // activation codes shared by every epilogue
 enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };

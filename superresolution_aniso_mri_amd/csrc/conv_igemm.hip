@@ -480,10 +480,17 @@ static int launch_one(const IgemmArgs& a, hipStream_t st) {
         aesr_set_error("conv_igemm: tile needs %zu B of LDS", shmem);
         return AESR_ERR_ARG;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_f32<KS, NB, MBW, NT, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    // opt in to the full 160 KB of dynamic LDS once per (instantiation, device); a failure is reported here, with its cause
+    static bool attr_set[AESR_MAX_DEVICES] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= AESR_MAX_DEVICES) dev_ = 0;
+    if (!attr_set[dev_]) {
+        const hipError_t e_ = hipFuncSetAttribute((const void*)conv_igemm_f32<KS, NB, MBW, NT, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e_ != hipSuccess) {
+            aesr_set_error("conv_igemm_f32: hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KB) failed: %s", hipGetErrorString(e_));
+            return AESR_ERR_HIP;
+        }
+        attr_set[dev_] = true;
     }
     int grid = 256 * (512 / NT);              // persistent: 2 waves per SIMD (register budget), as one 8-wave or two 4-wave workgroups per CU
     if (const char* e = getenv("AESR_IGEMM_GRID")) grid = atoi(e);

@@ -300,10 +300,17 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
         aesr_set_error("conv_wgrad: tile %dx%d does not fit the register prefetch slots", a.TH, a.TW);
         return AESR_ERR_ARG;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_f32<KS, NWCO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    // opt in to the full 160 KB of dynamic LDS once per (instantiation, device); a failure is reported here, with its cause
+    static bool attr_set[AESR_MAX_DEVICES] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= AESR_MAX_DEVICES) dev_ = 0;
+    if (!attr_set[dev_]) {
+        const hipError_t e_ = hipFuncSetAttribute((const void*)conv_wgrad_f32<KS, NWCO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e_ != hipSuccess) {
+            aesr_set_error("conv_wgrad_f32: hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KB) failed: %s", hipGetErrorString(e_));
+            return AESR_ERR_HIP;
+        }
+        attr_set[dev_] = true;
     }
     dim3 grid(a.S * (a.CinP / 32) * (a.CoutP / COT));
     if (getenv("AESR_WGRAD_DBG")) {           // debug: per-phase cycle stamps, printed after a host sync

@@ -61,7 +61,8 @@ def interpolate_latents(trainer, z_a, z_b, num_interpol):
 def interpolate_2(trainer, x, num_interpol=9, show_critic=False, side=None, clear_cache=False, eval=True):
     """Grid of [first half | interpolations | second half] (reference :41-79)."""
     if show_critic:
-        raise NotImplementedError("the ACAI critic is not part of this build")
+        raise NotImplementedError("show_critic (the critic's score row under the grid, reference :59-62,76-78) is a visualisation option that is not built; "
+                                  "the ACAI critic itself is: kwatsch/trainer_acai.py")
     side = x.size(0) // 2 if side is None else side
     z = trainer.encode(x, eval=eval)
     x_interp = interpolate_latents(trainer, z[:side], z[-side:], num_interpol)

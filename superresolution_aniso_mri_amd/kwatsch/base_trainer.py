@@ -37,6 +37,17 @@ class LossLog(list):
         return [self._conv(k) for k in range(len(self))]
 
 
+def optimizer_state_to_cpu(opt):
+    """A CPU copy of ``opt.state_dict()`` for a checkpoint.  ``Optimizer.state_dict()`` hands out the SAME inner dicts as
+    ``opt.state[p]``, so they must never be written to: replacing a moment tensor there would detach HipAdam's flat-buffer
+    views from the live optimizer state and every later checkpoint would carry the moments of the first one."""
+    sd = opt.state_dict()
+    state = {pid: {k: (v.detach().cpu().clone().contiguous() if torch.is_tensor(v) else v) for k, v in st.items()}
+             for pid, st in sd["state"].items()}
+    groups = [dict(g, params=list(g["params"])) for g in sd["param_groups"]]
+    return {"state": state, "param_groups": groups}
+
+
 def _scalar(v):
     return v.detach() if torch.is_tensor(v) else float(v)
 
@@ -88,6 +99,17 @@ class BaseTrainer(object):
     def iters(self):
         return self._iters
 
+    @property
+    def _log_count(self):
+        """{"train": triplets of this rank's last training batch, "test": ... validation batch} (weights of the cross-rank means)."""
+        return self.__dict__.setdefault("_log_count_d", {})
+
+    def _note_batch(self, batch_item, eval_type):
+        t = batch_item.get("slice_between", None) if hasattr(batch_item, "get") else None
+        if t is None:
+            t = batch_item["image"]
+        self._log_count[eval_type] = int(t.shape[0])
+
     _capture_sink = None      # dict while a step is being captured into a HIP graph (see AEBaseTrainer._train_graphed)
 
     def _set_mode(self, training):
@@ -119,9 +141,17 @@ class BaseTrainer(object):
             self.loss_iters.append(self.iters)
         else:
             src, dst = self.losses_test, self.mean_losses_test
+        means = {}
         for key, vals in src.items():
             vals = LossLog(vals).floats()
-            mean_value = float(np.mean(np.array(vals))) if len(vals) else float("nan")
+            means[key] = float(np.mean(np.array(vals))) if len(vals) else float("nan")
+        dp = getattr(self, "dp", None)
+        if dp is not None and dp.active and means:
+            # data parallel: every rank logged the mean over ITS shard; model selection and the loss files must see the mean
+            # over the global batch (= what the single-process run logs): sum_r n_r * mean_r / sum_r n_r, one all-reduce
+            n_local = float(self._log_count.get(eval_type, 0) or 0)
+            means = dp.reduce_means(means, n_local)
+        for key, mean_value in means.items():
             if self.args.get("log_tensorboard") and getattr(self, "tb_writer", None) is not None:
                 self.tb_writer.add_scalar("{}/{}".format(key, eval_type), mean_value, self.iters)
             dst[key].append(mean_value)
@@ -217,6 +247,7 @@ class BaseTrainer(object):
     # ---- validation (reference :67-99) -----------------------------------------------------------------------------
     def validate(self, validation_batch, image_dict=None, frame_id=8, generate_images=True):
         self.model.eval()
+        self._note_batch(validation_batch, "test")
         image = self._to_device(validation_batch["image"])
         z = self.encode(image, eval=True)
         img_recons = self.decode(z, eval=True)
@@ -255,12 +286,7 @@ class BaseTrainer(object):
         if not self._is_writer():
             return
         sd = {k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()}
-        opt = self.opt_ae.state_dict()
-        for st in opt["state"].values():
-            for k, v in st.items():
-                if torch.is_tensor(v):
-                    st[k] = v.detach().cpu().contiguous()
-        torch.save({"model_dict_ae": sd, "optimizer_dict_ae": opt, "epoch": epoch}, fname)
+        torch.save({"model_dict_ae": sd, "optimizer_dict_ae": optimizer_state_to_cpu(self.opt_ae), "epoch": epoch}, fname)
 
     def load(self, fname):
         state = torch.load(fname, map_location="cpu")

@@ -110,6 +110,7 @@ class CombinedStepMixin(object):
                      for k, v in batch_item.items()}
         self._set_mode(not eval_mode)
         self._iters += 1
+        self._note_batch(batch_item, "train")
         self._lambda_tensor()
         if self._graph_ok(keep_predictions, eval_mode):
             self._train_graphed(dev_batch)

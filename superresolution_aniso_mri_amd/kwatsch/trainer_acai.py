@@ -16,6 +16,7 @@ the step cannot be replayed from a captured graph."""
 import torch
 
 from .. import ops
+from .base_trainer import optimizer_state_to_cpu
 from .brain.trainer_ae import AETrainerExtension1Brain
 
 
@@ -140,12 +141,6 @@ class ACAITrainer(AETrainerExtension1Brain):
         def host(sd):
             return {k: (v.detach().cpu().contiguous() if torch.is_tensor(v) else v) for k, v in sd.items()}
 
-        def host_opt(opt):
-            st = opt.state_dict()
-            for s in st["state"].values():
-                for k, v in s.items():
-                    if torch.is_tensor(v):
-                        s[k] = v.detach().cpu().contiguous()
-            return st
+        host_opt = optimizer_state_to_cpu         # a copy: never write into the dicts Optimizer.state_dict() hands out
         torch.save({"model_dict_ae": host(self.model.state_dict()), "optimizer_dict_ae": host_opt(self.opt_ae),
                     "model_disc": host(self.disc_model.state_dict()), "optimizer_disc": host_opt(self.opt_disc), "epoch": epoch}, fname)

@@ -143,6 +143,7 @@ class AEBaseTrainer(BaseTrainer):
         x = self._to_device(batch_item["image"])
         self._set_mode(not eval_mode)
         self._iters += 1
+        self._note_batch(batch_item, "train")
         z = self.model.encode(x)
         out = self.model.decode(z)
         loss_ae = self.get_loss(x, out, is_test=False)["loss_ae"]

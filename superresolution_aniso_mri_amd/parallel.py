@@ -193,6 +193,19 @@ class DataParallelContext(object):
         self._all_reduce(t)
         return float(t)
 
+    def reduce_means(self, means, n_local):
+        """{key: mean over this rank's shard} -> {key: mean over the global batch}: sum_r n_r * mean_r / sum_r n_r with ONE
+        all-reduce (keys in sorted order; every rank must log the same keys).  Used when losses are READ (epoch logging, model
+        selection), never inside the step."""
+        if not self.active or not means:
+            return means
+        keys = sorted(means.keys())
+        t = torch.tensor([means[k] * n_local for k in keys] + [n_local], dtype=torch.float64, device=self.device)
+        self._all_reduce(t)
+        tot = float(t[-1])
+        vals = t[:-1].cpu().tolist()
+        return {k: (v / tot if tot > 0 else float("nan")) for k, v in zip(keys, vals)}
+
     def barrier(self):
         if self.active:
             dist.barrier()

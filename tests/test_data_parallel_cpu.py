@@ -84,3 +84,39 @@ def test_two_rank_gloo_matches_single_process(tmp_path, B):
     assert abs(res["loss"] - float(loss)) < 1e-6 * float(loss)      # B=3: shards 1 + 2 triplets, weights 1/3 and 2/3
     for p, g in zip(ae.parameters(), res["grads"]):
         np.testing.assert_allclose(g.numpy(), p.grad.numpy(), rtol=2e-4, atol=1e-9)
+
+
+def _log_worker(rank, world, port, B, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from collections import defaultdict
+    from superresolution_aniso_mri_amd.kwatsch.base_trainer import BaseTrainer, LossLog
+    from superresolution_aniso_mri_amd.parallel import DataParallelContext
+    dp = DataParallelContext(backend="gloo", device="cpu")
+    lo, hi = dp.set_batch(B)
+    # per-triplet "losses" 1..B; every rank logs the mean over ITS shard, twice (two iterations of an epoch)
+    per = np.arange(1, B + 1, dtype=np.float64)
+    t = BaseTrainer()
+    t.args, t.dp, t._iters = {}, dp, 7
+    t.losses, t.losses_test = defaultdict(LossLog), defaultdict(LossLog)
+    t.mean_losses, t.mean_losses_test, t.loss_iters = defaultdict(list), defaultdict(list), []
+    for scale in (1.0, 3.0):
+        t.losses["loss_ae"].append(float(per[lo:hi].mean() * scale))
+        t.losses_test["loss_ae_dist"].append(float((per[lo:hi] ** 2).mean() * scale))
+    t._log_count.update(train=hi - lo, test=hi - lo)
+    t.show_loss_on_tensorboard()
+    t.show_loss_on_tensorboard(eval_type="test")
+    if rank == 0:
+        torch.save({"train": t.mean_losses["loss_ae"][-1], "test": t.mean_losses_test["loss_ae_dist"][-1]}, out)
+    dp.barrier()
+    dist.destroy_process_group()
+
+
+def test_logged_means_are_global_under_data_parallel(tmp_path):
+    """Model selection and the loss files see the mean over the GLOBAL batch, not rank 0's shard (uneven shards 1 + 2)."""
+    out = str(tmp_path / "log.pt")
+    B = 3
+    mp.spawn(_log_worker, args=(2, _free_port(), B, out), nprocs=2, join=True)
+    res = torch.load(out)
+    per = np.arange(1, B + 1, dtype=np.float64)
+    assert abs(res["train"] - per.mean() * 2.0) < 1e-12
+    assert abs(res["test"] - (per ** 2).mean() * 2.0) < 1e-12

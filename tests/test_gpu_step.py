@@ -89,6 +89,24 @@ def test_checkpoint_roundtrip(tmp_path):
     t2.train(batch1)
     for (k, a), (_, b) in zip(t1.model.state_dict().items(), t2.model.state_dict().items()):
         assert torch.equal(a, b), k
+    # a SECOND checkpoint must carry the moments of its own step (saving must not detach HipAdam's flat-buffer views from
+    # opt.state): step, save, load into a fresh trainer, one more step on both -> bit-equal parameters
+    p0 = t1.opt_ae._plist[0]
+    assert t1.opt_ae.state[p0]["exp_avg"].data_ptr() == t1.opt_ae.flat_m.data_ptr()
+    f2 = str(tmp_path / "8.models")
+    t1.save_models(f2, 8)
+    assert t1.opt_ae.state[p0]["exp_avg"].data_ptr() == t1.opt_ae.flat_m.data_ptr()
+    ck2 = torch.load(f2, map_location="cpu")
+    assert float(ck2["optimizer_dict_ae"]["state"][0]["step"]) == 2.0
+    assert not torch.equal(ck2["optimizer_dict_ae"]["state"][0]["exp_avg"], ck["optimizer_dict_ae"]["state"][0]["exp_avg"])
+    assert torch.equal(ck2["optimizer_dict_ae"]["state"][0]["exp_avg"], t1.opt_ae.flat_m[:p0.numel()].view_as(p0).cpu())
+    t3 = make_trainer("cardiac_mse", rec)
+    t3.load(f2)
+    batch2 = {"image": torch.from_numpy(rec["image_2"]), "slice_between": torch.from_numpy(rec["between_2"])}
+    t1.train(batch2)
+    t3.train(batch2)
+    for (k, a), (_, b) in zip(t1.model.state_dict().items(), t3.model.state_dict().items()):
+        assert torch.equal(a, b), k
 
 
 def test_step_graph_replay_equals_eager():
