@@ -11,9 +11,7 @@ Rank 0 prints ONE JSON line (see DESIGN.md section "Measurement").
 import argparse
 import json
 import os
-import subprocess
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -23,7 +21,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 # algorithmic conv FLOPs per training step (SURVEY.md section 8a / BASELINE.md section 2), B=12, 160x160, scales 2
-STEP_GFLOP = {"c2": 330.8, "c3": 894.5, "c4": 2223.5, "c5": 1524.4}
+STEP_GFLOP = {"c2": 330.8, "c3": 894.5, "c4": 2223.5, "c5": 1524.4, "c3_scales3": 959.6}
 # BASELINE configs[3], configs[4] on ONE rank (secondary numbers; the headline metric is quoted on c2): name -> (dataset, B, H, width, latent_width)
 BRAIN = {"c4": ("OASIS", 16, 220, 64, 16), "c5": ("dHCP", 8, 256, 256, 64)}
 
@@ -39,7 +37,7 @@ def stem_folded_gflop(B, H):
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 
 
-def build_args(config, device):
+def build_args(config, device, scales3=False):
     from superresolution_aniso_mri_amd.networks.net_config import NetworkConfig
     args = dict(model="ae_combined", dataset="ACDC", device=device, lr=1e-5, weight_decay=0.0, epochs=900, batch_size=12,
                 width=128, latent_width=32, depth=32, latent=128, ex_loss_weight1=0.05, use_percept_loss=False,
@@ -49,6 +47,8 @@ def build_args(config, device):
     if config in BRAIN:
         ds, B, _, width, lw = BRAIN[config]
         args.update(dataset=ds, batch_size=B, width=width, latent_width=lw, ex_loss_weight1=0.001)
+    if scales3:
+        args.update(latent_width=16)       # README-literal latent_width: width // latent_width = 8 -> three pooling stages (C3')
     for k, v in NetworkConfig("ae_combined", dataset=args["dataset"]).architecture.items():
         args.setdefault(k, v)
     return args
@@ -102,35 +102,38 @@ def make_line(opt, B, H, elapsed, launch, loss, roofline, engine):
     return line
 
 
-_KEEPER_SRC = (
-    "import sys\n"
-    "last = None\n"
-    "for line in sys.stdin:\n"
-    "    if line.strip():\n"
-    "        last = line\n"
-    "if last is not None:\n"
-    "    sys.stdout.write(last if last.endswith('\\n') else last + '\\n')\n"
-    "    sys.stdout.flush()\n")
-
-
-class LineKeeper(object):
-    """Rank 0 under N > 1: a tiny child process that owns the real stdout and prints the LAST JSON line it was handed once its
-    stdin closes.  The bench first measures the host-launched data-parallel step (always available) and hands that line over,
-    then tries the graph-replayed step; if that attempt takes the process down, the child still prints the first line."""
-
-    def __init__(self, fd):
-        self.p = subprocess.Popen([sys.executable, "-c", _KEEPER_SRC], stdin=subprocess.PIPE, stdout=fd, close_fds=True)
-
-    def put(self, line):
-        self.p.stdin.write((json.dumps(line) + "\n").encode())
-        self.p.stdin.flush()
-
-    def close(self):
-        try:
-            self.p.stdin.close()
-            self.p.wait(timeout=30)
-        except Exception:              # noqa: BLE001
-            pass
+def secondary_measurements(device, steps=10, warmup=4):
+    """The other single-GPU configurations north_star asks for, measured the same way (inputs resident, captured-graph replay,
+    K steps between synchronizes) AFTER the headline measurement: BASELINE configs[2] (C3: + LPIPS), C3 with the README-literal
+    three pooling stages, and the 256x256 configuration (configs[4] on one rank).  Reported inside the one JSON line."""
+    from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    out = {}
+    for name, config, scales3 in (("c3", "c3", False), ("c3_scales3", "c3", True), ("c5", "c5", False)):
+        B, H = (12, 160) if config not in BRAIN else (BRAIN[config][1], BRAIN[config][2])
+        torch.manual_seed(892372)
+        tr = get_trainer_dynamic(build_args(config, device, scales3=scales3))
+        tr.enable_step_graph(eager_steps=2)
+        pool = []
+        for i in range(2):
+            b = synthetic_batch(B, H, H, seed=892372 + i, brain=config in BRAIN)
+            pool.append({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items()})
+        for i in range(warmup):
+            tr.train(pool[i % 2], keep_predictions=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tr.train(pool[i % 2], keep_predictions=False)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        gf = STEP_GFLOP[name]
+        out[name] = {"workload": "%d triplets of %dx%d, LPIPS-VGG synthesis loss%s" % (B, H, H, ", scales 3 (latent_width 16)" if scales3 else ""),
+                     "ms_per_step": round(ms, 3), "slices_per_s": round(3 * B / ms * 1e3, 1), "steps": steps, "warmup": warmup,
+                     "step_algorithmic_gflop": gf, "step_algorithmic_tflops": round(gf / ms, 2),
+                     "frac_of_f32_mfma_peak": round(gf / ms / PEAK_F32_MFMA_TFLOPS, 4), "final_loss": round(float(tr.losses["loss_ae"][-1]), 6)}
+        del tr, pool
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -148,10 +151,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--triplets", type=int, default=12, help="global batch in triplets (12 = the BASELINE workload; other values are for experiments only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured step")
-    ap.add_argument("--dp-graph", nargs="?", const="segments", default="auto", choices=("auto", "off", "segments", "whole"),
-                    help="N > 1: 'auto' (default) times the host-launched step, then the graph-replayed step ('whole' = one graph "
-                    "with the RCCL collectives captured on the nccl backend, 'segments' = a chain of graphs cut at the eager "
-                    "collectives otherwise) and reports the faster; 'off' = host launches only; 'segments' / 'whole' = that form only")
+    ap.add_argument("--dp-graph", choices=("on", "off"), default="on",
+                    help="N > 1: 'on' (default) replays the step from the captured graph (RCCL data plane: ONE graph with the collectives "
+                    "as nodes; gloo rehearsal: graph segments between eager collectives); 'off' launches every kernel from the host. "
+                    "A failure in either form ends the run with a non-zero exit code: no other form is substituted")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary single-GPU measurements (c3, c3 with scales 3, c5)")
     opt = ap.parse_args()
 
     from superresolution_aniso_mri_amd import engine
@@ -162,8 +166,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if opt.gpus > 1 and world != opt.gpus:
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (opt.gpus, opt.gpus))
-    # rank 0 of a multi-rank run: the child that will print the line (started before this process touches the GPU)
-    keeper = LineKeeper(real_stdout) if (world > 1 and int(os.environ.get("RANK", "0")) == 0) else None
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("AESR_SINGLE_DEVICE") == "1":       # rehearsal on a one-GPU box: every rank on cuda:0 (with AESR_DIST_BACKEND=gloo)
         local_rank = 0
@@ -178,11 +180,9 @@ def main():
     if dp.active:
         dp.attach(trainer)
         dp.set_batch(B)
-    auto_dp = dp.active and opt.dp_graph == "auto" and not opt.no_graph
-    dp_mode = opt.dp_graph if (dp.active and opt.dp_graph in ("segments", "whole")) else None
-    use_graph = not opt.no_graph and (not dp.active or dp_mode is not None)
+    use_graph = not opt.no_graph and (not dp.active or opt.dp_graph == "on")
     if use_graph:
-        trainer.enable_step_graph(eager_steps=2, dp_mode=dp_mode)
+        trainer.enable_step_graph(eager_steps=2)        # data parallel: the form follows the data plane (parallel.DataParallelContext.graph_mode)
     # a small pool of distinct batches, sharded by triplet and resident in HBM before the timed region
     pool = []
     for i in range(4):
@@ -207,41 +207,17 @@ def main():
         return dp.max_over_ranks(time.perf_counter() - t0)
 
     elapsed = measure()
-    launch = ("captured HIP graph replay" if not dp.active else
-              "HIP graph segments between eager collectives" if dp_mode == "segments" else
-              "one HIP graph per step with the RCCL collectives captured") if use_graph else "host launches"
-    graph_failed = False
-    if auto_dp:
-        # data parallel, default: the host-launched number is safe in the keeper before the graph-replayed step is attempted
-        import torch.distributed as dist
-        if keeper is not None:
-            keeper.put(make_line(opt, B, H, elapsed, "host launches", trainer.losses["loss_ae"][-1], None, engine))
-        mode = "whole" if dist.get_backend() == "nccl" else "segments"
-
-        def on_hang():           # every rank has its own timer: a stuck collective must not hold the job forever
-            sys.stderr.write("bench: the graph-replayed data-parallel step did not finish; reporting the host-launched step\n")
-            if keeper is not None:
-                keeper.close()
-            os._exit(0)
-        guard = threading.Timer(float(os.environ.get("AESR_DP_GRAPH_TIMEOUT", "120")), on_hang)
-        guard.daemon = True
-        guard.start()
-        try:
-            trainer.enable_step_graph(eager_steps=0, dp_mode=mode)
-            e2 = measure()
-            if e2 < elapsed:
-                elapsed = e2
-                launch = ("one HIP graph per step with the RCCL collectives captured" if mode == "whole"
-                          else "HIP graph segments between eager collectives")
-                use_graph = True
-        except Exception as exc:           # noqa: BLE001
-            sys.stderr.write("bench: graph-replayed data-parallel step failed (%r); reporting the host-launched step\n" % (exc,))
-            graph_failed = True
-        guard.cancel()
+    launch = "host launches"
+    if use_graph:
+        launch = ("captured HIP graph replay" if not dp.active else
+                  "one HIP graph per step, RCCL collectives (library-owned communicator) as graph nodes" if dp.graph_mode == "whole" else
+                  "HIP graph segments between eager host-staged (gloo) collectives")
+        if not getattr(trainer, "_graphs", None):
+            raise SystemExit("bench: the step graph was requested but never captured")
     loss = trainer.losses["loss_ae"][-1]
 
     roofline = None
-    if not opt.no_roofline and not graph_failed:
+    if not opt.no_roofline:
         # same steps again with one HIP-event pair around every MFMA convolution launch (on the launching stream)
         trainer._graph_enabled = False          # event pairs need host-side launches
         engine.PROFILER = engine.KernelProfiler()
@@ -280,11 +256,11 @@ def main():
     if opt.gpus == 1 and not opt.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(B, H)
     sys.stdout.flush()
-    if keeper is not None:
-        keeper.put(line)
-        keeper.close()
-    else:
-        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if opt.gpus == 1 and opt.config == "c2" and B == 12 and not opt.no_secondary:
+        del trainer, pool
+        torch.cuda.empty_cache()
+        line["secondary"] = secondary_measurements(device)
+    os.write(real_stdout, (json.dumps(line) + "\n").encode())
     dp.shutdown()
 
 

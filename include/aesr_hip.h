@@ -259,6 +259,31 @@ size_t aesr_ssim_workspace_doubles(int Z, int H, int W);
 int aesr_ssim_mse(const float* a, const float* b, double* workspace, double* ssim, double* mse, int Z, int H, int W, int win,
                   double data_range, double k1, double k2, void* stream);
 
+/* ---- data-parallel collectives: an RCCL communicator owned by the library (one process per GPU; new functionality -- the
+ * reference's only multi-GPU code moves the loss to 'cuda:1', kwatsch/trainer_ae.py:43-44,84-86) --------------------------------
+ * Collectives are plain enqueues on the caller's stream (capturable into a HIP graph; no watchdog thread, unlike
+ * torch.distributed's ProcessGroupNCCL).  Bootstrap: rank 0 calls aesr_comm_unique_id and hands the 128 bytes to every rank
+ * over any host channel (the shipped host code uses torch.distributed's gloo/TCP store); every rank then calls aesr_comm_init
+ * with its device current (hipSetDevice / torch.cuda.set_device).  librccl is bound at run time: without it these entries
+ * return AESR_ERR_UNSUPPORTED with a message.  dtype: 0 = f32, 1 = f64.  op: 0 = sum, 1 = max.  All buffers are device
+ * pointers, reduced / broadcast IN PLACE. */
+#define AESR_COMM_ID_BYTES 128
+#define AESR_COMM_F32 0
+#define AESR_COMM_F64 1
+#define AESR_COMM_SUM 0
+#define AESR_COMM_MAX 1
+int aesr_comm_rccl_version(int* version_out);                      /* NCCL_VERSION_CODE of the bound librccl */
+int aesr_comm_unique_id(void* id_host128);
+int aesr_comm_init(const void* id_host128, int nranks, int rank, void** comm_out);
+int aesr_comm_destroy(void* comm);
+int aesr_comm_abort(void* comm);                                  /* tear down without waiting for pending collectives */
+/* Flat gradient buffer (kwatsch/trainer_ae.py:93-96's backward/step pair, made data parallel) and SyncBN partial sums. */
+int aesr_comm_allreduce(void* comm, void* buf, size_t count, int dtype, int op, void* stream);
+/* Several buffers as ONE fused RCCL group launch (ncclGroupStart/End): the pointer / count arrays are host arrays. */
+int aesr_comm_allreduce_many(void* comm, void* const* bufs_host, const size_t* counts_host, int nbufs, int dtype, int op,
+                             void* stream);
+int aesr_comm_broadcast(void* comm, void* buf, size_t count, int dtype, int root, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -239,6 +239,182 @@ def gen_steps(av, net):
         np.savez_compressed(os.path.join(OUT, "step_k3_%s.npz" % tag), **rec)
 
 
+# ---- the reference's OWN trainer classes on the CPU ---------------------------------------------------------------------------
+class _DummyMeta(type):
+    def __getattr__(cls, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return _Dummy
+
+
+class _Dummy(metaclass=_DummyMeta):
+    """Stand-in for names of third-party packages the trainer modules import at module level and never call on this path."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return None
+
+
+class _AnyModule(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return _Dummy
+
+
+def _any_stub(name):
+    m = _AnyModule(name)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+def import_reference_trainers():
+    """kwatsch/cardiac/trainer_ae.py, kwatsch/brain/trainer_ae.py, kwatsch/trainer_ae.py of the reference, imported as they are.
+    Their import chain (kwatsch/base_trainer.py:1-13 -> evaluate/*, datasets/*) pulls in packages that are absent here and that
+    the train step never calls (tensorboard, SimpleITK, imageio, cv2, batchgenerators, gpustat, torchvision.datasets): each
+    ModuleNotFoundError is answered with an empty stand-in module.  The ONE behavioural shim: ``torch.cuda.FloatTensor`` (used
+    once, kwatsch/trainer_ae.py:51, to build the constant 0.5) makes a CPU tensor.  Nothing of the step itself is replaced."""
+    import_reference()
+    _any_stub("torch.utils.tensorboard")
+    _any_stub("torch.utils.tensorboard.writer")
+    tv = sys.modules["torchvision"]
+    for sub in ("datasets", "transforms", "utils"):
+        setattr(tv, sub, _any_stub("torchvision." + sub))
+    torch.cuda.FloatTensor = lambda data, device=None: torch.FloatTensor(data)
+    for _ in range(64):
+        try:
+            import kwatsch.trainer_ae as tae
+            import kwatsch.cardiac.trainer_ae as cta
+            import kwatsch.brain.trainer_ae as bta
+            return tae, cta, bta
+        except ModuleNotFoundError as e:
+            _any_stub(e.name)
+    raise RuntimeError("could not import the reference trainers")
+
+
+def trainer_args(mix="mse", lr=1e-3, epochs=10, **over):
+    a = small_args()
+    a.update(model="ae_combined", lr=lr, weight_decay=0.0, epochs=epochs, use_percept_loss=False, get_masks=False,
+             use_loss_annealing=False, use_extra_latent_loss=False, ex_loss_weight1=0.05, image_mix_loss_func=mix,
+             epoch_threshold=100)
+    a.update(over)
+    return a
+
+
+def _run_reference_trainer(av, cls, args, batches, seed=4242, epochs_at=None):
+    """Construct the reference trainer ``cls`` around the reference ``VanillaACAI`` and call its real ``train()`` once per batch.
+    Returns the record: initial / final parameters, the scalars the trainer logged, first-step predictions and gradients."""
+    torch.manual_seed(seed)
+    model = av.VanillaACAI(args)
+    rec = {"p0/" + k: v for k, v in np_state(model.state_dict()).items()}
+    trainer = cls(args, model)
+    z_seen = []
+    hook = model.enc.register_forward_hook(lambda m, i, o: z_seen.append(o.detach().clone()))
+    keys = None
+    rows = []
+    for step, batch in enumerate(batches):
+        if epochs_at is not None:
+            trainer.epoch = int(epochs_at[step])
+        n0 = {k: len(v) for k, v in trainer.losses.items()}
+        z_seen.clear()
+        trainer.train(dict(batch), keep_predictions=True)
+        if keys is None:
+            keys = [k for k in ("loss_ae", "loss_ae_dist", "loss_ae_dist_extra", "loss_latent_1") if k in trainer.losses]
+        for k in trainer.losses:
+            assert len(trainer.losses[k]) == n0.get(k, 0) + 1, "one value per key per step expected (%s)" % k
+        rows.append([trainer.losses[k][-1] for k in keys])
+        rec["image_%d" % step], rec["between_%d" % step] = batch["image"].numpy(), batch["slice_between"].numpy()
+        if step == 0:
+            pr = trainer.train_predictions
+            rec["z_0"] = z_seen[0].numpy()                      # first encoder call of the step = enc(x)
+            rec["out_0"], rec["s_mix_0"], rec["z_mix_0"] = pr["reconstruction"].numpy(), pr["slice_inbetween_mix"].numpy(), pr["z_mix"].numpy()
+            rec.update({"grad0/" + k: p.grad.numpy().copy() for k, p in model.named_parameters()})
+    hook.remove()
+    rec["losses"] = np.array(rows, dtype=np.float64)
+    rec["loss_keys"] = np.array(keys)
+    rec["iters"] = np.array(trainer.iters)
+    rec["loss_weights"] = np.asarray(trainer.loss_weights, dtype=np.float64)
+    nsteps = len(batches)
+    rec.update({"p%d/" % nsteps + k: v for k, v in np_state(model.state_dict()).items()})
+    return rec, trainer
+
+
+def _triplet_batches(n, B, H, W, seed0, brain=False):
+    out = []
+    for step in range(n):
+        image, between = step_oracle.synthetic_triplets(B, H, W, seed=seed0 + step)
+        b = {"image": image, "slice_between": between}
+        if brain:
+            af = torch.tensor([[0.25], [0.5], [0.75]])[:B] if B <= 3 else torch.linspace(0.2, 0.8, B)[:, None]
+            b["alpha_from"], b["alpha_to"] = af, 1 - af
+        out.append(b)
+    return out
+
+
+def gen_trainer_steps(av):
+    """tests/golden/step_k3_*.npz: three optimisation steps made by the reference's own ``AETrainerEndToEnd.train``
+    (kwatsch/cardiac/trainer_ae.py:10-50), ``AETrainerExtension1Brain.train`` (kwatsch/brain/trainer_ae.py:92-132) and the plain
+    ``AEBaseTrainer.train`` (kwatsch/trainer_ae.py:71-109) on the CPU -- pass order, BatchNorm update order, loss composition and
+    logging are the reference's, not a restatement.  LPIPS uses the reference's PerceptualLoss -> DistModel -> PNetLin with the
+    local lin weights and the synthetic backbone (the ImageNet weights are a download)."""
+    tae, cta, bta = import_reference_trainers()
+    cases = [("cardiac_mse", cta.AETrainerEndToEnd, trainer_args("mse"), False),
+             ("cardiac_lpips", cta.AETrainerEndToEnd, trainer_args("perceptual"), False),
+             ("brain_lpips", bta.AETrainerExtension1Brain, trainer_args("perceptual"), True),
+             # --use_percept_loss: LPIPS as the reconstruction loss too (kwatsch/base_trainer.py:165-175), synthesis loss follows it
+             ("cardiac_percept", cta.AETrainerEndToEnd, trainer_args(None, use_percept_loss=True), False),
+             # plain `ae` (reconstruction loss only; latent loss and the 0.5 mix are logged)
+             ("ae_plain", tae.AEBaseTrainer, trainer_args("mse", model="ae"), False),
+             # three pooling stages (README-literal latent_width: width // latent_width = 8 -> scales 3)
+             ("cardiac_mse_s3", cta.AETrainerEndToEnd, trainer_args("mse", width=32, latent_width=4), False),
+             # the reference's default learning rate: parameters after 3 steps agree far inside Adam's sign-noise band
+             ("cardiac_mse_lr1e-5", cta.AETrainerEndToEnd, trainer_args("mse", lr=1e-5), False)]
+    for tag, cls, args, brain in cases:
+        if args.get("image_mix_loss_func") is None:
+            args.pop("image_mix_loss_func")
+        rec, tr = _run_reference_trainer(av, cls, args, _triplet_batches(3, 3, 32, 32, 500, brain))
+        if brain:
+            rec["alpha_from"], rec["alpha_to"] = np.array([[0.25], [0.5], [0.75]], np.float32), np.array([[0.75], [0.5], [0.25]], np.float32)
+        rec["trainer_class"] = np.array(cls.__name__)
+        np.savez_compressed(os.path.join(OUT, "step_k3_%s.npz" % tag), **rec)
+        print("  step_k3_%s: %s keys %s, losses[0] %s" % (tag, cls.__name__, list(rec["loss_keys"]), rec["losses"][0]))
+    # loss annealing (kwatsch/base_trainer.py:456-459, kwatsch/cardiac/trainer_ae.py:80-83): 4 epochs, one step in each
+    args = trainer_args("mse", epochs=4, use_loss_annealing=True)
+    rec, tr = _run_reference_trainer(av, cta.AETrainerEndToEnd, args, _triplet_batches(4, 3, 32, 32, 700), epochs_at=[0, 1, 2, 3])
+    rec["trainer_class"] = np.array("AETrainerEndToEnd")
+    np.savez_compressed(os.path.join(OUT, "step_k4_cardiac_anneal.npz"), **rec)
+    # BASELINE configs[1] / [2] at their own size (12 triplets of 160x160, depth 32, latent 128), ONE step of the reference trainer:
+    # stored as probes (scalars, norms, 64 sampled values per tensor) -- the batch is re-made from its seed by the tests
+    for tag, mix in (("c2", "mse"), ("c3", "perceptual")):
+        args = trainer_args(mix, lr=1e-5, width=128, latent_width=32, depth=32, latent=128)
+        torch.manual_seed(892372)
+        model = av.VanillaACAI(args)
+        from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+        batch = synthetic_batch(12, 160, 160, seed=892372)
+        trainer = cta.AETrainerEndToEnd(args, model)
+        init_sum = {k: float(v.double().sum()) for k, v in model.state_dict().items()}
+        trainer.train({"image": batch["image"], "slice_between": batch["slice_between"]}, keep_predictions=True)
+        pr = trainer.train_predictions
+        idx = torch.randperm(pr["reconstruction"].numel(), generator=torch.Generator().manual_seed(1))[:64]
+        idx_s = torch.randperm(pr["slice_inbetween_mix"].numel(), generator=torch.Generator().manual_seed(2))[:64]
+        rec = {"losses": np.array([trainer.losses[k][-1] for k in ("loss_ae", "loss_ae_dist", "loss_ae_dist_extra", "loss_latent_1")]),
+               "out_idx": idx.numpy(), "out_val": pr["reconstruction"].flatten()[idx].numpy(), "out_norm": np.float64(pr["reconstruction"].double().norm()),
+               "s_idx": idx_s.numpy(), "s_val": pr["slice_inbetween_mix"].flatten()[idx_s].numpy(), "s_norm": np.float64(pr["slice_inbetween_mix"].double().norm()),
+               "zmix_norm": np.float64(pr["z_mix"].double().norm())}
+        for k, p_ in model.named_parameters():
+            rec["gnorm/" + k] = np.float64(p_.grad.double().norm())
+            rec["ghead/" + k] = p_.grad.flatten()[:8].numpy().copy()
+        for k, v in model.state_dict().items():
+            if "running" in k:
+                rec["bn/" + k] = v.numpy().copy()
+            rec["init_sum/" + k] = np.float64(init_sum[k])
+        np.savez_compressed(os.path.join(OUT, "step_probe_%s.npz" % tag), **rec)
+        print("  step_probe_%s: losses %s" % (tag, rec["losses"]))
+
+
 def gen_supervolume(av):
     """generate_hr_volumes.py:12-101 arithmetic (z=5, n=3) around the reference model in eval mode; the
     reference function itself hard-codes .to('cuda') so its loop is restated here verbatim in meaning:
@@ -511,6 +687,9 @@ def main():
         import_reference()
         gen_laploss()
         return
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "trainer_steps":
+        gen_trainer_steps(import_reference()[0])
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "supervolume_eval":
         gen_supervolume_eval(import_reference()[0])
         return
@@ -524,8 +703,8 @@ def main():
     gen_ae_small(av, avs, avm)
     m = gen_ae_init(av)
     gen_ae_acdc_probe(m)
-    net = gen_lpips(nb)
-    gen_steps(av, net)
+    gen_lpips(nb)
+    gen_trainer_steps(av)          # step_k3_*: the reference's own trainer classes (supersedes the restated gen_steps)
     gen_supervolume(av)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote %d fixtures, %.1f KiB" % (len(os.listdir(OUT)), tot / 1024))

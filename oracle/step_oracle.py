@@ -16,15 +16,18 @@ from . import lpips_oracle
 
 
 class OracleStep:
-    """One ``ae_combined`` trainer on the oracle AE (device-agnostic CPU restatement)."""
+    """One ``ae_combined`` trainer on the oracle AE (device-agnostic CPU restatement).  ``recon_loss="perceptual"`` is
+    ``--use_percept_loss`` (kwatsch/base_trainer.py:165-175: LPIPS(recons, reference) instead of the MSE); ``plain=True`` is the
+    plain ``ae`` model (kwatsch/trainer_ae.py:71-109: reconstruction loss only)."""
 
     def __init__(self, ae, lr=1e-5, weight_decay=0.0, momentum=0.9, ex_loss_weight1=0.05,
-                 image_mix_loss_func="perceptual", vgg_sd=None, lin_w=None):
+                 image_mix_loss_func="perceptual", vgg_sd=None, lin_w=None, recon_loss="mse", plain=False):
         self.ae = ae
         self.opt = torch.optim.Adam(ae.parameters(), lr=lr, weight_decay=weight_decay, betas=(momentum, 0.999))
         self.lam = ex_loss_weight1
         self.mix_loss = image_mix_loss_func
         self.vgg_sd, self.lin_w = vgg_sd, lin_w
+        self.recon_loss, self.plain = recon_loss, plain
 
     def extra_image_loss(self, reference, synthesized):
         # kwatsch/cardiac/trainer_ae.py:103-130 without masks / laploss
@@ -33,15 +36,46 @@ class OracleStep:
                                                 normalize=True).mean()
         return F.mse_loss(reference, synthesized)
 
-    def train(self, image, slice_between, alpha_from=None, alpha_to=None, update=True):
-        """image [2B,1,H,W] (from-slices then to-slices), slice_between [B,1,H,W].
-        alpha_* None -> cardiac 0.5/0.5 (trainer_ae.py:51, cardiac/trainer_ae.py:173);
-        else [B,1] per-sample coefficients (brain/trainer_ae.py:264-266)."""
+    def reconstruction_loss(self, reference, recons):
+        # kwatsch/base_trainer.py:164-198: percept_criterion(recons, reference, normalize=True).mean() or F.mse_loss(recons, reference)
+        if self.recon_loss == "perceptual":
+            return lpips_oracle.perceptual_loss(recons, reference, self.vgg_sd, self.lin_w, normalize=True).mean()
+        return F.mse_loss(recons, reference, reduction="mean")
+
+    def train_plain(self, image, slice_between, update=True):
+        """kwatsch/trainer_ae.py:71-109.  The latent loss is for the log only: ``get_latent_loss(no_grad=True)`` encodes
+        slice_between through ``self.encode(eval=True)`` (kwatsch/base_trainer.py:200-211,243-282), which switches the model to
+        eval mode and nothing switches it back before ``_get_mixup_image`` (:337-346) -- the 0.5-mix is decoded in EVAL mode."""
         ae = self.ae
         B = image.shape[0] // 2
         z = ae.encode(image, train=True)
         out = ae.decode(z, train=True)
-        loss_ae_dist = F.mse_loss(out, image, reduction="mean")          # base_trainer.py:177
+        loss = self.reconstruction_loss(image, out)
+        with torch.no_grad():
+            z_mix = 0.5 * z[:B] + 0.5 * z[B:]
+            z_ref = ae.encode(slice_between, train=False)
+            loss_latent = F.mse_loss(z_mix, z_ref)
+        self.opt.zero_grad()
+        if update:
+            loss.backward()
+            self.opt.step()
+        with torch.no_grad():
+            s_mix = ae.decode(z_mix, train=False)
+        return dict(loss_ae=float(loss.detach()), loss_ae_dist=float(loss.detach()), loss_latent_1=float(loss_latent), z=z.detach(),
+                    out=out.detach(), z_mix=z_mix.detach(), s_mix=s_mix)
+
+    def train(self, image, slice_between, alpha_from=None, alpha_to=None, update=True, lam=None):
+        """image [2B,1,H,W] (from-slices then to-slices), slice_between [B,1,H,W].
+        alpha_* None -> cardiac 0.5/0.5 (trainer_ae.py:51, cardiac/trainer_ae.py:173);
+        else [B,1] per-sample coefficients (brain/trainer_ae.py:264-266).  ``lam``: this step's synthesis-loss weight when loss
+        annealing is on (kwatsch/cardiac/trainer_ae.py:80-83: ``loss_weights[epoch]``)."""
+        if self.plain:
+            return self.train_plain(image, slice_between, update=update)
+        ae = self.ae
+        B = image.shape[0] // 2
+        z = ae.encode(image, train=True)
+        out = ae.decode(z, train=True)
+        loss_ae_dist = self.reconstruction_loss(image, out)             # base_trainer.py:177
         if alpha_from is None:
             z_mix = 0.5 * z[:B] + (1 - 0.5) * z[B:]
         else:
@@ -49,7 +83,7 @@ class OracleStep:
         s_mix = ae.decode(z_mix, train=True)
         z_ref = ae.encode(slice_between, train=True)       # graph never back-propagated; updates BN stats (Q6)
         loss_latent = F.mse_loss(z_mix, z_ref)
-        loss_extra = self.lam * self.extra_image_loss(slice_between, s_mix)
+        loss_extra = (self.lam if lam is None else lam) * self.extra_image_loss(slice_between, s_mix)
         loss = loss_ae_dist + loss_extra
         self.opt.zero_grad()
         if update:
@@ -58,6 +92,12 @@ class OracleStep:
         return dict(loss_ae=float(loss.detach()), loss_ae_dist=float(loss_ae_dist.detach()),
                     loss_ae_dist_extra=float(loss_extra.detach()), loss_latent_1=float(loss_latent.detach()), z=z.detach(), out=out.detach(), z_mix=z_mix.detach(),
                     s_mix=s_mix.detach())
+
+
+def annealing_weights(epochs, ex_loss_weight1):
+    """kwatsch/base_trainer.py:456-459: sigmoid(linspace(-5, 5, epochs)) * lambda, reversed; indexed by the trainer's epoch."""
+    x = np.linspace(-5, 5, epochs)
+    return (1.0 / (1.0 + np.exp(-x)) * ex_loss_weight1)[::-1].copy()
 
 
 class OracleACAIStep:

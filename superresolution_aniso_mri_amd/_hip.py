@@ -93,7 +93,17 @@ SIGNATURES = {
     "aesr_ssim_workspace_doubles": (c_size_t, [c_int, c_int, c_int]),
     "aesr_ssim_mse": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_double, c_double, c_double, P]),
     "aesr_adam_step": (c_int, [P, P, P, P, P, c_size_t] + [c_float] * 5 + [P]),
+    "aesr_comm_rccl_version": (c_int, [IP]),
+    "aesr_comm_unique_id": (c_int, [c_char_p]),
+    "aesr_comm_init": (c_int, [c_char_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "aesr_comm_destroy": (c_int, [P]),
+    "aesr_comm_abort": (c_int, [P]),
+    "aesr_comm_allreduce": (c_int, [P, P, c_size_t, c_int, c_int, P]),
+    "aesr_comm_allreduce_many": (c_int, [P, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_int, c_int, c_int, P]),
+    "aesr_comm_broadcast": (c_int, [P, P, c_size_t, c_int, c_int, P]),
 }
+COMM_ID_BYTES = 128
+COMM_F32, COMM_F64, COMM_SUM, COMM_MAX = 0, 1, 0, 1
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 BN_NONE, BN_POOL, BN_UP = 0, 1, 2

@@ -72,17 +72,21 @@ class AEBaseTrainer(BaseTrainer):
     # ---- HIP-graph capture of the whole step (forward, backward, Adam) ---------------------------------------------
     def enable_step_graph(self, eager_steps=3, dp_segments=False, dp_mode=None):
         """Replay the training step from ONE captured HIP graph (no per-kernel host launches).  The first ``eager_steps``
-        calls still run eagerly (allocator / plan caches warm up), then the step is captured once per input signature.
-        Under data parallel ``dp_mode`` selects how the collectives are handled:
-          "whole"    -- the RCCL collectives are captured into the one step graph (capture mode "thread_local": the
-                        ProcessGroupNCCL watchdog thread may query events while this thread captures; nccl backend only);
-          "segments" -- (= ``dp_segments=True``) a chain of graphs cut at the collectives, which stay eager
-                        (parallel.SegmentedStepGraph; any backend);
-          None       -- every kernel is launched from the host."""
-        if dp_mode is None and dp_segments:
-            dp_mode = "segments"
+        calls still run eagerly (allocator / plan caches and, under data parallel, RCCL's lazily built channels warm up), then
+        the step is captured once per input signature.  Under data parallel the collectives are handled as the data plane allows
+        (``dp_mode`` None = pick that form):
+          "whole"    -- library-owned RCCL communicator: the collectives are enqueued on the capturing stream and become nodes
+                        of the one step graph (capture mode "thread_local": RCCL's own proxy thread keeps running meanwhile);
+          "segments" -- host-staged gloo data plane (CPU tests, several ranks rehearsed on one GPU): a chain of graphs cut at the
+                        collectives, which stay eager (parallel.SegmentedStepGraph)."""
+        dp_active = self.dp is not None and self.dp.active
+        if dp_mode is None and (dp_segments or dp_active):
+            dp_mode = self.dp.graph_mode if dp_active else "segments"
         if dp_mode not in (None, "whole", "segments"):
             raise ValueError("dp_mode must be None, 'whole' or 'segments', got %r" % (dp_mode,))
+        if dp_active and dp_mode == "whole" and self.dp.data_backend != "rccl":
+            raise ValueError("dp_mode='whole' needs the RCCL data plane (collectives of the %s data plane cannot be graph nodes)"
+                             % self.dp.data_backend)
         self._graph_enabled = True
         self._graph_dp = dp_mode
         self._graph_eager_left = int(eager_steps)
@@ -155,7 +159,12 @@ class AEBaseTrainer(BaseTrainer):
         self._log("loss_ae", loss_ae)
         self._log("loss_latent_1", lat["loss_latent"])
         if keep_predictions:
+            # reference :100-102: get_latent_loss(no_grad=True) left the model in EVAL mode (BaseTrainer.encode(eval=True)) and
+            # nothing switches it back before _get_mixup_image: the logged 0.5-mix is decoded with the running statistics and
+            # does not update them
+            self._set_mode(False)
             mix = self._get_mixup_image(z=z.detach(), alpha_from=a_from, alpha_to=a_to, is_test=True)
+            self._set_mode(not eval_mode)
             s = mix["slice_inbetween_mix"].detach().cpu()
             self.train_predictions = {"z_mix": lat["z_mix"].detach().cpu(), "pred_alphas": torch.tensor([0.5]),
                                       "slice_inbetween_mix": s, "slice_inbetween_05": s, "reconstruction": out.detach().cpu()}

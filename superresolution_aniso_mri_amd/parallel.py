@@ -1,5 +1,6 @@
-"""Data parallelism for the ae_combined step: one process per GPU, ``torch.distributed`` (backend "nccl" == RCCL over
-xGMI on ROCm; "gloo" in CPU tests).  New functionality -- the reference has no distributed path.
+"""Data parallelism for the ae_combined step: one process per GPU; the device collectives run on an RCCL communicator (xGMI)
+that the C-ABI library owns (csrc/comm.hip), ``torch.distributed`` (gloo) is the host-side control plane only.
+New functionality -- the reference has no distributed path.
 
 The unit that shards is the *triplet* (from, to, between).  Per step there are exactly these exchanges:
   * gradients   ONE all-reduce(SUM) of the flat fp32 gradient buffer (1.78 MB for the ACDC model: latency-bound,
@@ -16,14 +17,13 @@ import torch.distributed as dist
 
 
 class SegmentedStepGraph(object):
-    """The data-parallel step as a CHAIN of HIP graphs cut at every collective.
+    """The data-parallel step as a CHAIN of HIP graphs cut at every collective -- the form for a HOST-staged data plane (gloo:
+    CPU tests and several ranks rehearsed on one GPU), whose collectives cannot be graph nodes.  With the library-owned RCCL
+    communicator the collectives ARE graph nodes and the whole step is one graph (``dp_mode="whole"``); this class is not used.
 
-    Capturing an RCCL collective into a graph is not possible on this stack (the ProcessGroupNCCL watchdog queries an event
-    while the stream is capturing and the process aborts: scripts/nccl_smoke.py), so the collectives stay eager: during the
-    capture step every ``cut(fn)`` ends the running capture, replays that segment (its results are needed now), runs the
-    collective ``fn`` eagerly and begins the next segment.  Later steps replay segment i, then call collective i on the very
-    tensor it was recorded with (kept alive here; all segments share one memory pool, so addresses repeat).
-    Capture mode is "relaxed": segments end on the autograd thread and the watchdog thread may query events meanwhile."""
+    During the capture step every ``cut(fn)`` ends the running capture, replays that segment (its results are needed now), runs
+    the collective ``fn`` eagerly and begins the next segment.  Later steps replay segment i, then call collective i on the very
+    tensor it was recorded with (kept alive here; all segments share one memory pool, so addresses repeat)."""
 
     def __init__(self):
         self.graphs, self.collectives = [], []
@@ -78,47 +78,93 @@ class SegmentedStepGraph(object):
 
 
 class DataParallelContext(object):
+    """Control plane: a ``torch.distributed`` **gloo** group (rendezvous, barriers, host scalars, the RCCL unique id).
+    Data plane on GPUs: an RCCL communicator owned behind the C ABI (``aesr_comm_*``, csrc/comm.hip) whose collectives are
+    plain enqueues on the current stream -- capturable into the step graph, no ProcessGroupNCCL and therefore no watchdog thread
+    polling events of a capturing stream.  ``AESR_DIST_BACKEND=gloo`` (CPU tests, several ranks rehearsed on ONE GPU, where RCCL
+    refuses duplicate devices) stages device tensors through the host instead."""
 
     def __init__(self, backend=None, device=None):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = device
-        if self.world > 1 and not dist.is_initialized():
+        backend = backend or os.environ.get("AESR_DIST_BACKEND")
+        if backend == "nccl":
+            backend = "rccl"                # "nccl" used to mean ProcessGroupNCCL here; the data plane is the library's own comm now
+        if backend not in (None, "gloo", "rccl"):
+            raise ValueError("data-parallel backend must be 'rccl' or 'gloo', got %r" % (backend,))
+        self.data_backend = backend or ("rccl" if torch.cuda.is_available() else "gloo")
+        # rehearsal switch: treat a single process as "data parallel" (collectives over a group of one) so that the RCCL call
+        # pattern, incl. the captured step graph, can be exercised on a one-GPU box
+        self._force = os.environ.get("AESR_FORCE_DP", "0") == "1"
+        if (self.world > 1 or self._force) and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            # AESR_DIST_BACKEND=gloo: rehearsal of the N-rank launch on a box with fewer GPUs than ranks (RCCL refuses two ranks
-            # on one device); production = nccl (RCCL over xGMI)
-            backend = backend or os.environ.get("AESR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+            dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+        self.comm = None                # aesr_comm handle (data_backend == "rccl"), created on first use with the device current
         self.weight = 1.0
         self.global_B = None
-        self.segments = None            # a SegmentedStepGraph while a step is being captured
-        # rehearsal switch: treat a single process as "data parallel" (collectives over a group of one) so that the
-        # NCCL call pattern, incl. the segmented step graph, can be exercised on a one-GPU box
-        self._force = os.environ.get("AESR_FORCE_DP", "0") == "1"
-        if self._force and self.world == 1 and not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29500")
-            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-            dist.init_process_group(backend=backend, rank=0, world_size=1)
+        self.segments = None            # a SegmentedStepGraph while a step is being captured (gloo data plane only)
+        self.n_collectives = 0          # collectives issued so far (tests / DESIGN accounting)
 
     @property
     def active(self):
         return self.world > 1 or self._force
 
-    def _all_reduce(self, t, op=None):
-        """In-place all-reduce; with the gloo backend (CPU tests, single-GPU rehearsals) device tensors are staged through
-        the host, with nccl (= RCCL over xGMI) they are reduced in place on the device."""
-        op = op or dist.ReduceOp.SUM
+    @property
+    def graph_mode(self):
+        """How a captured step handles the collectives: "whole" (RCCL calls are graph nodes) or "segments" (eager, between graphs)."""
+        return "whole" if self.data_backend == "rccl" else "segments"
+
+    # ---- the library-owned RCCL communicator -------------------------------------------------------------------
+    def ensure_comm(self):
+        if self.comm is not None or self.data_backend != "rccl" or not self.active:
+            return self.comm
+        import ctypes
+        from ._hip import COMM_ID_BYTES, check, lib
+        uid = ctypes.create_string_buffer(COMM_ID_BYTES)
+        if self.rank == 0:
+            check(lib.aesr_comm_unique_id(uid), "aesr_comm_unique_id")
+        box = [uid.raw]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0)           # 128 bytes over the gloo/TCP control plane
+        handle = ctypes.c_void_p()
+        # collective over all ranks; the CURRENT device becomes this rank's device (callers set it before the first collective)
+        check(lib.aesr_comm_init(box[0], self.world, self.rank, ctypes.byref(handle)), "aesr_comm_init")
+        self.comm = handle
+        return self.comm
+
+    def _rccl(self, t, op):
+        from ._hip import COMM_F32, COMM_F64, COMM_MAX, COMM_SUM, check, lib, ptr, stream
+        if not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError("RCCL collectives take contiguous device tensors (got %s, contiguous=%s)" % (t.device, t.is_contiguous()))
+        if t.dtype == torch.float32:
+            dt = COMM_F32
+        elif t.dtype == torch.float64:
+            dt = COMM_F64
+        else:
+            raise RuntimeError("RCCL all-reduce of %s is not wired" % t.dtype)
+        check(lib.aesr_comm_allreduce(self.ensure_comm(), ptr(t), t.numel(), dt, COMM_MAX if op == "max" else COMM_SUM, stream()),
+              "aesr_comm_allreduce")
+
+    def _all_reduce(self, t, op="sum"):
+        """In-place all-reduce.  Device tensors go through the library's RCCL communicator on the current stream (data backend
+        "rccl"); with the gloo data backend (CPU tests, one-GPU rehearsals) they are staged through the host.  Host tensors always
+        use gloo."""
+        self.n_collectives += 1
+        if t.is_cuda and self.data_backend == "rccl":
+            self._rccl(t, op)
+            return
+        rop = dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM
 
         def run():
-            if t.is_cuda and dist.get_backend() == "gloo":
+            if t.is_cuda:
                 h = t.detach().cpu()
-                dist.all_reduce(h, op=op)
+                dist.all_reduce(h, op=rop)
                 t.copy_(h)
             else:
-                dist.all_reduce(t, op=op)
+                dist.all_reduce(t, op=rop)
 
         if self.segments is not None and self.segments.capturing:
             self.segments.cut(run)          # eager, between two graph segments; replayed on this same tensor later
@@ -166,13 +212,21 @@ class DataParallelContext(object):
     def broadcast_parameters(self, model):
         if not self.active:
             return
+        from ._hip import COMM_F32, check, lib, ptr, stream
         for t in list(model.parameters()) + list(model.buffers()):
-            if t.is_cuda and dist.get_backend() == "gloo":
-                h = t.data.cpu()
+            d = t.data
+            if d.is_cuda and self.data_backend == "rccl":
+                if not d.is_contiguous() or (d.numel() * d.element_size()) % 4 != 0:
+                    raise RuntimeError("broadcast needs contiguous tensors of whole 32-bit words")
+                # raw 32-bit words: fp32 parameters and the int64 num_batches_tracked counters alike
+                check(lib.aesr_comm_broadcast(self.ensure_comm(), ptr(d), d.numel() * d.element_size() // 4, COMM_F32, 0, stream()),
+                      "aesr_comm_broadcast")
+            elif d.is_cuda:
+                h = d.cpu()
                 dist.broadcast(h, src=0)
-                t.data.copy_(h)
+                d.copy_(h)
             else:
-                dist.broadcast(t.data, src=0)
+                dist.broadcast(d, src=0)
         if hasattr(model, "mark_weights_dirty"):
             model.mark_weights_dirty()
 
@@ -187,7 +241,7 @@ class DataParallelContext(object):
     def reduce_scalar(self, v, weighted=True):
         if not self.active:
             return v
-        t = torch.as_tensor(v, dtype=torch.float64, device=self.device).clone().reshape(1)
+        t = torch.tensor([float(v)], dtype=torch.float64)          # host scalar on the control plane
         if weighted:
             t *= self.weight
         self._all_reduce(t)
@@ -200,18 +254,26 @@ class DataParallelContext(object):
         if not self.active or not means:
             return means
         keys = sorted(means.keys())
-        t = torch.tensor([means[k] * n_local for k in keys] + [n_local], dtype=torch.float64, device=self.device)
+        t = torch.tensor([means[k] * n_local for k in keys] + [n_local], dtype=torch.float64)
         self._all_reduce(t)
         tot = float(t[-1])
-        vals = t[:-1].cpu().tolist()
+        vals = t[:-1].tolist()
         return {k: (v / tot if tot > 0 else float("nan")) for k, v in zip(keys, vals)}
 
     def barrier(self):
-        if self.active:
+        if self.active and self.world > 1:
             dist.barrier()
 
     def shutdown(self):
-        """Tear the process group down (quiet exit under torch.distributed.run)."""
+        """Tear the communicator and the process group down (quiet exit under torch.distributed.run)."""
+        if self.comm is not None:
+            from ._hip import lib
+            try:
+                torch.cuda.synchronize()
+                lib.aesr_comm_destroy(self.comm)
+            except Exception:              # noqa: BLE001
+                pass
+            self.comm = None
         if dist.is_available() and dist.is_initialized():
             try:
                 dist.destroy_process_group()
@@ -221,6 +283,6 @@ class DataParallelContext(object):
     def max_over_ranks(self, v):
         if not self.active:
             return v
-        t = torch.tensor([float(v)], dtype=torch.float64, device=self.device)
-        self._all_reduce(t, dist.ReduceOp.MAX)
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        self._all_reduce(t, "max")
         return float(t)

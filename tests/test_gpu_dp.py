@@ -100,3 +100,83 @@ def test_segmented_step_graph_equals_host_launched_data_parallel(tmp_path):
             assert float((seg["sd"][k].double() - v.double()).abs().max()) <= 1e-6 + 1e-5 * float(v.abs().max()), k
         else:
             assert int(seg["sd"][k]) == int(v)
+
+
+def _rccl_worker(rank, port, out):
+    """A data-parallel group of ONE on the library-owned RCCL communicator (RCCL refuses two ranks on one device, so a one-GPU box
+    exercises the call pattern with nranks = 1): raw collectives, then the trainer step host-launched and as ONE captured graph
+    with the RCCL calls as graph nodes."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AESR_FORCE_DP="1")
+    os.environ.pop("AESR_DIST_BACKEND", None)
+    import ctypes
+    import warnings
+    warnings.simplefilter("ignore")
+    from superresolution_aniso_mri_amd import _hip
+    from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    from superresolution_aniso_mri_amd.parallel import DataParallelContext
+    torch.cuda.set_device(0)
+    dp = DataParallelContext(device="cuda:0")
+    assert dp.active and dp.data_backend == "rccl" and dp.graph_mode == "whole"
+    ver = ctypes.c_int(0)
+    _hip.check(_hip.lib.aesr_comm_rccl_version(ctypes.byref(ver)), "aesr_comm_rccl_version")
+    res = {"rccl_version": ver.value}
+    # raw collectives through the C ABI
+    a32 = torch.arange(1000, device="cuda", dtype=torch.float32)
+    a64 = torch.arange(77, device="cuda", dtype=torch.float64) * 0.5
+    dp._all_reduce(a32)
+    dp._all_reduce(a64, "max")
+    bufs = [torch.full((n,), float(n), device="cuda") for n in (3, 0, 130)]
+    arr = (ctypes.c_void_p * 3)(*[b.data_ptr() for b in bufs])
+    cnt = (ctypes.c_size_t * 3)(*[b.numel() for b in bufs])
+    _hip.check(_hip.lib.aesr_comm_allreduce_many(dp.ensure_comm(), arr, cnt, 3, _hip.COMM_F32, _hip.COMM_SUM, _hip.stream()), "allreduce_many")
+    torch.cuda.synchronize()
+    res["raw_ok"] = bool(torch.equal(a32.cpu(), torch.arange(1000, dtype=torch.float32)) and
+                         torch.equal(a64.cpu(), torch.arange(77, dtype=torch.float64) * 0.5) and float(bufs[2][0]) == 130.0)
+    # argument errors are reported, not crashed on
+    rc = _hip.lib.aesr_comm_allreduce(dp.ensure_comm(), _hip.ptr(a32), 4, 7, 0, _hip.stream())
+    res["bad_dtype"] = (rc, _hip.last_error())
+    torch.manual_seed(100)
+    tr = get_trainer_dynamic(_args("mse"))
+    dp.attach(tr)
+    dp.set_batch(3)
+    tr.enable_step_graph(eager_steps=2)                  # dp_mode picked from the data plane: "whole"
+    n0 = dp.n_collectives
+    for step in range(5):                                # 2 host-launched, 1 capture, 2 replays
+        tr.train(synthetic_batch(3, 32, 32, seed=40 + step, brain=True), keep_predictions=False)
+        if step == 0:
+            res["collectives_per_step"] = dp.n_collectives - n0
+    torch.cuda.synchronize()
+    res.update(graphs=len(tr._graphs), graph_dp=tr._graph_dp, loss=tr.losses["loss_ae"].floats(),
+               sd={k: v.cpu() for k, v in tr.model.state_dict().items()})
+    torch.save(res, out)
+    dp.shutdown()
+
+
+def test_rccl_communicator_and_whole_step_graph(tmp_path):
+    import warnings
+    from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    out = str(tmp_path / "rccl.pt")
+    mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
+    res = torch.load(out)
+    assert res["rccl_version"] >= 21800 and res["raw_ok"]
+    assert res["bad_dtype"][0] != 0 and "dtype" in res["bad_dtype"][1]
+    assert res["graphs"] == 1 and res["graph_dp"] == "whole"
+    # per step: 4 BatchNorm layers x (forward + backward) SyncBN exchanges + ONE flat gradient all-reduce
+    assert res["collectives_per_step"] == 9
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(100)
+        ref = get_trainer_dynamic(_args("mse"))
+    for step in range(5):
+        ref.train(synthetic_batch(3, 32, 32, seed=40 + step, brain=True), keep_predictions=False)
+    np.testing.assert_allclose(res["loss"], ref.losses["loss_ae"].floats(), rtol=2e-5)
+    for k, v in ref.model.state_dict().items():
+        a, b = res["sd"][k].double(), v.cpu().double()
+        if "num_batches" in k:
+            assert int(a) == int(b)
+            continue
+        diff = (a - b).abs()
+        assert float(diff.max()) <= 5 * 2 * 1e-3 + 1e-6, k
+        assert float((diff > 1e-4 + 1e-3 * b.abs()).double().mean()) <= 0.03, k

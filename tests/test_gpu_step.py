@@ -1,6 +1,8 @@
-"""-m gpu: the full ae_combined training step (trainer classes on the HIP engine) against the vectors generated
-from the reference modules (tests/golden/step_k3_*.npz): losses of step 0 (pure forward, rel 1e-5), latents / synthesised
-slices (rel-L2 1e-5), first-step gradients (rel-L2 1e-4) and parameters after 3 Adam steps (Adam sign-noise bound)."""
+"""-m gpu: the full training step (trainer classes on the HIP engine) against vectors made by the reference's OWN trainer classes
+(tests/golden/step_k3_*.npz, step_k4_cardiac_anneal.npz, step_probe_c*.npz: oracle/make_golden.py runs AETrainerEndToEnd /
+AETrainerExtension1Brain / AEBaseTrainer on the CPU): losses of step 0 (pure forward, rel 2e-5), latents / synthesised slices
+(rel-L2 1e-5), first-step gradients (rel-L2 2e-4), parameters and BatchNorm statistics after 3 Adam steps; the BASELINE
+configurations at their own size (12 triplets of 160x160, MSE and LPIPS, scales 2 and 3) against the probes and the oracle."""
 import os
 
 import numpy as np
@@ -16,55 +18,97 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def make_trainer(tag, rec, lr=1e-3):
+# fixture tag -> (args overrides, lr); every step_k3_* fixture is the reference's OWN trainer class run on the CPU (oracle/make_golden.py)
+STEP_CASES = {
+    "cardiac_mse": (dict(image_mix_loss_func="mse"), 1e-3),
+    "cardiac_lpips": (dict(image_mix_loss_func="perceptual"), 1e-3),
+    "brain_lpips": (dict(image_mix_loss_func="perceptual", dataset="OASIS"), 1e-3),
+    "cardiac_percept": (dict(use_percept_loss=True), 1e-3),                      # --use_percept_loss: LPIPS reconstruction loss too
+    "ae_plain": (dict(model="ae", image_mix_loss_func="mse"), 1e-3),            # plain `ae`: kwatsch/trainer_ae.py:71-109
+    "cardiac_mse_s3": (dict(image_mix_loss_func="mse", latent_width=4), 1e-3),  # three pooling stages
+    "cardiac_mse_lr1e-5": (dict(image_mix_loss_func="mse"), 1e-5),              # the reference's default learning rate
+}
+
+
+def make_trainer(tag, rec, lr=None, **over):
     from superresolution_aniso_mri_amd.networks.net_config import NetworkConfig
     from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
-    dataset = "OASIS" if tag.startswith("brain") else "ACDC"
-    args = dict(model="ae_combined", dataset=dataset, device="cuda", lr=lr, weight_decay=0.0, epochs=10, width=32,
+    kw, lr0 = STEP_CASES.get(tag, (dict(image_mix_loss_func="mse" if tag.endswith("mse") else "perceptual"), 1e-3))
+    args = dict(model="ae_combined", dataset="ACDC", device="cuda", lr=lr0 if lr is None else lr, weight_decay=0.0, epochs=10, width=32,
                 latent_width=8, depth=8, latent=16, ex_loss_weight1=0.05, use_percept_loss=False, get_masks=False,
                 use_loss_annealing=False, use_extra_latent_loss=False, epoch_threshold=100, ae_class="VanillaACAI",
-                image_mix_loss_func="mse" if tag.endswith("mse") else "perceptual", vgg_weights="synthetic-hash")
-    for k, v in NetworkConfig("ae_combined", dataset=dataset).architecture.items():
+                vgg_weights="synthetic-hash")
+    args.update(kw)
+    args.update(over)
+    for k, v in NetworkConfig(args["model"], dataset=args["dataset"]).architecture.items():
         args.setdefault(k, v)
     trainer = get_trainer_dynamic(args)
     trainer.model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in rec.items() if k.startswith("p0/")})
     return trainer
 
 
-@pytest.mark.parametrize("tag", ["cardiac_mse", "cardiac_lpips", "brain_lpips"])
+def _batch(rec, step):
+    batch = {"image": torch.from_numpy(rec["image_%d" % step]), "slice_between": torch.from_numpy(rec["between_%d" % step])}
+    if "alpha_from" in rec:
+        batch["alpha_from"], batch["alpha_to"] = torch.from_numpy(rec["alpha_from"]), torch.from_numpy(rec["alpha_to"])
+    return batch
+
+
+@pytest.mark.parametrize("tag", sorted(STEP_CASES))
 def test_three_train_steps(tag):
+    """Three optimisation steps of the HIP trainer classes against three steps of the reference's own trainer classes."""
     rec = dict(np.load(os.path.join(GOLDEN, "step_k3_%s.npz" % tag)))
+    lr = STEP_CASES[tag][1]
     trainer = make_trainer(tag, rec)
-    assert type(trainer).__name__ == ("AETrainerExtension1Brain" if tag.startswith("brain") else "AETrainerEndToEnd")
+    assert type(trainer).__name__ == str(rec["trainer_class"])
+    keys = [str(k) for k in rec["loss_keys"]]
     for step in range(3):
-        batch = {"image": torch.from_numpy(rec["image_%d" % step]), "slice_between": torch.from_numpy(rec["between_%d" % step])}
-        if "alpha_from" in rec:
-            batch["alpha_from"], batch["alpha_to"] = torch.from_numpy(rec["alpha_from"]), torch.from_numpy(rec["alpha_to"])
-        if step == 0:
-            # first-step gradients: run the step with a zero learning rate replica of the maths via hooks is overkill;
-            # read them from the flat gradient buffer right after the step (Adam does not modify gradients)
-            pass
-        trainer.train(batch, keep_predictions=(step == 0))
-        got = [trainer.losses["loss_ae"][-1], trainer.losses["loss_ae_dist"][-1], trainer.losses["loss_ae_dist_extra"][-1],
-               trainer.losses["loss_latent_1"][-1]]
-        np.testing.assert_allclose(got, rec["losses"][step], rtol=2e-5 if step == 0 else 5e-3)
+        trainer.train(_batch(rec, step), keep_predictions=(step == 0))
+        got = [trainer.losses[k][-1] for k in keys]
+        # step 0 is a pure forward comparison; behind Adam updates of lr * sign(g) the sign of a near-zero gradient is summation
+        # noise, so at lr 1e-3 later losses agree to ~1e-3 only; at the reference's lr (1e-5) they stay at forward accuracy
+        np.testing.assert_allclose(got, rec["losses"][step], rtol=2e-5 if (step == 0 or lr < 1e-4) else 2e-3)
         if step == 0:
             assert rel_l2(trainer.train_predictions["slice_inbetween_mix"], rec["s_mix_0"]) < 1e-5
             assert rel_l2(trainer.train_predictions["reconstruction"], rec["out_0"]) < 1e-5
+            assert rel_l2(trainer.train_predictions["z_mix"], rec["z_mix_0"]) < 1e-5
             for k, p in trainer.model.named_parameters():
                 assert rel_l2(p.grad, rec["grad0/" + k]) < 2e-4, k
-    assert trainer.iters == 4
+    assert trainer.iters == int(rec["iters"]) == 4
     sd = trainer.model.state_dict()
+    nbt = 3 if tag == "ae_plain" else 6          # BatchNorm calls per layer: plain ae = one train-mode pass per step, ae_combined = two
     for k, v in rec.items():
         if not k.startswith("p3/"):
             continue
         a, b = sd[k[3:]].double().cpu().numpy(), v.astype(np.float64)
         if "num_batches" in k:
-            assert int(a) == int(b) == 6          # two statistic groups per pass, three steps
+            assert int(a) == int(b) == nbt, k
             continue
         diff = np.abs(a - b)
-        assert diff.max() <= 3 * 2 * 1e-3 + 1e-6, k
-        assert (diff > 2e-4 + 1e-3 * np.abs(b)).mean() <= 0.03, k
+        assert diff.max() <= 3 * 2 * lr + 1e-6, k                              # Adam: at most 2 lr per step
+        assert (diff > 0.2 * lr + 1e-3 * np.abs(b)).mean() <= 0.03, k          # bulk: within a fifth of one Adam step
+        if "running" in k:                                                     # BatchNorm statistics: momentum / unbiased-var details
+            np.testing.assert_allclose(a, b, rtol=2e-3 if lr > 1e-4 else 2e-5, atol=2e-3 * lr + 1e-7, err_msg=k)
+
+
+def test_loss_annealing_under_the_step_graph():
+    """use_loss_annealing (kwatsch/cardiac/trainer_ae.py:80-83, kwatsch/base_trainer.py:456-459) with the step replayed from a
+    captured HIP graph: lambda lives in a device scalar, so the epoch's weight reaches the replayed kernels.  The reference
+    trainer ran one step in each of 4 epochs (fixture); here 2 eager steps, then 2 replays of the graph captured at epoch 2."""
+    rec = dict(np.load(os.path.join(GOLDEN, "step_k4_cardiac_anneal.npz")))
+    trainer = make_trainer("cardiac_mse", rec, epochs=4, use_loss_annealing=True)
+    np.testing.assert_allclose(trainer.loss_weights, rec["loss_weights"], rtol=1e-12)
+    trainer.enable_step_graph(eager_steps=2)
+    keys = [str(k) for k in rec["loss_keys"]]
+    for step in range(4):
+        trainer.epoch = step
+        trainer.train(_batch(rec, step), keep_predictions=False)
+        got = [trainer.losses[k][-1] for k in keys]
+        np.testing.assert_allclose(got, rec["losses"][step], rtol=2e-5 if step == 0 else 2e-3)
+        # the logged synthesis loss is lambda_epoch * mse: its ratio to the un-annealed weight pins the lambda that was applied
+    assert len(trainer._graphs) == 1
+    lam = np.array(trainer.losses["loss_ae_dist_extra"].floats()) / rec["losses"][:, keys.index("loss_ae_dist_extra")]
+    np.testing.assert_allclose(lam, 1.0, rtol=2e-3)
 
 
 def test_checkpoint_roundtrip(tmp_path):
