@@ -88,7 +88,8 @@ def test_conv_fwd(hip, case, act):
     assert rel_l2(nchw(out), ref) < 1e-5
 
 
-@pytest.mark.parametrize("case", [(24, 20, 20, 512, 512, 4), (12, 10, 10, 512, 512, 2), (6, 10, 10, 256, 128, 4), (3, 9, 11, 128, 64, 2)])
+# image counts no other test uses: the library caches one tile plan per shape, and the forced split must be planned fresh
+@pytest.mark.parametrize("case", [(23, 20, 20, 512, 512, 4), (11, 10, 10, 512, 512, 2), (5, 10, 10, 256, 128, 4), (3, 9, 11, 128, 64, 2)])
 def test_conv_ksplit_workspace_paths(hip, case, monkeypatch):
     """Under-filled deep layers (VGG conv4/5 shapes): the workspace entry points split the input channels into extra work
     items + a fix-up pass.  Forward (bias + ReLU) and masked data gradient equal the unsplit kernels' results (1e-5)."""

@@ -152,7 +152,7 @@ def test_train_steps(tag):
         a, b = sd[k].numpy().astype(np.float64), v.numpy().astype(np.float64)
         diff = np.abs(a - b)
         assert diff.max() <= nsteps * 2 * lr + 1e-6, k
-        assert (diff > 0.2 * lr + 1e-3 * np.abs(b)).mean() <= 0.03, k
+        assert (diff > 0.2 * lr + 1e-3 * np.abs(b)).sum() <= max(1, 0.03 * diff.size), k
 
 
 def test_loss_annealing_steps():
