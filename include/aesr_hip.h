@@ -259,6 +259,19 @@ size_t aesr_ssim_workspace_doubles(int Z, int H, int W);
 int aesr_ssim_mse(const float* a, const float* b, double* workspace, double* ssim, double* mse, int Z, int H, int W, int win,
                   double data_range, double k1, double k2, void* stream);
 
+/* ---- Winograd F(2x2,3x3) form of the same 3x3 / padding-1 convolutions (2.25x fewer matrix-core flops; csrc/conv_wino.hip) ------
+ * Same results as aesr_conv2d_fwd / _dgrad up to fp32 rounding of the transforms (2-4e-7 relative).  Needs K-side channels % 16
+ * == 0 and N-side channels % 32 == 0 (aesr_conv2d_wino_supported; transpose = 1 asks for the data-gradient roles).  The filter is
+ * handed over pre-transformed: U = G g G^T, packed by aesr_conv2d_wino_pack_many (job.transpose: 0 forward, 1 data gradient;
+ * job.KS must be 3) into aesr_conv2d_wino_packed_floats floats. */
+int aesr_conv2d_wino_supported(int Cin, int Cout, int KS, int pad, int transpose);
+size_t aesr_conv2d_wino_packed_floats(int Cout, int Cin, int transpose);
+int aesr_conv2d_wino_pack_many(const aesr_pack_job* jobs_host, int njobs, void* stream);
+int aesr_conv2d_wino_fwd(const float* in, const float* upacked, const float* bias, float* out, int N, int H, int W, int Cin,
+                         int Cout, int act, float slope, void* stream);
+int aesr_conv2d_wino_dgrad(const float* dy, const float* upacked_t, const float* x_saved, float* dx, int N, int H, int W, int Cin,
+                           int Cout, int mask_act, float slope, void* stream);
+
 /* ---- data-parallel collectives: an RCCL communicator owned by the library (one process per GPU; new functionality -- the
  * reference's only multi-GPU code moves the loss to 'cuda:1', kwatsch/trainer_ae.py:43-44,84-86) --------------------------------
  * Collectives are plain enqueues on the caller's stream (capturable into a HIP graph; no watchdog thread, unlike

@@ -93,6 +93,11 @@ SIGNATURES = {
     "aesr_ssim_workspace_doubles": (c_size_t, [c_int, c_int, c_int]),
     "aesr_ssim_mse": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_double, c_double, c_double, P]),
     "aesr_adam_step": (c_int, [P, P, P, P, P, c_size_t] + [c_float] * 5 + [P]),
+    "aesr_conv2d_wino_supported": (c_int, [c_int] * 5),
+    "aesr_conv2d_wino_packed_floats": (c_size_t, [c_int, c_int, c_int]),
+    "aesr_conv2d_wino_pack_many": (c_int, [ctypes.POINTER(PackJob), c_int, P]),
+    "aesr_conv2d_wino_fwd": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),
+    "aesr_conv2d_wino_dgrad": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),
     "aesr_comm_rccl_version": (c_int, [IP]),
     "aesr_comm_unique_id": (c_int, [c_char_p]),
     "aesr_comm_init": (c_int, [c_char_p, c_int, c_int, ctypes.POINTER(c_void_p)]),

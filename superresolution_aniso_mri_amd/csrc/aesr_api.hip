@@ -117,6 +117,49 @@ static ConvPlan plan_conv(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
     return p;
 }
 
+// Winograd F(2x2,3x3) work-item shape: TI images x THt x TWt tiles (<= 128 tiles = 8 waves x 16), patch within LDS (two buffers)
+// and within 5 staging pieces per thread.  Cost = work-item rounds over the 256 CUs x chunk time; a chunk costs one or two
+// wave-passes per SIMD (waves whose 16 tiles are all invalid skip the arithmetic).
+struct WinoPlan { int TI, THt, TWt, CinP, CoutP; double cost; };
+static std::map<std::tuple<int, int, int, int, int>, WinoPlan> g_wino_plans;
+
+static WinoPlan plan_wino(int N, int H, int W, int Cin, int Cout) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    const auto key = std::make_tuple(N, H, W, Cin, Cout);
+    auto it = g_wino_plans.find(key);
+    if (it != g_wino_plans.end()) return it->second;
+    WinoPlan p;
+    p.CinP = round_up(Cin, 16);
+    p.CoutP = round_up(Cout, 32);
+    const int Ht = ceil_div(H, 2), Wt = ceil_div(W, 2), ncot = p.CoutP / 32, nch = p.CinP / 16;
+    p.TI = 1; p.THt = 1; p.TWt = 1; p.cost = 1e300;
+    auto consider = [&](int TI, int THt, int TWt) {
+        const int TP = TI * THt * TWt, PP = TI * (2 * THt + 2) * (2 * TWt + 2);
+        if (TP > 128 || PP * 4 > 512 * 5 || aesr_wino_lds_bytes(PP) > (size_t)160 * 1024) return;
+        const long items = (long)ceil_div(N, TI) * ceil_div(Ht, THt) * ceil_div(Wt, TWt) * ncot;
+        const double passes = ceil_div(ceil_div(TP, 16), 4);
+        const double per = nch * (passes * 128 * 32.0 + 1200.0) + 2500.0;
+        const double rounds = items <= 8 * 256 ? (double)ceil_div((int)items, 256) : (double)items / 256.0;
+        const double t = per * rounds;
+        if (t < p.cost * 0.999 || (t < p.cost * 1.001 && TP > p.TI * p.THt * p.TWt)) {
+            if (t < p.cost) p.cost = t;
+            p.TI = TI; p.THt = THt; p.TWt = TWt;
+        }
+    };
+    for (int TI = 1; TI <= N && TI * Ht * Wt <= 128; ++TI) consider(TI, Ht, Wt);
+    for (int THt = 1; THt <= Ht && THt <= 64; ++THt)
+        for (int TWt = 1; TWt <= Wt && TWt <= 64; ++TWt) consider(1, THt, TWt);
+    if (const char* e = getenv("AESR_WINO_TILE")) {           // experiments: force "TI,THt,TWt"
+        int ti, th, tw;
+        if (sscanf(e, "%d,%d,%d", &ti, &th, &tw) == 3) { p.TI = ti; p.THt = th < Ht ? th : Ht; p.TWt = tw < Wt ? tw : Wt; }
+    }
+    if (getenv("AESR_PLAN_DEBUG"))
+        fprintf(stderr, "[aesr plan] wino N=%d %dx%d Cin=%d Cout=%d -> TI=%d THt=%d TWt=%d (tiles %d, patch %d px) cost %.0f\n", N, H, W, Cin, Cout,
+                p.TI, p.THt, p.TWt, p.TI * p.THt * p.TWt, p.TI * (2 * p.THt + 2) * (2 * p.TWt + 2), p.cost);
+    g_wino_plans[key] = p;
+    return p;
+}
+
 struct WgradPlan { int variant, COT, CinP, CoutP, TH, TW, S, nslab, PWS, TWS, PSX, PSD; size_t slab_floats; };
 static std::map<std::tuple<int, int, int, int, int, int>, WgradPlan> g_wgrad_plans;
 
@@ -308,6 +351,68 @@ int aesr_conv2d_dgrad(const float* dy, const float* packed_t, const float* x_sav
     // dx = conv(dy [N,Ho,Wo,Cout], flipped w) with padding KS-1-pad -> output [N,H,W,Cin]
     return run_igemm(dy, packed_t, nullptr, x_saved, dx, N, Ho, Wo, Cout, Cin, KS, KS - 1 - pad, ACT_NONE, mask_act, slope, nullptr,
                      (hipStream_t)stream);
+}
+
+// ---- Winograd F(2x2,3x3) path --------------------------------------------------------------------------------------
+int aesr_conv2d_wino_supported(int Cin, int Cout, int KS, int pad, int transpose) {
+    const int kin = transpose ? Cout : Cin, nout = transpose ? Cin : Cout;
+    return KS == 3 && pad == 1 && kin > 0 && nout > 0 && kin % 16 == 0 && nout % 32 == 0;
+}
+
+size_t aesr_conv2d_wino_packed_floats(int Cout, int Cin, int transpose) {
+    const int kin = transpose ? Cout : Cin, nout = transpose ? Cin : Cout;
+    return (size_t)16 * round_up(kin, 16) * round_up(nout, 32);
+}
+
+int aesr_conv2d_wino_pack_many(const aesr_pack_job* jobs_host, int njobs, void* stream) {
+    AESR_CHECK_ARG(jobs_host && njobs > 0, "aesr_conv2d_wino_pack_many: no jobs");
+    for (int j0 = 0; j0 < njobs; j0 += PACK_MAX_JOBS) {
+        PackTable t;
+        memset(&t, 0, sizeof(t));
+        t.njobs = njobs - j0 < PACK_MAX_JOBS ? njobs - j0 : PACK_MAX_JOBS;
+        int nb = 0;
+        for (int k = 0; k < t.njobs; ++k) {
+            const aesr_pack_job& jb = jobs_host[j0 + k];
+            AESR_CHECK_ARG(jb.w && jb.packed && jb.Cout > 0 && jb.Cin > 0 && jb.KS == 3, "aesr_conv2d_wino_pack_many: bad job %d", j0 + k);
+            const int kin = jb.transpose ? jb.Cout : jb.Cin, nout = jb.transpose ? jb.Cin : jb.Cout;
+            PackJob& o = t.job[k];
+            o.w = jb.w; o.p = jb.packed; o.Cout = jb.Cout; o.Cin = jb.Cin; o.KS = 3; o.KinP = round_up(kin, 16); o.NoutP = round_up(nout, 32);
+            o.TN = 32; o.transpose = jb.transpose; o.block0 = nb;
+            const size_t pairs = (size_t)o.KinP * o.NoutP;
+            int blocks = (int)((pairs + 255) / 256);
+            if (blocks > 256) blocks = 256;
+            nb += blocks;
+        }
+        t.nblocks = nb;
+        if (int e = aesr_launch_wino_pack_many(t, (hipStream_t)stream)) return e;
+    }
+    return AESR_OK;
+}
+
+static int run_wino(const float* in, const float* upk, const float* bias, const float* ysave, float* out, int N, int H, int W,
+                    int Cin, int Cout, int act, int mask_act, float slope, hipStream_t st) {
+    const WinoPlan p = plan_wino(N, H, W, Cin, Cout);
+    WinoArgs a;
+    a.in = in; a.upk = upk; a.bias = bias; a.ysave = ysave; a.out = out;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = p.CinP; a.Cout = Cout; a.CoutP = p.CoutP;
+    a.TI = p.TI; a.THt = p.THt; a.TWt = p.TWt; a.regs_y = a.regs_x = a.nitems = 0;
+    a.act = act; a.mask_act = mask_act; a.slope = slope; a.dbgbuf = nullptr; a.flags = 0;
+    return aesr_launch_conv_wino(a, st);
+}
+
+int aesr_conv2d_wino_fwd(const float* in, const float* upacked, const float* bias, float* out, int N, int H, int W, int Cin,
+                         int Cout, int act, float slope, void* stream) {
+    AESR_CHECK_ARG(in && upacked && out && N > 0 && H > 0 && W > 0, "aesr_conv2d_wino_fwd: null pointer or empty shape");
+    AESR_CHECK_ARG(aesr_conv2d_wino_supported(Cin, Cout, 3, 1, 0), "aesr_conv2d_wino_fwd: needs Cin %% 16 == 0 and Cout %% 32 == 0 (got %d -> %d)", Cin, Cout);
+    return run_wino(in, upacked, bias, nullptr, out, N, H, W, Cin, Cout, act, ACT_NONE, slope, (hipStream_t)stream);
+}
+
+int aesr_conv2d_wino_dgrad(const float* dy, const float* upacked_t, const float* x_saved, float* dx, int N, int H, int W, int Cin,
+                           int Cout, int mask_act, float slope, void* stream) {
+    AESR_CHECK_ARG(dy && upacked_t && dx && N > 0 && H > 0 && W > 0, "aesr_conv2d_wino_dgrad: null pointer or empty shape");
+    AESR_CHECK_ARG(aesr_conv2d_wino_supported(Cin, Cout, 3, 1, 1), "aesr_conv2d_wino_dgrad: needs Cout %% 16 == 0 and Cin %% 32 == 0 (got %d -> %d)", Cin, Cout);
+    // dx = conv(dy [N,H,W,Cout], flipped / transposed filter), padding 1 -> [N,H,W,Cin]
+    return run_wino(dy, upacked_t, nullptr, x_saved, dx, N, H, W, Cout, Cin, ACT_NONE, mask_act, slope, (hipStream_t)stream);
 }
 
 size_t aesr_conv2d_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int KS, int pad) {

@@ -18,10 +18,25 @@ int aesr_launch_conv_ksplit_fixup(const float* partial, const float* bias, const
                                   int ksplit, int act, int mask_act, float slope, hipStream_t st);
 int aesr_launch_pack_weights(const float* w, float* p, int Cout, int Cin, int KS, int KinP, int NoutP, int TN, int transpose, hipStream_t st);
 
+// Winograd F(2x2,3x3) convolution (conv_wino.hip): 3x3, stride 1, padding 1
+struct WinoArgs {
+    const float* in; const float* upk; const float* bias; const float* ysave; float* out;
+    int N, H, W, Cin, CinP, Cout, CoutP;
+    int TI, THt, TWt;            // work item = TI images x THt x TWt Winograd tiles (2x2 outputs each) x 32 output channels
+    int regs_y, regs_x, nitems;  // filled by the launcher
+    int act, mask_act;
+    float slope;
+    float* dbgbuf;               // per-wave phase stamps (AESR_WINO_DBG=1), nullptr in normal operation
+    int flags;                   // experiment switches (AESR_WINO_FLAGS)
+};
+int aesr_launch_conv_wino(const WinoArgs& a, hipStream_t st);
+size_t aesr_wino_lds_bytes(int patch_pixels);
+
 #define PACK_MAX_JOBS 32
 struct PackJob { const float* w; float* p; int Cout, Cin, KS, KinP, NoutP, TN, transpose, block0; };
 struct PackTable { int njobs, nblocks; PackJob job[PACK_MAX_JOBS]; };
 int aesr_launch_pack_many(const PackTable& t, hipStream_t st);
+int aesr_launch_wino_pack_many(const PackTable& t, hipStream_t st);
 
 struct WgradArgs {
     const float* x; const float* dy; float* slab;

@@ -54,6 +54,13 @@ class KernelProfiler:
 
 PROFILER = None
 FUSE_STEM = os.environ.get("AESR_FUSE_STEM", "1") != "0"      # fold the encoder stem into the first 3x3 conv
+# 3x3 / padding-1 convolutions with enough channels run in Winograd F(2x2,3x3) form (csrc/conv_wino.hip: 2.25x fewer MFMA flops,
+# results equal to the implicit GEMM within 2-4e-7); AESR_WINO=0 keeps every layer on the exact-fp32 fma-chain implicit GEMM
+USE_WINO = os.environ.get("AESR_WINO", "1") != "0"
+
+
+def wino_ok(cin, cout, ks, pad, transpose):
+    return bool(USE_WINO and lib.aesr_conv2d_wino_supported(int(cin), int(cout), int(ks), int(pad), int(transpose)))
 
 
 def _pb(kind, flops):
@@ -94,9 +101,13 @@ class ConvStep:
                 raise NotImplementedError("activation fused behind a stride-2 convolution")
             self.cin_full, self.cin, self.ks, self.pad = mod.in_channels, 4 * mod.in_channels, 1, 0
         self.w1 = None          # s2d: the equivalent [Cout, 4Cin, 1, 1] filter
-        self.packed = None      # forward operand
+        self.packed = None      # forward operand (implicit GEMM packing)
         self.packed_t = None    # data-gradient operand
+        self.packed_w = None    # forward operand, Winograd-transformed (U = G g G^T)
+        self.packed_wt = None   # data-gradient operand, Winograd-transformed
         self.packed_epoch = -1
+        self.wino_fwd = (not self.s2d) and wino_ok(self.cin, self.cout, self.ks, self.pad, 0)
+        self.wino_dgrad = (not self.s2d) and wino_ok(self.cin, self.cout, self.ks, self.pad, 1)
 
     @property
     def mfma_fwd(self):
@@ -262,22 +273,29 @@ class SequentialRunner:
                 stale.append((s, epoch))
         if not stale:
             return
-        jobs = []
+        jobs, wjobs = [], []
         for s, _ in stale:
             _hip.require_gpu_tensor(s.mod.weight, "conv weight")
             wk = s.weight_for_kernels()
-            for transpose, attr, ok in ((0, "packed", s.cin % 4 == 0), (1, "packed_t", s.cout % 4 == 0)):
+            # each direction is packed for the kernel that will run it: Winograd where it applies, implicit GEMM otherwise
+            forms = ((0, "packed", s.cin % 4 == 0 and not s.wino_fwd, False), (1, "packed_t", s.cout % 4 == 0 and not s.wino_dgrad, False),
+                     (0, "packed_w", s.wino_fwd, True), (1, "packed_wt", s.wino_dgrad, True))
+            for transpose, attr, ok, wino in forms:
                 if not ok:
                     continue
-                n = lib.aesr_conv2d_packed_floats(s.cout, s.cin, s.ks, transpose)
+                n = (lib.aesr_conv2d_wino_packed_floats(s.cout, s.cin, transpose) if wino
+                     else lib.aesr_conv2d_packed_floats(s.cout, s.cin, s.ks, transpose))
                 buf = getattr(s, attr)
                 if buf is None or buf.numel() != n:
                     buf = _empty((n,), wk)
                     setattr(s, attr, buf)
-                jobs.append(_hip.PackJob(wk.data_ptr(), buf.data_ptr(), s.cout, s.cin, s.ks, transpose))
+                (wjobs if wino else jobs).append(_hip.PackJob(wk.data_ptr(), buf.data_ptr(), s.cout, s.cin, s.ks, transpose))
         if jobs:
             arr = (_hip.PackJob * len(jobs))(*jobs)
             check(lib.aesr_conv2d_pack_many(arr, len(jobs), stream()), "aesr_conv2d_pack_many")
+        if wjobs:
+            arr = (_hip.PackJob * len(wjobs))(*wjobs)
+            check(lib.aesr_conv2d_wino_pack_many(arr, len(wjobs), stream()), "aesr_conv2d_wino_pack_many")
         for s, epoch in stale:
             s.packed_epoch = epoch
 
@@ -332,6 +350,11 @@ class SequentialRunner:
                 if s.cout == 1 and s.ks == 3 and s.pad == 1 and s.cin % 4 == 0:
                     check(lib.aesr_conv2d_cout1_fwd(ptr(cur), ptr(s.mod.weight), ptr(bias), ptr(out), N, H, W, s.cin, s.act,
                                                     s.slope, stream()), "aesr_conv2d_cout1_fwd")
+                elif s.wino_fwd:
+                    _pb("conv_wino_f32", 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
+                    check(lib.aesr_conv2d_wino_fwd(ptr(cur), ptr(s.packed_w), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, s.act,
+                                                   s.slope, stream()), "aesr_conv2d_wino_fwd")
+                    _pe()
                 elif s.mfma_fwd:
                     _pb("conv_igemm_f32", 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
                     nws = lib.aesr_conv2d_workspace_floats(N, H, W, s.cin, s.cout, s.ks, s.pad)    # > 0: few, deep work items
@@ -490,6 +513,11 @@ class SequentialRunner:
                 if s.cin <= 4 and mask is None:
                     check(lib.aesr_conv2d_smallcin_dgrad(ptr(g), ptr(s.mod.weight), ptr(dx), N, H, W, s.cin, s.cout, s.ks,
                                                          s.pad, 0, None, stream()), "aesr_conv2d_smallcin_dgrad")
+                elif s.wino_dgrad:
+                    _pb("conv_wino_f32", 2.0 * N * H * W * s.cin * 9 * s.cout)
+                    check(lib.aesr_conv2d_wino_dgrad(ptr(g), ptr(s.packed_wt), ptr(mask), ptr(dx), N, H, W, s.cin, s.cout, mask_act,
+                                                     mslope, stream()), "aesr_conv2d_wino_dgrad")
+                    _pe()
                 elif s.cout % 4 == 0:
                     _pb("conv_igemm_f32", 2.0 * N * H * W * s.cin * s.ks * s.ks * s.cout)
                     nws = lib.aesr_conv2d_dgrad_workspace_floats(N, H, W, s.cin, s.cout, s.ks, s.pad)

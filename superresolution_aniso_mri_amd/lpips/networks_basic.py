@@ -15,7 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import _hip
+from .. import _hip, engine
 from .._hip import check, lib, ptr, stream
 from .synthetic_vgg import VGG16_CFG, conv_indices, synthetic_vgg16_state
 
@@ -129,7 +129,7 @@ class PNetLin(nn.Module):
             (l.model[-1].weight.data_ptr(), l.model[-1].weight._version) for l in self.lins)
         if self._packed is not None and self._packed["key"] == key:
             return self._packed
-        pk = {"key": key, "fwd": [], "bwd": [], "lin": []}
+        pk = {"key": key, "fwd": [], "bwd": [], "fwd_wino": [], "bwd_wino": [], "lin": []}
         # conv1_1: 3 input channels padded to 4 (zero filter plane) so the MFMA kernel's 16-byte channel pieces apply
         w0 = convs[0].weight
         _hip.require_gpu_tensor(w0, "vgg weight")
@@ -140,12 +140,19 @@ class PNetLin(nn.Module):
             cin = w.shape[1]
             cout = w.shape[0]
             _hip.require_gpu_tensor(w, "vgg weight")
-            pf = torch.empty(lib.aesr_conv2d_packed_floats(cout, cin, 3, 0), device=w.device)
-            pb = torch.empty(lib.aesr_conv2d_packed_floats(cout, cin, 3, 1), device=w.device)
-            check(lib.aesr_conv2d_pack(ptr(w), ptr(pf), cout, cin, 3, 0, stream()), "aesr_conv2d_pack")
-            check(lib.aesr_conv2d_pack(ptr(w), ptr(pb), cout, cin, 3, 1, stream()), "aesr_conv2d_pack")
-            pk["fwd"].append(pf)
-            pk["bwd"].append(pb)
+            # per direction: the Winograd-transformed filter where conv_wino_f32 applies (every layer but conv1_1), else the
+            # implicit-GEMM packing
+            for transpose, key in ((0, "fwd"), (1, "bwd")):
+                wino = engine.wino_ok(cin, cout, 3, 1, transpose)
+                if wino:
+                    buf = torch.empty(lib.aesr_conv2d_wino_packed_floats(cout, cin, transpose), device=w.device)
+                    job = (_hip.PackJob * 1)(_hip.PackJob(w.data_ptr(), buf.data_ptr(), cout, cin, 3, transpose))
+                    check(lib.aesr_conv2d_wino_pack_many(job, 1, stream()), "aesr_conv2d_wino_pack_many")
+                else:
+                    buf = torch.empty(lib.aesr_conv2d_packed_floats(cout, cin, 3, transpose), device=w.device)
+                    check(lib.aesr_conv2d_pack(ptr(w), ptr(buf), cout, cin, 3, transpose, stream()), "aesr_conv2d_pack")
+                pk[key].append(buf)
+                pk[key + "_wino"].append(wino)
         for k, l in enumerate(self.lins):
             if self.L_weights[k] != 1.0:
                 raise NotImplementedError("L_weights != 1")
@@ -190,10 +197,16 @@ class PNetLin(nn.Module):
                 continue
             c = convs[nconv]
             out = torch.empty((N, h, w, v), device=x.device)
-            nws = lib.aesr_conv2d_workspace_floats(N, h, w, cin, v, 3, 1)      # > 0: the small deep layers (conv4/5) get K-split
-            ws = torch.empty((nws,), device=x.device) if nws else None
-            check(lib.aesr_conv2d_fwd_ws(ptr(cur), ptr(pk["fwd"][nconv]), ptr(c.bias), ptr(out), ptr(ws), N, h, w, cin, v, 3, 1,
-                                         _hip.ACT_RELU, 0.0, stream()), "aesr_conv2d_fwd_ws(vgg)")
+            if pk["fwd_wino"][nconv]:
+                engine._pb("conv_wino_f32", 2.0 * N * h * w * v * 9 * cin)
+                check(lib.aesr_conv2d_wino_fwd(ptr(cur), ptr(pk["fwd"][nconv]), ptr(c.bias), ptr(out), N, h, w, cin, v, _hip.ACT_RELU,
+                                               0.0, stream()), "aesr_conv2d_wino_fwd(vgg)")
+                engine._pe()
+            else:
+                nws = lib.aesr_conv2d_workspace_floats(N, h, w, cin, v, 3, 1)      # > 0: the small deep layers (conv4/5) get K-split
+                ws = torch.empty((nws,), device=x.device) if nws else None
+                check(lib.aesr_conv2d_fwd_ws(ptr(cur), ptr(pk["fwd"][nconv]), ptr(c.bias), ptr(out), ptr(ws), N, h, w, cin, v, 3, 1,
+                                             _hip.ACT_RELU, 0.0, stream()), "aesr_conv2d_fwd_ws(vgg)")
             cur, cin = out, v
             nconv += 1
             acts.append(cur)
@@ -249,11 +262,18 @@ class PNetLin(nn.Module):
             producer_is_pool = (n - 1) in tap_of           # conv n reads pool(tap layer n-1)
             mask = None if producer_is_pool else prev
             dxs = torch.empty((B, h, w, cv.in_channels), device=dev)
-            nws = lib.aesr_conv2d_dgrad_workspace_floats(B, h, w, cv.in_channels, cv.out_channels, 3, 1)
-            ws = torch.empty((nws,), device=dev) if nws else None
-            check(lib.aesr_conv2d_dgrad_ws(ptr(g), ptr(pk["bwd"][n - 1]), ptr(mask), ptr(dxs), ptr(ws), B, h, w, cv.in_channels,
-                                           cv.out_channels, 3, 1, _hip.ACT_RELU if mask is not None else 0, 0.0, stream()),
-                  "aesr_conv2d_dgrad_ws(vgg)")
+            if pk["bwd_wino"][n - 1]:
+                engine._pb("conv_wino_f32", 2.0 * B * h * w * cv.in_channels * 9 * cv.out_channels)
+                check(lib.aesr_conv2d_wino_dgrad(ptr(g), ptr(pk["bwd"][n - 1]), ptr(mask), ptr(dxs), B, h, w, cv.in_channels,
+                                                 cv.out_channels, _hip.ACT_RELU if mask is not None else 0, 0.0, stream()),
+                      "aesr_conv2d_wino_dgrad(vgg)")
+                engine._pe()
+            else:
+                nws = lib.aesr_conv2d_dgrad_workspace_floats(B, h, w, cv.in_channels, cv.out_channels, 3, 1)
+                ws = torch.empty((nws,), device=dev) if nws else None
+                check(lib.aesr_conv2d_dgrad_ws(ptr(g), ptr(pk["bwd"][n - 1]), ptr(mask), ptr(dxs), ptr(ws), B, h, w, cv.in_channels,
+                                               cv.out_channels, 3, 1, _hip.ACT_RELU if mask is not None else 0, 0.0, stream()),
+                      "aesr_conv2d_dgrad_ws(vgg)")
             g = dxs
         raise AssertionError("unreachable")
 

@@ -452,3 +452,89 @@ def test_bad_arguments_fail_loudly(hip):
     assert rc != 0
     with pytest.raises(RuntimeError):
         hip.check(rc, "lerp")
+
+
+# ---- Winograd F(2x2,3x3) form of the 3x3 / padding-1 convolutions (csrc/conv_wino.hip) -----------------------------------------
+WINO_CASES = [
+    # N, H, W, Cin, Cout
+    (2, 162, 162, 32, 32),      # enc.1 / enc.3 of the ACDC model: 81x81 tiles, regions of 9x14 tiles
+    (3, 81, 81, 32, 64),        # odd size: the last tile row / column is half outside the image
+    (2, 40, 40, 128, 64),       # 8 chunks of input channels, two cout tiles
+    (5, 10, 10, 64, 64),        # 5x5 tiles per image: several images per work item (TI > 1), idle waves
+    (3, 7, 9, 16, 32),          # one chunk, partial tiles everywhere
+    (1, 1, 1, 16, 32),          # a single pixel
+    (2, 2, 3, 48, 96),          # Cin = 3 chunks, Cout = 3 cout tiles
+    (1, 33, 130, 32, 32),       # wide image: regions that straddle the right border
+]
+
+
+def _pack_wino(hip, w, transpose):
+    cout, cin = w.shape[:2]
+    buf = torch.empty(hip.lib.aesr_conv2d_wino_packed_floats(cout, cin, transpose), device="cuda")
+    job = (hip.PackJob * 1)(hip.PackJob(w.data_ptr(), buf.data_ptr(), cout, cin, 3, transpose))
+    hip.check(hip.lib.aesr_conv2d_wino_pack_many(job, 1, hip.stream()), "wino_pack")
+    return buf
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_conv_wino_fwd(hip, case, act):
+    """Forward with bias and every fused activation against an fp64 convolution (1e-5; measured 2-4e-7) and against the
+    implicit-GEMM kernel of the same library."""
+    N, H, W, Cin, Cout = case
+    assert hip.lib.aesr_conv2d_wino_supported(Cin, Cout, 3, 1, 0) == 1
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = {0: ref, 1: F.leaky_relu(ref, 0.01), 2: F.relu(ref), 3: torch.sigmoid(ref)}[act]
+    xd, wd, bd = nhwc(x).cuda(), w.cuda(), b.cuda()
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    hip.check(hip.lib.aesr_conv2d_wino_fwd(hip.ptr(xd), hip.ptr(D(_pack_wino(hip, wd, 0))), hip.ptr(bd), hip.ptr(out), N, H, W, Cin, Cout,
+                                           act, 0.01, hip.stream()), "wino_fwd")
+    out_i = torch.empty_like(out)
+    hip.check(hip.lib.aesr_conv2d_fwd(hip.ptr(xd), hip.ptr(D(_pack(hip, wd, 0))), hip.ptr(bd), hip.ptr(out_i), N, H, W, Cin, Cout, 3, 1,
+                                      act, 0.01, hip.stream()), "conv_fwd")
+    torch.cuda.synchronize()
+    assert rel_l2(nchw(out), ref) < 1e-5
+    assert rel_l2(out, out_i) < 2e-6
+    # no bias: the bias slot of the accumulators must start from zero
+    out2 = torch.full_like(out, float("nan"))
+    hip.check(hip.lib.aesr_conv2d_wino_fwd(hip.ptr(xd), hip.ptr(D(_pack_wino(hip, wd, 0))), None, hip.ptr(out2), N, H, W, Cin, Cout, 0, 0.0,
+                                           hip.stream()), "wino_fwd")
+    torch.cuda.synchronize()
+    assert rel_l2(nchw(out2), F.conv2d(x.double(), w.double(), None, padding=1)) < 1e-5
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+@pytest.mark.parametrize("mask_act", [0, 1, 2])
+def test_conv_wino_dgrad(hip, case, mask_act):
+    """Data gradient (flipped / transposed filter) with the fused derivative mask of the producing activation."""
+    N, H, W, Cout, Cin = case            # roles swapped so that the data-gradient constraints (Cout % 16, Cin % 32) hold
+    assert hip.lib.aesr_conv2d_wino_supported(Cin, Cout, 3, 1, 1) == 1
+    g = torch.Generator().manual_seed(3 + hash(case) % 1000)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cout * 9)
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    xs = torch.randn(N, Cin, H, W, generator=g)            # saved activation output whose sign selects the derivative
+    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w.double(), dy.double(), padding=1)
+    if mask_act == 1:
+        ref = ref * torch.where(xs > 0, 1.0, 0.01).double()
+    elif mask_act == 2:
+        ref = ref * (xs > 0).double()
+    dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+    hip.check(hip.lib.aesr_conv2d_wino_dgrad(hip.ptr(D(nhwc(dy))), hip.ptr(D(_pack_wino(hip, w.cuda(), 1))),
+                                             hip.ptr(D(nhwc(xs))) if mask_act else None, hip.ptr(dx), N, H, W, Cin, Cout, mask_act, 0.01,
+                                             hip.stream()), "wino_dgrad")
+    torch.cuda.synchronize()
+    assert rel_l2(nchw(dx), ref) < 1e-5
+
+
+def test_conv_wino_argument_errors(hip):
+    L = hip.lib
+    assert L.aesr_conv2d_wino_supported(8, 32, 3, 1, 0) == 0 and L.aesr_conv2d_wino_supported(32, 48, 3, 1, 0) == 0
+    assert L.aesr_conv2d_wino_supported(32, 32, 1, 0, 0) == 0 and L.aesr_conv2d_wino_supported(32, 32, 3, 0, 0) == 0
+    x = torch.zeros(1, 4, 4, 8, device="cuda")
+    out = torch.zeros(1, 4, 4, 32, device="cuda")
+    rc = L.aesr_conv2d_wino_fwd(hip.ptr(x), hip.ptr(x), None, hip.ptr(out), 1, 4, 4, 8, 32, 0, 0.0, hip.stream())
+    assert rc != 0 and "Cin" in hip.last_error()
