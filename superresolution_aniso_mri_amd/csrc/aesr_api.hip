@@ -165,11 +165,72 @@ static std::map<std::tuple<int, int, int, int, int, int>, WgradPlan> g_wgrad_pla
 
 static int plane_stride(int n) { return round_up(n, 64) + 4; }    // = 4 (mod 64): 16 channel planes hit 16 distinct bank quads
 
-static WgradPlan plan_wgrad(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
+// Winograd F(2x2,3x3) weight gradient (conv_wgrad_wino.hip, variant 2): 3x3 / padding 1 with both channel counts multiples of 32.
+// One 4-wave workgroup per CU walks spatial tiles of TH x TW output pixels (TH even, TW a multiple of 8, within the register
+// prefetch slots); S splits x (ci, co) chunks ~ 256 workgroups.  AESR_WGRAD_WINO=0 keeps the direct kernels.
+static bool wgrad_wino_ok(int Cin, int Cout, int KS, int pad) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("AESR_WGRAD_WINO"); enabled = (e && atoi(e) == 0) ? 0 : 1; }
+    return enabled && KS == 3 && pad == 1 && Cin % 32 == 0 && Cout % 32 == 0;
+}
+
+static WgradPlan plan_wgrad_wino(int N, int H, int W, int Cin, int Cout) {
+    WgradPlan p;
+    p.variant = 2;
+    p.COT = 32;
+    p.CinP = Cin;
+    p.CoutP = Cout;
+    const int nchunks = (Cin / 32) * (Cout / 32);
+    int S = 256 / nchunks;
+    if (S >= 8) S &= ~7;                       // multiple of 8: XCD-aware workgroup order
+    if (S < 1) S = 1;
+    double best = 1e300;
+    p.TH = 4; p.TW = 32; p.S = S;
+    for (int TW = 8; TW <= 32; TW += 8) {
+        for (int TH = 2; TH <= 16; TH += 2) {
+            if ((TH + 2) * round_up(TW + 2, 4) * 8 > 256 * 12 || TH * TW * 8 > 256 * 8 || aesr_wgrad_wino_lds_bytes(TH, TW) > (size_t)160 * 1024) break;
+            const int ntiles = N * ceil_div(H, TH) * ceil_div(W, TW);
+            const int s = S < ntiles ? S : ntiles;
+            const double rounds = (double)ceil_div(ntiles, s);
+            const int nks = (TH / 2) * (TW / 8);
+            if (nks % 8 != 0) continue;             // an even number of k-steps per wave: the kernel's operand buffers keep fixed roles
+            // per visit: a wave's k-steps (64 MFMAs + both transforms, ~3200 cycles each at the clock this instruction mix
+            // holds) + DMA issue, the unpipelined first operands and the barrier (~2500); fitted to scripts/wgrad_wino_tiles.sh
+            const double t = rounds * (ceil_div(nks, 4) * 3200.0 + 2500.0);
+            if (t < best) { best = t; p.TH = TH; p.TW = TW; p.S = s; }
+        }
+    }
+    if (const char* e = getenv("AESR_WGRAD_WINO_TILE")) {     // experiment knob: "TH,TW"
+        int th = 0, tw = 0;
+        if (sscanf(e, "%d,%d", &th, &tw) == 2 && th > 0 && tw > 0 && tw % 8 == 0 && th % 2 == 0) {
+            p.TH = th; p.TW = tw;
+            const int ntiles = N * ceil_div(H, p.TH) * ceil_div(W, p.TW);
+            p.S = S < ntiles ? S : ntiles;
+        }
+    }
+    if (const char* e = getenv("AESR_WGRAD_WINO_S")) { const int s_ = atoi(e); if (s_ > 0) p.S = s_; }
+    p.PWS = round_up(p.TW + 2, 4);             // LDS row strides in pixels (conv_wgrad_wino.hip)
+    p.TWS = round_up(p.TW, 4);
+    p.PSX = p.PSD = 0;
+    p.nslab = p.S;
+    p.slab_floats = (size_t)p.nslab * 10 * p.CinP * p.CoutP;
+    if (getenv("AESR_PLAN_DEBUG"))
+        fprintf(stderr, "[plan_wgrad] wino N=%d %dx%d %d->%d: tile %dx%d S=%d tiles=%d\n", N, H, W, Cin, Cout, p.TH, p.TW, p.S,
+                N * ceil_div(H, p.TH) * ceil_div(W, p.TW));
+    return p;
+}
+
+static WgradPlan plan_wgrad(int N, int Ho, int Wo, int Cin, int Cout, int KS, int pad = -1) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
-    const auto key = std::make_tuple(N, Ho, Wo, Cin, Cout, KS);
+    const bool wino = wgrad_wino_ok(Cin, Cout, KS, pad);
+    const auto key = std::make_tuple(N, Ho, Wo, Cin, Cout, wino ? -KS : KS);
     auto it = g_wgrad_plans.find(key);
     if (it != g_wgrad_plans.end()) return it->second;
+    if (wino) {
+        const WgradPlan pw = plan_wgrad_wino(N, Ho, Wo, Cin, Cout);
+        g_wgrad_plans[key] = pw;
+        return pw;
+    }
     WgradPlan p;
     p.variant = Cout > 32 ? 1 : 0;
     p.COT = p.variant ? 64 : 32;
@@ -417,7 +478,7 @@ int aesr_conv2d_wino_dgrad(const float* dy, const float* upacked_t, const float*
 
 size_t aesr_conv2d_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int KS, int pad) {
     const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
-    return plan_wgrad(N, Ho, Wo, Cin, Cout, KS).slab_floats;
+    return plan_wgrad(N, Ho, Wo, Cin, Cout, KS, pad).slab_floats;
 }
 
 int aesr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W, int Cin,
@@ -426,14 +487,18 @@ int aesr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, flo
     AESR_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0, "aesr_conv2d_wgrad: Cin=%d, Cout=%d must be multiples of 4", Cin, Cout);
     AESR_CHECK_ARG((KS == 1 || KS == 3) && pad >= 0 && pad < KS, "aesr_conv2d_wgrad: unsupported KS=%d pad=%d", KS, pad);
     const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
-    const WgradPlan p = plan_wgrad(N, Ho, Wo, Cin, Cout, KS);
+    const WgradPlan p = plan_wgrad(N, Ho, Wo, Cin, Cout, KS, pad);
     WgradArgs a;
     a.x = x; a.dy = dy; a.slab = workspace;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = p.CinP; a.Cout = Cout; a.CoutP = p.CoutP; a.Ho = Ho; a.Wo = Wo; a.pad = pad;
     a.TH = p.TH; a.TW = p.TW; a.tiles_y = ceil_div(Ho, p.TH); a.tiles_x = ceil_div(Wo, p.TW);
     a.ntiles = N * a.tiles_y * a.tiles_x; a.S = p.S;
     a.PWS = p.PWS; a.TWS = p.TWS; a.PSX = p.PSX; a.PSD = p.PSD; a.dbgbuf = nullptr;
-    if (int e = aesr_launch_conv_wgrad(a, KS, p.variant, (hipStream_t)stream)) return e;
+    if (p.variant == 2) {
+        if (int e = aesr_launch_conv_wgrad_wino(a, (hipStream_t)stream)) return e;
+    } else if (int e = aesr_launch_conv_wgrad(a, KS, p.variant, (hipStream_t)stream)) {
+        return e;
+    }
     return aesr_launch_wgrad_reduce(workspace, dw, db, p.nslab, KS, Cin, p.CinP, Cout, p.CoutP, (hipStream_t)stream);
 }
 

@@ -47,6 +47,8 @@ struct WgradArgs {
     float* dbgbuf;            // debug phase stamps (AESR_WGRAD_DBG=1), nullptr in normal operation
 };
 int aesr_launch_conv_wgrad(const WgradArgs& a, int KS, int variant, hipStream_t st);
+int aesr_launch_conv_wgrad_wino(const WgradArgs& a, hipStream_t st);
+size_t aesr_wgrad_wino_lds_bytes(int TH, int TW);
 int aesr_launch_wgrad_reduce(const float* slab, float* dw, float* db, int nslab, int KS, int Cin, int CinP, int Cout, int CoutP, hipStream_t st);
 
 struct SmallArgs {

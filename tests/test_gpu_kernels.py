@@ -538,3 +538,30 @@ def test_conv_wino_argument_errors(hip):
     out = torch.zeros(1, 4, 4, 32, device="cuda")
     rc = L.aesr_conv2d_wino_fwd(hip.ptr(x), hip.ptr(x), None, hip.ptr(out), 1, 4, 4, 8, 32, 0, 0.0, hip.stream())
     assert rc != 0 and "Cin" in hip.last_error()
+
+
+@pytest.mark.parametrize("case", [(2, 162, 162, 32, 32), (3, 81, 81, 32, 64), (2, 40, 40, 128, 64), (5, 10, 10, 64, 64), (3, 7, 9, 32, 32),
+                                  (1, 1, 1, 32, 32), (2, 2, 3, 64, 96), (1, 33, 130, 32, 32)])
+def test_conv_wgrad_wino(hip, case):
+    """3x3 / padding-1 layers with both channel counts multiples of 32 take the Winograd weight-gradient kernel
+    (csrc/conv_wgrad_wino.hip) behind aesr_conv2d_wgrad: dW, db against fp64 (sums over up to 50k pixels: 2e-5)."""
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(5 + hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    ref_w = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), padding=1)
+    ref_b = dy.double().sum((0, 2, 3))
+    dw = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+    db = torch.full((Cout,), float("nan"), device="cuda")
+    ws = torch.empty(hip.lib.aesr_conv2d_wgrad_workspace_floats(N, H, W, Cin, Cout, 3, 1), device="cuda")
+    hip.check(hip.lib.aesr_conv2d_wgrad(hip.ptr(D(nhwc(x))), hip.ptr(D(nhwc(dy))), hip.ptr(dw), hip.ptr(db), hip.ptr(ws),
+                                        N, H, W, Cin, Cout, 3, 1, hip.stream()), "wgrad")
+    torch.cuda.synchronize()
+    assert rel_l2(dw, ref_w) < 2e-5
+    assert rel_l2(db, ref_b) < 2e-5
+    # twice the same call: bitwise identical (fixed-order slab reduction, no atomics)
+    dw2 = torch.empty_like(dw)
+    hip.check(hip.lib.aesr_conv2d_wgrad(hip.ptr(D(nhwc(x))), hip.ptr(D(nhwc(dy))), hip.ptr(dw2), hip.ptr(db), hip.ptr(ws),
+                                        N, H, W, Cin, Cout, 3, 1, hip.stream()), "wgrad")
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2)
