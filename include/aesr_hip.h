@@ -272,6 +272,20 @@ int aesr_conv2d_wino_fwd(const float* in, const float* upacked, const float* bia
 int aesr_conv2d_wino_dgrad(const float* dy, const float* upacked_t, const float* x_saved, float* dx, int N, int H, int W, int Cin,
                            int Cout, int mask_act, float slope, void* stream);
 
+/* nearest-neighbour Upsample(x2) in front of a 3x3 convolution (Decoder: networks/acai_vanilla.py:92-96) folded into the Winograd
+ * kernels: H, W are the convolution's (= the upsampled, even) size; `in_half` / `x_half` / `dx_half` are [N,H/2,W/2,C] tensors.  The
+ * forward and the weight gradient read pixel (y, x) at (y/2, x/2) of the half-resolution tensor (the upsampled tensor never
+ * exists); the data gradient stores the sum of every 2x2 block (the adjoint of the upsampling) -- no mask, the upsampled tensor
+ * is not an activation output.  aesr_conv2d_wgrad_up2 needs aesr_conv2d_wgrad_up2_supported (Cin, Cout multiples of 32); its
+ * workspace is that of aesr_conv2d_wgrad for the same N, H, W, Cin, Cout, KS = 3, pad = 1. */
+int aesr_conv2d_wino_fwd_up2(const float* in_half, const float* upacked, const float* bias, float* out, int N, int H, int W, int Cin,
+                             int Cout, int act, float slope, void* stream);
+int aesr_conv2d_wino_dgrad_sum2(const float* dy, const float* upacked_t, float* dx_half, int N, int H, int W, int Cin, int Cout,
+                                void* stream);
+int aesr_conv2d_wgrad_up2_supported(int Cin, int Cout);
+int aesr_conv2d_wgrad_up2(const float* x_half, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W, int Cin,
+                          int Cout, void* stream);
+
 /* ---- data-parallel collectives: an RCCL communicator owned by the library (one process per GPU; new functionality -- the
  * reference's only multi-GPU code moves the loss to 'cuda:1', kwatsch/trainer_ae.py:43-44,84-86) --------------------------------
  * Collectives are plain enqueues on the caller's stream (capturable into a HIP graph; no watchdog thread, unlike

@@ -98,6 +98,10 @@ SIGNATURES = {
     "aesr_conv2d_wino_pack_many": (c_int, [ctypes.POINTER(PackJob), c_int, P]),
     "aesr_conv2d_wino_fwd": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),
     "aesr_conv2d_wino_dgrad": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),
+    "aesr_conv2d_wino_fwd_up2": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),
+    "aesr_conv2d_wino_dgrad_sum2": (c_int, [P, P, P] + [c_int] * 5 + [P]),
+    "aesr_conv2d_wgrad_up2_supported": (c_int, [c_int, c_int]),
+    "aesr_conv2d_wgrad_up2": (c_int, [P, P, P, P, P] + [c_int] * 5 + [P]),
     "aesr_comm_rccl_version": (c_int, [IP]),
     "aesr_comm_unique_id": (c_int, [c_char_p]),
     "aesr_comm_init": (c_int, [c_char_p, c_int, c_int, ctypes.POINTER(c_void_p)]),

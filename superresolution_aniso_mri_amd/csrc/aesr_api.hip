@@ -451,13 +451,13 @@ int aesr_conv2d_wino_pack_many(const aesr_pack_job* jobs_host, int njobs, void* 
 }
 
 static int run_wino(const float* in, const float* upk, const float* bias, const float* ysave, float* out, int N, int H, int W,
-                    int Cin, int Cout, int act, int mask_act, float slope, hipStream_t st) {
+                    int Cin, int Cout, int act, int mask_act, float slope, hipStream_t st, int in_up2 = 0, int out_sum2 = 0) {
     const WinoPlan p = plan_wino(N, H, W, Cin, Cout);
     WinoArgs a;
     a.in = in; a.upk = upk; a.bias = bias; a.ysave = ysave; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = p.CinP; a.Cout = Cout; a.CoutP = p.CoutP;
     a.TI = p.TI; a.THt = p.THt; a.TWt = p.TWt; a.regs_y = a.regs_x = a.nitems = 0;
-    a.act = act; a.mask_act = mask_act; a.slope = slope; a.dbgbuf = nullptr; a.flags = 0;
+    a.act = act; a.mask_act = mask_act; a.slope = slope; a.dbgbuf = nullptr; a.flags = 0; a.in_up2 = in_up2; a.out_sum2 = out_sum2;
     return aesr_launch_conv_wino(a, st);
 }
 
@@ -476,13 +476,45 @@ int aesr_conv2d_wino_dgrad(const float* dy, const float* upacked_t, const float*
     return run_wino(dy, upacked_t, nullptr, x_saved, dx, N, H, W, Cout, Cin, ACT_NONE, mask_act, slope, (hipStream_t)stream);
 }
 
+/* nearest Upsample(x2) in front of the convolution folded into the kernels (H, W = the convolution's = upsampled size, even) */
+int aesr_conv2d_wino_fwd_up2(const float* in_half, const float* upacked, const float* bias, float* out, int N, int H, int W, int Cin,
+                             int Cout, int act, float slope, void* stream) {
+    AESR_CHECK_ARG(in_half && upacked && out && N > 0 && H > 0 && W > 0 && !((H | W) & 1), "aesr_conv2d_wino_fwd_up2: null pointer, empty or odd shape");
+    AESR_CHECK_ARG(aesr_conv2d_wino_supported(Cin, Cout, 3, 1, 0), "aesr_conv2d_wino_fwd_up2: needs Cin %% 16 == 0 and Cout %% 32 == 0 (got %d -> %d)", Cin, Cout);
+    return run_wino(in_half, upacked, bias, nullptr, out, N, H, W, Cin, Cout, act, ACT_NONE, slope, (hipStream_t)stream, 1, 0);
+}
+
+int aesr_conv2d_wino_dgrad_sum2(const float* dy, const float* upacked_t, float* dx_half, int N, int H, int W, int Cin, int Cout,
+                                void* stream) {
+    AESR_CHECK_ARG(dy && upacked_t && dx_half && N > 0 && H > 0 && W > 0 && !((H | W) & 1), "aesr_conv2d_wino_dgrad_sum2: null pointer, empty or odd shape");
+    AESR_CHECK_ARG(aesr_conv2d_wino_supported(Cin, Cout, 3, 1, 1), "aesr_conv2d_wino_dgrad_sum2: needs Cout %% 16 == 0 and Cin %% 32 == 0 (got %d -> %d)", Cin, Cout);
+    return run_wino(dy, upacked_t, nullptr, nullptr, dx_half, N, H, W, Cout, Cin, ACT_NONE, ACT_NONE, 0.f, (hipStream_t)stream, 0, 1);
+}
+
 size_t aesr_conv2d_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int KS, int pad) {
     const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
     return plan_wgrad(N, Ho, Wo, Cin, Cout, KS, pad).slab_floats;
 }
 
+static int wgrad_impl(const float* x, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W, int Cin,
+                      int Cout, int KS, int pad, void* stream, int x_up2);
+
 int aesr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W, int Cin,
                       int Cout, int KS, int pad, void* stream) {
+    return wgrad_impl(x, dy, dw, db, workspace, N, H, W, Cin, Cout, KS, pad, stream, 0);
+}
+
+int aesr_conv2d_wgrad_up2_supported(int Cin, int Cout) { return wgrad_wino_ok(Cin, Cout, 3, 1) ? 1 : 0; }
+
+int aesr_conv2d_wgrad_up2(const float* x_half, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W, int Cin,
+                          int Cout, void* stream) {
+    AESR_CHECK_ARG(wgrad_wino_ok(Cin, Cout, 3, 1) && !((H | W) & 1), "aesr_conv2d_wgrad_up2: needs the Winograd weight-gradient kernel "
+                   "(Cin, Cout multiples of 32; got %d -> %d) and an even size", Cin, Cout);
+    return wgrad_impl(x_half, dy, dw, db, workspace, N, H, W, Cin, Cout, 3, 1, stream, 1);
+}
+
+static int wgrad_impl(const float* x, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W, int Cin,
+                      int Cout, int KS, int pad, void* stream, int x_up2) {
     AESR_CHECK_ARG(x && dy && dw && workspace && N > 0, "aesr_conv2d_wgrad: null pointer or empty shape");
     AESR_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0, "aesr_conv2d_wgrad: Cin=%d, Cout=%d must be multiples of 4", Cin, Cout);
     AESR_CHECK_ARG((KS == 1 || KS == 3) && pad >= 0 && pad < KS, "aesr_conv2d_wgrad: unsupported KS=%d pad=%d", KS, pad);
@@ -493,7 +525,7 @@ int aesr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, flo
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = p.CinP; a.Cout = Cout; a.CoutP = p.CoutP; a.Ho = Ho; a.Wo = Wo; a.pad = pad;
     a.TH = p.TH; a.TW = p.TW; a.tiles_y = ceil_div(Ho, p.TH); a.tiles_x = ceil_div(Wo, p.TW);
     a.ntiles = N * a.tiles_y * a.tiles_x; a.S = p.S;
-    a.PWS = p.PWS; a.TWS = p.TWS; a.PSX = p.PSX; a.PSD = p.PSD; a.dbgbuf = nullptr;
+    a.PWS = p.PWS; a.TWS = p.TWS; a.PSX = p.PSX; a.PSD = p.PSD; a.dbgbuf = nullptr; a.x_up2 = x_up2;
     if (p.variant == 2) {
         if (int e = aesr_launch_conv_wgrad_wino(a, (hipStream_t)stream)) return e;
     } else if (int e = aesr_launch_conv_wgrad(a, KS, p.variant, (hipStream_t)stream)) {

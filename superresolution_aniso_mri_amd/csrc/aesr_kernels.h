@@ -28,6 +28,8 @@ struct WinoArgs {
     float slope;
     float* dbgbuf;               // per-wave phase stamps (AESR_WINO_DBG=1), nullptr in normal operation
     int flags;                   // experiment switches (AESR_WINO_FLAGS)
+    int in_up2;                  // the input is stored at half resolution: pixel (y, x) reads (y/2, x/2) (nearest Upsample x2 folded in)
+    int out_sum2;                // store the sum of every 2x2 output tile at half resolution (adjoint of that Upsample)
 };
 int aesr_launch_conv_wino(const WinoArgs& a, hipStream_t st);
 size_t aesr_wino_lds_bytes(int patch_pixels);
@@ -45,6 +47,7 @@ struct WgradArgs {
     int S;
     int PWS, TWS, PSX, PSD;   // LDS row / plane strides in floats (even; planes = 4 mod 64)
     float* dbgbuf;            // debug phase stamps (AESR_WGRAD_DBG=1), nullptr in normal operation
+    int x_up2;                // Winograd kernel only: x is stored at half resolution (nearest Upsample x2 folded into the loader)
 };
 int aesr_launch_conv_wgrad(const WgradArgs& a, int KS, int variant, hipStream_t st);
 int aesr_launch_conv_wgrad_wino(const WgradArgs& a, hipStream_t st);

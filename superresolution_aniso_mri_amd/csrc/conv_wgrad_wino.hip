@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
     const int tpi = a.tiles_y * a.tiles_x;
 
     // ---- DMA pieces: piece m = tid + 256 k fills LDS float4 slot m = (pixel m >> 3, position m & 7) of the buffer ----
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 4), 0x00020000);
+    const int xH = a.x_up2 ? a.H >> 1 : a.H, xW = a.x_up2 ? a.W >> 1 : a.W;          // stored size of x (nearest Upsample x2 folded in: pixel (y, x) <- (y/2, x/2))
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.N * xH * xW * a.Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
     int xrc[WW_NX], drc[WW_ND], xrel[WW_NX], drel[WW_ND];      // (row << 16 | col) or -1; byte offset relative to the tile origin or OOB
     const int pos = tid & 7;
@@ -103,7 +104,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
         for (int k = 0; k < WW_NX; ++k) {
             if (k < npx) {
                 const unsigned gy = (unsigned)(y0 + (xrc[k] >> 16) - 1), gx = (unsigned)(x0 + (xrc[k] & 0xffff) - 1);
-                const int off = (xrc[k] >= 0 && gy < (unsigned)a.H && gx < (unsigned)a.W) ? xorg + xrel[k] : WW_OOB;
+                int off = (xrc[k] >= 0 && gy < (unsigned)a.H && gx < (unsigned)a.W) ? xorg + xrel[k] : WW_OOB;
+                if (a.x_up2 && off != WW_OOB && xrel[k] != WW_OOB) {
+                    const int q = pos ^ ((((xrc[k] & 0xffff) >> 1) & 1) << 2);
+                    off = (((n * xH + (int)(gy >> 1)) * xW + (int)(gx >> 1)) * a.Cin + ci0 + q * 4) * 4;
+                }
                 ww_dma(rs_x, xdst + k * 1024, off);
             }
         }
@@ -328,6 +333,10 @@ int aesr_launch_conv_wgrad_wino(const WgradArgs& a, hipStream_t st) {
     if ((size_t)a.N * a.H * a.W * a.Cin >= (size_t)0x1C000000 || (size_t)a.N * a.H * a.W * a.Cout >= (size_t)0x1C000000) {
         aesr_set_error("conv_wgrad_wino: tensors of 469M elements (1.75 GB) or more need 64-bit indexing (not built)");
         return AESR_ERR_UNSUPPORTED;
+    }
+    if (a.x_up2 && ((a.H | a.W) & 1)) {
+        aesr_set_error("conv_wgrad_wino: the folded Upsample(x2) needs even convolution sizes (got %dx%d)", a.H, a.W);
+        return AESR_ERR_ARG;
     }
     if (a.TW % 8 != 0 || a.TH % 2 != 0 || a.PWS != round_up(a.TW + 2, 4) || a.TWS != round_up(a.TW, 4) || a.pad != 1 || a.Ho != a.H || a.Wo != a.W) {
         aesr_set_error("conv_wgrad_wino: TW=%d must be a multiple of 8, TH=%d even, row strides multiples of 4, 3x3 padding 1", a.TW, a.TH);

@@ -23,6 +23,9 @@
 //    ~8200 LDS cycles per chunk).  Out-of-range buffer offsets deliver zeros: halo, padding and tails need no masking.
 //  * the bias rides in the accumulator of position (1,1), whose value reaches all four outputs of the tile with weight +1.
 //  * the same kernel is the data gradient (run on dY with U of the flipped / transposed filter, derivative mask in the epilogue).
+//  * nearest-neighbour Upsample(x2) in front of the convolution (networks/acai_vanilla.py:92) is folded in: with `in_up2` the DMA
+//    source of patch pixel (y, x) is pixel (y/2, x/2) of the half-resolution tensor -- the upsampled tensor never exists; its
+//    adjoint in the data gradient (`out_sum2`) is the sum of the lane's 2x2 output tile, stored as ONE half-resolution pixel.
 //
 // Accuracy: products and sums are fp32 (exact-fp32 MFMA); the transforms add a few roundings (G has entries 1/2: exact).
 // Measured against fp64: 2-4e-7 relative (tests/test_gpu_kernels.py::test_conv_wino_*), inside the stated 1e-5 forward bound.
@@ -74,9 +77,11 @@ __global__ __launch_bounds__(WN_NT, 2) void conv_wino_f32(WinoArgs a) {
     float* const ldsBias = ldsW0 + 2 * WN_WFL;           // [CoutP] (zeros when there is no bias)
     for (int c = tid; c < a.CoutP; c += WN_NT) ldsBias[c] = (a.bias && c < a.Cout) ? a.bias[c] : 0.f;
 
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 4), 0x00020000);
+    const int inH = a.in_up2 ? a.H >> 1 : a.H, inW = a.in_up2 ? a.W >> 1 : a.W;            // stored size of the input tensor
+    const int outH = a.out_sum2 ? a.H >> 1 : a.H, outW = a.out_sum2 ? a.W >> 1 : a.W;      // stored size of the output tensor
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * inH * inW * a.Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.upk, 0, (int)((size_t)16 * a.CinP * a.CoutP * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)((size_t)a.N * outH * outW * a.Cout * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_ys = __builtin_amdgcn_make_buffer_rsrc((void*)(MASK ? a.ysave : a.out), 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
 
     // ---- position-independent maps (computed once) ------------------------------------------------------------
@@ -134,7 +139,8 @@ __global__ __launch_bounds__(WN_NT, 2) void conv_wino_f32(WinoArgs a) {
             if (piece[j] >= 0) {                                                                                  \
                 const int n = n0_ + (piece[j] >> 20), gy = 2 * ty0_ + ((piece[j] >> 10) & 1023) - 1;              \
                 const int gx = 2 * tx0_ + (piece[j] & 1023) - 1;                                                  \
-                go = (n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (((n * a.H + gy) * a.W + gx) * a.Cin + part4) * 4 : WN_OOB; \
+                const int sy = a.in_up2 ? gy >> 1 : gy, sx = a.in_up2 ? gx >> 1 : gx;                             \
+                go = (n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (((n * inH + sy) * inW + sx) * a.Cin + part4) * 4 : WN_OOB; \
             }                                                                                                     \
             goff[j] = go;                                                                                         \
         }                                                                                                         \
@@ -304,6 +310,14 @@ __global__ __launch_bounds__(WN_NT, 2) void conv_wino_f32(WinoArgs a) {
                 for (int j = 0; j < 4; ++j) {
                     P[0][j] = acc[0 + j][nb] + acc[4 + j][nb] + acc[8 + j][nb];
                     P[1][j] = acc[4 + j][nb] - acc[8 + j][nb] - acc[12 + j][nb];
+                }
+                if (a.out_sum2) {
+                    // adjoint of the nearest Upsample(x2) in front of this layer's forward: the 2x2 tile collapses to one pixel
+                    // (the sum of A^T M A over its four entries = the corner combination below); no activation, no mask
+                    const f32x4 s = (P[0][0] + P[1][0]) + 2.f * (P[0][1] + P[1][1]) - (P[0][3] + P[1][3]);
+                    const int obs = (okn && y0 < a.H && x0 < a.W) ? ((n * outH + (y0 >> 1)) * outW + (x0 >> 1)) * a.Cout * 4 : WN_OOB;
+                    wn_st(rs_out, obs + cob, s);
+                    continue;
                 }
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
@@ -494,6 +508,14 @@ int aesr_launch_conv_wino(const WinoArgs& a_in, hipStream_t st) {
     if (a.ysave && a.mask_act == ACT_SIGMOID) {
         aesr_set_error("conv_wino: a sigmoid derivative mask is not fused into the data gradient (use aesr_act_bwd)");
         return AESR_ERR_UNSUPPORTED;
+    }
+    if ((a.in_up2 || a.out_sum2) && ((a.H | a.W) & 1)) {
+        aesr_set_error("conv_wino: the folded Upsample(x2) needs even convolution sizes (got %dx%d)", a.H, a.W);
+        return AESR_ERR_ARG;
+    }
+    if (a.out_sum2 && (a.ysave || a.act != ACT_NONE || a.bias)) {
+        aesr_set_error("conv_wino: the 2x2-summing epilogue takes no bias, activation or derivative mask");
+        return AESR_ERR_ARG;
     }
     if (2 * a.THt + 2 > 1023 || 2 * a.TWt + 2 > 1023 || a.TI > 1023) {
         aesr_set_error("conv_wino: tile dimensions exceed the packed-coordinate range");

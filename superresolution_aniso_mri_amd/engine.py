@@ -57,6 +57,7 @@ FUSE_STEM = os.environ.get("AESR_FUSE_STEM", "1") != "0"      # fold the encoder
 # 3x3 / padding-1 convolutions with enough channels run in Winograd F(2x2,3x3) form (csrc/conv_wino.hip: 2.25x fewer MFMA flops,
 # results equal to the implicit GEMM within 2-4e-7); AESR_WINO=0 keeps every layer on the exact-fp32 fma-chain implicit GEMM
 USE_WINO = os.environ.get("AESR_WINO", "1") != "0"
+FOLD_UPSAMPLE = os.environ.get("AESR_FOLD_UPSAMPLE", "1") != "0"
 
 
 def wino_ok(cin, cout, ks, pad, transpose):
@@ -108,6 +109,7 @@ class ConvStep:
         self.packed_epoch = -1
         self.wino_fwd = (not self.s2d) and wino_ok(self.cin, self.cout, self.ks, self.pad, 0)
         self.wino_dgrad = (not self.s2d) and wino_ok(self.cin, self.cout, self.ks, self.pad, 1)
+        self.in_up2 = False     # the nearest Upsample(x2) in front of this convolution is folded into its kernels (compile_steps)
 
     @property
     def mfma_fwd(self):
@@ -167,8 +169,15 @@ class BnStep:
 
     def __init__(self, mod, mode):
         self.mod, self.mode, self.c = mod, mode, mod.num_features
+        self.fold_up = False    # mode BN_UP whose upsampling the next convolution does in its loaders: apply at the input size
+
+    @property
+    def run_mode(self):
+        return _hip.BN_NONE if self.fold_up else self.mode
 
     def out_hw(self, h, w):
+        if self.fold_up:
+            return h, w
         if self.mode == _hip.BN_POOL:
             return h // 2, w // 2
         if self.mode == _hip.BN_UP:
@@ -234,6 +243,14 @@ def compile_steps(seq):
             raise NotImplementedError("no HIP lowering for %r at position %d (use_batchnorm=False stacks are not "
                                       "covered)" % (m, i))
         i += 1
+    # nearest Upsample(x2) between a BatchNorm and a 3x3 convolution is folded into that convolution's Winograd kernels (forward
+    # and weight-gradient loaders read (y/2, x/2) of the half-resolution tensor, the data gradient stores 2x2 block sums): the
+    # upsampled tensor and its gradient never exist (aesr_conv2d_wino_fwd_up2 / _dgrad_sum2, aesr_conv2d_wgrad_up2)
+    for k, s in enumerate(steps[:-1]):
+        nxt = steps[k + 1]
+        if (FOLD_UPSAMPLE and s.kind == "bn" and s.mode == _hip.BN_UP and nxt.kind == "conv" and nxt.wino_fwd and nxt.wino_dgrad
+                and lib.aesr_conv2d_wgrad_up2_supported(nxt.cin, nxt.cout)):
+            s.fold_up, nxt.in_up2 = True, True
     for k, s in enumerate(steps):
         if s.kind == "bn" and (k == 0 or steps[k - 1].kind != "conv"):
             raise NotImplementedError("BatchNorm must follow a convolution")
@@ -344,10 +361,17 @@ class SequentialRunner:
                     cur, H, W, C = xs, H // 2, W // 2, 4 * C
                 if C != s.cin:
                     raise RuntimeError("channel mismatch: tensor has %d channels, conv expects %d" % (C, s.cin))
+                if s.in_up2:
+                    H, W = 2 * H, 2 * W                    # the convolution's size; ``cur`` stays at half resolution
                 Ho, Wo = (H, W) if s.s2d else s.out_hw(H, W)
                 out = _empty((N, Ho, Wo, s.cout), x)
                 bias = s.mod.bias
-                if s.cout == 1 and s.ks == 3 and s.pad == 1 and s.cin % 4 == 0:
+                if s.in_up2:
+                    _pb("conv_wino_f32", 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
+                    check(lib.aesr_conv2d_wino_fwd_up2(ptr(cur), ptr(s.packed_w), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, s.act,
+                                                       s.slope, stream()), "aesr_conv2d_wino_fwd_up2")
+                    _pe()
+                elif s.cout == 1 and s.ks == 3 and s.pad == 1 and s.cin % 4 == 0:
                     check(lib.aesr_conv2d_cout1_fwd(ptr(cur), ptr(s.mod.weight), ptr(bias), ptr(out), N, H, W, s.cin, s.act,
                                                     s.slope, stream()), "aesr_conv2d_cout1_fwd")
                 elif s.wino_fwd:
@@ -385,7 +409,7 @@ class SequentialRunner:
                 st = self._bn_forward_stats(bn, cur, N, H, W, C, nstart, train)
                 Ho, Wo = s.out_hw(H, W)
                 out = _empty((N, Ho, Wo, C), x)
-                check(lib.aesr_bn_apply(ptr(cur), ptr(st["scale"]), ptr(st["shift"]), ptr(out), N, H, W, C, s.mode, G,
+                check(lib.aesr_bn_apply(ptr(cur), ptr(st["scale"]), ptr(st["shift"]), ptr(out), N, H, W, C, s.run_mode, G,
                                         _hip.int_array(nstart), stream()), "aesr_bn_apply")
                 if save:
                     saved.append((cur, st))
@@ -472,6 +496,8 @@ class SequentialRunner:
                 xin, yout = saved[k][0], saved[k][1]
                 N, H, W, _ = xin.shape
                 N = ngrad
+                if s.in_up2:
+                    H, W = 2 * H, 2 * W                    # the convolution's size; xin is the half-resolution tensor
                 Ho, Wo = (H, W) if s.s2d else s.out_hw(H, W)
                 if k == len(steps) - 1 and s.act != _hip.ACT_NONE:
                     dpre = torch.empty_like(g)
@@ -485,8 +511,12 @@ class SequentialRunner:
                     nws = lib.aesr_conv2d_wgrad_workspace_floats(N, H, W, s.cin, s.cout, s.ks, s.pad)
                     ws = _empty((nws,), g)
                     _pb("conv_wgrad_f32", 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
-                    check(lib.aesr_conv2d_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout, s.ks,
-                                                s.pad, stream()), "aesr_conv2d_wgrad")
+                    if s.in_up2:
+                        check(lib.aesr_conv2d_wgrad_up2(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout, stream()),
+                              "aesr_conv2d_wgrad_up2")
+                    else:
+                        check(lib.aesr_conv2d_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout, s.ks,
+                                                    s.pad, stream()), "aesr_conv2d_wgrad")
                     _pe()
                 elif s.cin <= 4 and s.ks == 1 and db is not None:
                     ws = _empty((lib.aesr_small_wgrad_workspace_floats(s.cout * (s.cin + 1)),), g)
@@ -509,8 +539,15 @@ class SequentialRunner:
                     mask, mask_act, mslope = saved[k - 1][1], steps[k - 1].act, steps[k - 1].slope
                     if mask_act == _hip.ACT_NONE:
                         mask = None
-                dx = _empty((N, H, W, s.cin), g)
-                if s.cin <= 4 and mask is None:
+                dx = _empty((N, H // 2, W // 2, s.cin) if s.in_up2 else (N, H, W, s.cin), g)
+                if s.in_up2:
+                    # adjoint of the folded upsampling: 2x2 block sums of the data gradient, at half resolution (no mask: the
+                    # producer is a BatchNorm)
+                    _pb("conv_wino_f32", 2.0 * N * H * W * s.cin * 9 * s.cout)
+                    check(lib.aesr_conv2d_wino_dgrad_sum2(ptr(g), ptr(s.packed_wt), ptr(dx), N, H, W, s.cin, s.cout, stream()),
+                          "aesr_conv2d_wino_dgrad_sum2")
+                    _pe()
+                elif s.cin <= 4 and mask is None:
                     check(lib.aesr_conv2d_smallcin_dgrad(ptr(g), ptr(s.mod.weight), ptr(dx), N, H, W, s.cin, s.cout, s.ks,
                                                          s.pad, 0, None, stream()), "aesr_conv2d_smallcin_dgrad")
                 elif s.wino_dgrad:
@@ -567,15 +604,15 @@ class SequentialRunner:
                 if self.sync_bn is None:
                     check(lib.aesr_bn_bwd(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(partial),
                                           _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dpre), N, H, W,
-                                          C, s.mode, prev.act, prev.slope, G, nsa, stream()), "aesr_bn_bwd")
+                                          C, s.run_mode, prev.act, prev.slope, G, nsa, stream()), "aesr_bn_bwd")
                 else:
                     sums = torch.empty((G, 2, C), device=dev, dtype=torch.float64)
                     check(lib.aesr_bn_bwd_reduce(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(partial), ptr(sums), N,
-                                                 H, W, C, s.mode, G, nsa, stream()), "aesr_bn_bwd_reduce")
+                                                 H, W, C, s.run_mode, G, nsa, stream()), "aesr_bn_bwd_reduce")
                     self.sync_bn(sums)
                     check(lib.aesr_bn_bwd_apply(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(sums),
                                                 _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dpre),
-                                                N, H, W, C, s.mode, prev.act, prev.slope, G, nsa, stream()), "aesr_bn_bwd_apply")
+                                                N, H, W, C, s.run_mode, prev.act, prev.slope, G, nsa, stream()), "aesr_bn_bwd_apply")
                 g = dpre
         return g, grads
 

@@ -565,3 +565,41 @@ def test_conv_wgrad_wino(hip, case):
                                         N, H, W, Cin, Cout, 3, 1, hip.stream()), "wgrad")
     torch.cuda.synchronize()
     assert torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize("case", [(3, 80, 80, 64, 32), (2, 160, 160, 32, 32), (2, 6, 10, 32, 64), (1, 2, 2, 32, 32)])
+def test_conv_wino_folded_upsample(hip, case):
+    """nearest Upsample(x2) in front of a 3x3 convolution folded into the Winograd kernels (Decoder, networks/acai_vanilla.py:92-96):
+    forward and weight gradient read the half-resolution tensor through (y/2, x/2); the data gradient stores the 2x2 block sums."""
+    N, H, W, Cin, Cout = case              # H, W: the convolution's (upsampled) size
+    L = hip.lib
+    assert L.aesr_conv2d_wgrad_up2_supported(Cin, Cout) == 1
+    g = torch.Generator().manual_seed(H + Cin)
+    xh = torch.randn(N, Cin, H // 2, W // 2, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g, dtype=torch.float64) / np.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g, dtype=torch.float64)
+    dy = torch.randn(N, Cout, H, W, generator=g, dtype=torch.float64)
+    xh.requires_grad_(True)
+    w.requires_grad_(True)
+    b.requires_grad_(True)
+    xu = F.interpolate(xh, scale_factor=2, mode="nearest")
+    ref = F.leaky_relu(F.conv2d(xu, w, b, padding=1), 0.01)
+    pre = F.conv2d(xu, w, b, padding=1)
+    pre.backward(dy)                          # gradients of the un-activated convolution wrt the half-resolution input / filter
+    xd, wd, bd, dyd = D(nhwc(xh.detach().float())), D(w.detach().float()), D(b.detach().float()), D(nhwc(dy.float()))
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    hip.check(L.aesr_conv2d_wino_fwd_up2(hip.ptr(xd), hip.ptr(D(_pack_wino(hip, wd, 0))), hip.ptr(bd), hip.ptr(out), N, H, W, Cin, Cout, 1,
+                                         0.01, hip.stream()), "wino_fwd_up2")
+    dxh = torch.full((N, H // 2, W // 2, Cin), float("nan"), device="cuda")
+    hip.check(L.aesr_conv2d_wino_dgrad_sum2(hip.ptr(dyd), hip.ptr(D(_pack_wino(hip, wd, 1))), hip.ptr(dxh), N, H, W, Cin, Cout, hip.stream()),
+              "wino_dgrad_sum2")
+    dw = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+    db = torch.full((Cout,), float("nan"), device="cuda")
+    ws = torch.empty(L.aesr_conv2d_wgrad_workspace_floats(N, H, W, Cin, Cout, 3, 1), device="cuda")
+    hip.check(L.aesr_conv2d_wgrad_up2(hip.ptr(xd), hip.ptr(dyd), hip.ptr(dw), hip.ptr(db), hip.ptr(ws), N, H, W, Cin, Cout, hip.stream()),
+              "wgrad_up2")
+    torch.cuda.synchronize()
+    assert rel_l2(nchw(out), ref.detach()) < 1e-5
+    assert rel_l2(nchw(dxh), xh.grad) < 1e-5
+    assert rel_l2(dw, w.grad) < 2e-5
+    assert rel_l2(db, b.grad) < 2e-5
