@@ -239,8 +239,8 @@ __global__ __launch_bounds__(WN_NT, 2) void conv_wino_f32(WinoArgs a) {
                     // software pipeline, pinned with sched_barrier: the weight fragments and the transformed operand of position
                     // xi + 1 are produced BEFORE the 8 MFMAs of position xi (left alone, the scheduler sinks the LDS reads to
                     // just before their first use); inside the two groups the compiler's own order is kept (a fully
-                    // hand-interleaved order pinned per MFMA measured 25 % slower, a
-                    // sched_group_barrier deal-out 2 % slower)
+                    // hand-interleaved order pinned per MFMA and a
+                    // sched_group_barrier deal-out both measured 0-3 % slower: profiles/r02_wino_experiments.txt)
                     f32x4 wc[WN_NB];
 #pragma unroll
                     for (int nb = 0; nb < WN_NB; ++nb) wc[nb] = wnx[nb];

@@ -89,7 +89,10 @@ def test_three_train_steps(tag):
         # bulk: within a fifth of one Adam step (LPIPS as the reconstruction loss has more near-zero gradients whose sign is noise)
         assert (diff > 0.2 * lr + 1e-3 * np.abs(b)).sum() <= max(1, (0.10 if tag == "cardiac_percept" else 0.03) * diff.size), k
         if "running" in k:                                                     # BatchNorm statistics: momentum / unbiased-var details
-            np.testing.assert_allclose(a, b, rtol=2e-3 if lr > 1e-4 else 2e-5, atol=1e-2 * lr + 1e-7, err_msg=k)
+            # (at lr 1e-3 the trajectories separate through Adam's sign noise, most with LPIPS as the reconstruction loss; the
+            # lr 1e-5 fixture pins momentum / unbiased-variance details at 2e-5)
+            np.testing.assert_allclose(a, b, rtol=(1e-2 if tag == "cardiac_percept" else 2e-3) if lr > 1e-4 else 2e-5, atol=1e-2 * lr + 1e-7,
+                                       err_msg=k)
 
 
 def test_loss_annealing_under_the_step_graph():
