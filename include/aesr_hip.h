@@ -286,6 +286,20 @@ int aesr_conv2d_wgrad_up2_supported(int Cin, int Cout);
 int aesr_conv2d_wgrad_up2(const float* x_half, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W, int Cin,
                           int Cout, void* stream);
 
+/* Weight gradients of a whole backward pass with ONE reduction launch: aesr_conv2d_wgrad_partial writes only the partial slabs of
+ * a layer into its workspace (same planner, same workspace size as aesr_conv2d_wgrad; x_up2 as aesr_conv2d_wgrad_up2), and
+ * aesr_conv2d_wgrad_reduce_many sums the slabs of up to 16 layers per launch in the fixed order of aesr_conv2d_wgrad (bitwise the
+ * same results).  The job array is read on the host during the call. */
+typedef struct aesr_wgrad_reduce_job {
+    const float* workspace;
+    float* dw;
+    float* db;       /* may be NULL */
+    int N, H, W, Cin, Cout, KS, pad;
+} aesr_wgrad_reduce_job;
+int aesr_conv2d_wgrad_partial(const float* x, const float* dy, float* workspace, int N, int H, int W, int Cin, int Cout, int KS,
+                              int pad, int x_up2, void* stream);
+int aesr_conv2d_wgrad_reduce_many(const aesr_wgrad_reduce_job* jobs_host, int njobs, void* stream);
+
 /* ---- data-parallel collectives: an RCCL communicator owned by the library (one process per GPU; new functionality -- the
  * reference's only multi-GPU code moves the loss to 'cuda:1', kwatsch/trainer_ae.py:43-44,84-86) --------------------------------
  * Collectives are plain enqueues on the caller's stream (capturable into a HIP graph; no watchdog thread, unlike

@@ -24,6 +24,12 @@ class TripletDesc(ctypes.Structure):
                 ("oy", c_int), ("ox", c_int), ("k", c_int), ("gain", c_float), ("cutoff", c_float)]
 
 
+class WgradReduceJob(ctypes.Structure):
+    """aesr_wgrad_reduce_job of include/aesr_hip.h"""
+    _fields_ = [("workspace", c_void_p), ("dw", c_void_p), ("db", c_void_p), ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int),
+                ("Cout", c_int), ("KS", c_int), ("pad", c_int)]
+
+
 class PackJob(ctypes.Structure):
     """aesr_pack_job of include/aesr_hip.h"""
     _fields_ = [("w", c_void_p), ("packed", c_void_p), ("Cout", c_int), ("Cin", c_int), ("KS", c_int), ("transpose", c_int)]
@@ -102,6 +108,8 @@ SIGNATURES = {
     "aesr_conv2d_wino_dgrad_sum2": (c_int, [P, P, P] + [c_int] * 5 + [P]),
     "aesr_conv2d_wgrad_up2_supported": (c_int, [c_int, c_int]),
     "aesr_conv2d_wgrad_up2": (c_int, [P, P, P, P, P] + [c_int] * 5 + [P]),
+    "aesr_conv2d_wgrad_partial": (c_int, [P, P, P] + [c_int] * 8 + [P]),
+    "aesr_conv2d_wgrad_reduce_many": (c_int, [ctypes.POINTER(WgradReduceJob), c_int, P]),
     "aesr_comm_rccl_version": (c_int, [IP]),
     "aesr_comm_unique_id": (c_int, [c_char_p]),
     "aesr_comm_init": (c_int, [c_char_p, c_int, c_int, ctypes.POINTER(c_void_p)]),

@@ -504,6 +504,36 @@ int aesr_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, flo
     return wgrad_impl(x, dy, dw, db, workspace, N, H, W, Cin, Cout, KS, pad, stream, 0);
 }
 
+int aesr_conv2d_wgrad_partial(const float* x, const float* dy, float* workspace, int N, int H, int W, int Cin, int Cout, int KS,
+                              int pad, int x_up2, void* stream) {
+    AESR_CHECK_ARG(!x_up2 || (wgrad_wino_ok(Cin, Cout, KS, pad) && !((H | W) & 1)), "aesr_conv2d_wgrad_partial: the folded upsampling needs "
+                   "the Winograd weight-gradient kernel (3x3, padding 1, Cin, Cout multiples of 32) and an even size");
+    return wgrad_impl(x, dy, nullptr, nullptr, workspace, N, H, W, Cin, Cout, KS, pad, stream, x_up2);
+}
+
+int aesr_conv2d_wgrad_reduce_many(const aesr_wgrad_reduce_job* jobs_host, int njobs, void* stream) {
+    AESR_CHECK_ARG(jobs_host && njobs > 0, "aesr_conv2d_wgrad_reduce_many: no jobs");
+    for (int j0 = 0; j0 < njobs; j0 += REDUCE_MAX_JOBS) {
+        ReduceTable t;
+        memset(&t, 0, sizeof(t));
+        t.njobs = njobs - j0 < REDUCE_MAX_JOBS ? njobs - j0 : REDUCE_MAX_JOBS;
+        int nb = 0;
+        for (int k = 0; k < t.njobs; ++k) {
+            const aesr_wgrad_reduce_job& jb = jobs_host[j0 + k];
+            AESR_CHECK_ARG(jb.workspace && jb.dw && jb.N > 0 && (jb.KS == 1 || jb.KS == 3), "aesr_conv2d_wgrad_reduce_many: bad job %d", j0 + k);
+            const int Ho = jb.H + 2 * jb.pad - jb.KS + 1, Wo = jb.W + 2 * jb.pad - jb.KS + 1;
+            const WgradPlan p = plan_wgrad(jb.N, Ho, Wo, jb.Cin, jb.Cout, jb.KS, jb.pad);      // the plan the partial launch used
+            ReduceJob& o = t.job[k];
+            o.slab = jb.workspace; o.dw = jb.dw; o.db = jb.db; o.nslab = p.nslab; o.KS2 = jb.KS * jb.KS; o.Cin = jb.Cin; o.CinP = p.CinP;
+            o.Cout = jb.Cout; o.CoutP = p.CoutP; o.block0 = nb;
+            nb += ceil_div(o.KS2 * jb.Cin * jb.Cout + (jb.db ? jb.Cout : 0), 64);
+        }
+        t.nblocks = nb;
+        if (int e = aesr_launch_wgrad_reduce_many(t, (hipStream_t)stream)) return e;
+    }
+    return AESR_OK;
+}
+
 int aesr_conv2d_wgrad_up2_supported(int Cin, int Cout) { return wgrad_wino_ok(Cin, Cout, 3, 1) ? 1 : 0; }
 
 int aesr_conv2d_wgrad_up2(const float* x_half, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W, int Cin,
@@ -515,7 +545,7 @@ int aesr_conv2d_wgrad_up2(const float* x_half, const float* dy, float* dw, float
 
 static int wgrad_impl(const float* x, const float* dy, float* dw, float* db, float* workspace, int N, int H, int W, int Cin,
                       int Cout, int KS, int pad, void* stream, int x_up2) {
-    AESR_CHECK_ARG(x && dy && dw && workspace && N > 0, "aesr_conv2d_wgrad: null pointer or empty shape");
+    AESR_CHECK_ARG(x && dy && workspace && N > 0, "aesr_conv2d_wgrad: null pointer or empty shape");
     AESR_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0, "aesr_conv2d_wgrad: Cin=%d, Cout=%d must be multiples of 4", Cin, Cout);
     AESR_CHECK_ARG((KS == 1 || KS == 3) && pad >= 0 && pad < KS, "aesr_conv2d_wgrad: unsupported KS=%d pad=%d", KS, pad);
     const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
@@ -531,6 +561,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* db, flo
     } else if (int e = aesr_launch_conv_wgrad(a, KS, p.variant, (hipStream_t)stream)) {
         return e;
     }
+    if (!dw) return AESR_OK;            // partial-slab form (aesr_conv2d_wgrad_partial): the caller reduces later
     return aesr_launch_wgrad_reduce(workspace, dw, db, p.nslab, KS, Cin, p.CinP, Cout, p.CoutP, (hipStream_t)stream);
 }
 

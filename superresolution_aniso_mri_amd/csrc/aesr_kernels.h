@@ -24,6 +24,7 @@ struct WinoArgs {
     int N, H, W, Cin, CinP, Cout, CoutP;
     int TI, THt, TWt;            // work item = TI images x THt x TWt Winograd tiles (2x2 outputs each) x 32 output channels
     int regs_y, regs_x, nitems;  // filled by the launcher
+    unsigned m_ncot, m_regs_x, m_regs_y;     // ceil(2^32 / d) of the item decomposition's divisors (0: d == 1), filled by the launcher
     int act, mask_act;
     float slope;
     float* dbgbuf;               // per-wave phase stamps (AESR_WINO_DBG=1), nullptr in normal operation
@@ -52,6 +53,10 @@ struct WgradArgs {
 int aesr_launch_conv_wgrad(const WgradArgs& a, int KS, int variant, hipStream_t st);
 int aesr_launch_conv_wgrad_wino(const WgradArgs& a, hipStream_t st);
 size_t aesr_wgrad_wino_lds_bytes(int TH, int TW);
+#define REDUCE_MAX_JOBS 16
+struct ReduceJob { const float* slab; float* dw; float* db; int nslab, KS2, Cin, CinP, Cout, CoutP, block0; };
+struct ReduceTable { int njobs, nblocks; ReduceJob job[REDUCE_MAX_JOBS]; };
+int aesr_launch_wgrad_reduce_many(const ReduceTable& t, hipStream_t st);
 int aesr_launch_wgrad_reduce(const float* slab, float* dw, float* db, int nslab, int KS, int Cin, int CinP, int Cout, int CoutP, hipStream_t st);
 
 struct SmallArgs {

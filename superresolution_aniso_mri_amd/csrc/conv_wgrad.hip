@@ -288,6 +288,58 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// the same for the convolutions of a whole backward pass in ONE launch: the block looks its job up in the by-value table
+__global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(ReduceTable t) {
+    __shared__ float red[4][64];
+    int j = 0;
+    for (int k = 1; k < t.njobs; ++k)
+        if ((int)blockIdx.x >= t.job[k].block0) j = k;
+    const ReduceJob& jb = t.job[j];
+    const int o = ((int)blockIdx.x - jb.block0) * 64 + (threadIdx.x & 63);
+    const int sl = threadIdx.x >> 6;
+    const int nw = jb.KS2 * jb.Cin * jb.Cout;
+    const int total = nw + (jb.db ? jb.Cout : 0);
+    float s = 0.f;
+    size_t off = 0;
+    const bool live = o < total;
+    int co = 0, ci = 0, tap = 0;
+    if (live) {
+        if (o < nw) {
+            co = o % jb.Cout;
+            const int rest = o / jb.Cout;
+            ci = rest % jb.Cin;
+            tap = rest / jb.Cin;
+            off = ((size_t)tap * jb.CinP + ci) * jb.CoutP + co;
+        } else {
+            off = (size_t)jb.KS2 * jb.CinP * jb.CoutP + (o - nw);
+        }
+        const size_t stride = (size_t)(jb.KS2 + 1) * jb.CinP * jb.CoutP;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = sl;
+        for (; k + 12 < jb.nslab; k += 16) {
+            s0 += jb.slab[(size_t)k * stride + off];
+            s1 += jb.slab[(size_t)(k + 4) * stride + off];
+            s2 += jb.slab[(size_t)(k + 8) * stride + off];
+            s3 += jb.slab[(size_t)(k + 12) * stride + off];
+        }
+        for (; k < jb.nslab; k += 4) s0 += jb.slab[(size_t)k * stride + off];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[sl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sl == 0 && live) {
+        s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (o < nw) jb.dw[((size_t)co * jb.Cin + ci) * jb.KS2 + tap] = s;
+        else jb.db[o - nw] = s;
+    }
+}
+
+int aesr_launch_wgrad_reduce_many(const ReduceTable& t, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(t.nblocks), dim3(256), 0, st, t);
+    AESR_LAUNCH_CHECK("wgrad_reduce_many");
+    return AESR_OK;
+}
+
 template <int KS, int NWCO>
 static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     constexpr int COT = 16 * NWCO;

@@ -118,14 +118,19 @@ __global__ __launch_bounds__(WN_NT, 2) void conv_wino_f32(WinoArgs a) {
     if (l_item >= nitems) return;
     int goff[NPP];
 
+    // item -> (image group, region row, region column, cout tile): divisions by launch constants as multiply-high with the
+    // host's magic numbers (x / d == mulhi(x, ceil(2^32 / d)) for x * d < 2^32): a runtime integer division costs ~40 instructions
+    // and three of them sit on every item boundary, where no MFMA overlaps them
+#define WN_DIV(x, m) ((m) ? (int)__umulhi((unsigned)(x), (m)) : (int)(x))          /* m == 0: divisor 1 */
 #define WN_ITEM_ORIGIN(item, n0, ty0, tx0, co0)               \
     {                                                         \
-        int reg_ = (item) / ncot;                             \
+        int reg_ = WN_DIV(item, a.m_ncot);                    \
         co0 = ((item) - reg_ * ncot) * WN_TN;                 \
-        const int rx_ = reg_ % a.regs_x;                      \
-        reg_ /= a.regs_x;                                     \
-        const int ry_ = reg_ % a.regs_y;                      \
-        n0 = (reg_ / a.regs_y) * a.TI;                        \
+        const int q1_ = WN_DIV(reg_, a.m_regs_x);             \
+        const int rx_ = reg_ - q1_ * a.regs_x;                \
+        const int q2_ = WN_DIV(q1_, a.m_regs_y);              \
+        const int ry_ = q1_ - q2_ * a.regs_y;                 \
+        n0 = q2_ * a.TI;                                      \
         ty0 = ry_ * a.THt;                                    \
         tx0 = rx_ * a.TWt;                                    \
     }
@@ -361,6 +366,7 @@ __global__ __launch_bounds__(WN_NT, 2) void conv_wino_f32(WinoArgs a) {
 #undef WN_CHUNK_OFFS
 #undef WN_COMPUTE_GOFF
 #undef WN_ITEM_ORIGIN
+#undef WN_DIV
 }
 
 // ---- weight transform + packing ----------------------------------------------------------------------------------------
@@ -524,6 +530,13 @@ int aesr_launch_conv_wino(const WinoArgs& a_in, hipStream_t st) {
     a.regs_y = ceil_div(ceil_div(a.H, 2), a.THt);
     a.regs_x = ceil_div(ceil_div(a.W, 2), a.TWt);
     a.nitems = ceil_div(a.N, a.TI) * a.regs_y * a.regs_x * (a.CoutP / WN_TN);
+    // magic numbers of the item decomposition: exact while item * divisor < 2^32
+    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((((unsigned long long)1 << 32) + d - 1) / d); };
+    a.m_ncot = magic(a.CoutP / WN_TN); a.m_regs_x = magic(a.regs_x); a.m_regs_y = magic(a.regs_y);
+    if ((unsigned long long)a.nitems * (unsigned)(a.CoutP / WN_TN + a.regs_x + a.regs_y) >= ((unsigned long long)1 << 31)) {
+        aesr_set_error("conv_wino: %d work items exceed the exact range of the item decomposition", a.nitems);
+        return AESR_ERR_UNSUPPORTED;
+    }
     const int NPP = ceil_div(PP * 4, WN_NT);
 #define WN_CASE(npp)                                                                                     \
     if (NPP == npp) return a.ysave ? wino_launch_one<npp, true>(a, st) : wino_launch_one<npp, false>(a, st);

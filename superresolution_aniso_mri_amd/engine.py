@@ -476,6 +476,14 @@ class SequentialRunner:
         g = gout[:ngrad]
         if not g.is_contiguous():
             g = g.contiguous()
+        reduce_jobs = []          # (job, workspace, dw, db): the tensors stay referenced until the reduction has been enqueued
+        g = self._backward_steps(steps, saved, g, ngrad, need_input_grad, grads, G, ns, reduce_jobs)
+        if reduce_jobs:
+            arr = (_hip.WgradReduceJob * len(reduce_jobs))(*[j[0] for j in reduce_jobs])
+            check(lib.aesr_conv2d_wgrad_reduce_many(arr, len(reduce_jobs), stream()), "aesr_conv2d_wgrad_reduce_many")
+        return g, grads
+
+    def _backward_steps(self, steps, saved, g, ngrad, need_input_grad, grads, G, ns, reduce_jobs):
         for k in range(len(steps) - 1, -1, -1):
             s = steps[k]
             if s.kind == "stemconv":
@@ -511,12 +519,15 @@ class SequentialRunner:
                     nws = lib.aesr_conv2d_wgrad_workspace_floats(N, H, W, s.cin, s.cout, s.ks, s.pad)
                     ws = _empty((nws,), g)
                     _pb("conv_wgrad_f32", 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
-                    if s.in_up2:
-                        check(lib.aesr_conv2d_wgrad_up2(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout, stream()),
-                              "aesr_conv2d_wgrad_up2")
-                    else:
+                    if s.s2d:        # its result is re-laid out right below: reduce at once
                         check(lib.aesr_conv2d_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout, s.ks,
                                                     s.pad, stream()), "aesr_conv2d_wgrad")
+                    else:
+                        # partial slabs now; the slabs of all layers of this pass are summed by ONE launch at the end of the pass
+                        check(lib.aesr_conv2d_wgrad_partial(ptr(xin), ptr(g), ptr(ws), N, H, W, s.cin, s.cout, s.ks, s.pad,
+                                                            int(s.in_up2), stream()), "aesr_conv2d_wgrad_partial")
+                        reduce_jobs.append((_hip.WgradReduceJob(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                                                N, H, W, s.cin, s.cout, s.ks, s.pad), ws, dw, db))
                     _pe()
                 elif s.cin <= 4 and s.ks == 1 and db is not None:
                     ws = _empty((lib.aesr_small_wgrad_workspace_floats(s.cout * (s.cin + 1)),), g)
@@ -614,7 +625,7 @@ class SequentialRunner:
                                                 _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dpre),
                                                 N, H, W, C, s.run_mode, prev.act, prev.slope, G, nsa, stream()), "aesr_bn_bwd_apply")
                 g = dpre
-        return g, grads
+        return g
 
 
 class _PassFn(torch.autograd.Function):

@@ -123,8 +123,7 @@ class AEBaseTrainer(BaseTrainer):
                     self._capture_sink = None
                     self.dp.segments = None
                 self._graphs[sig] = (graph, static, sink)
-                for k, v in sink.items():
-                    self.losses[k].append(v.detach().clone())
+                self._log_sink(sink)
                 return
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
@@ -139,8 +138,15 @@ class AEBaseTrainer(BaseTrainer):
         for k in keys:
             static[k].copy_(dev_batch[k])
         graph.replay()
-        for k, v in sink.items():
-            self.losses[k].append(v.detach().clone())
+        self._log_sink(sink)
+
+    def _log_sink(self, sink):
+        """Log the scalars a replayed step left in its static buffers: ONE gather kernel for all of them (the buffers are
+        overwritten by the next replay, so the values must be copied out; a clone per scalar costs a launch each)."""
+        keys = list(sink.keys())
+        vals = torch.stack([sink[k].detach().reshape(()) for k in keys])
+        for i, k in enumerate(keys):
+            self.losses[k].append(vals[i])
 
     def train(self, batch_item, keep_predictions=True, eval_mode=False):
         """Plain ``ae`` step (reference :71-109): reconstruction loss only; latent loss and the 0.5-mix are logged."""
