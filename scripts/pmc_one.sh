@@ -12,7 +12,7 @@ import csv, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"].split("(")[0][:40]
-    if "wino" not in k or "pack" in k: continue
+    if ("wino" not in k and "wgrad" not in k) or "pack" in k or "reduce" in k: continue
     agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     print(k, {c: round(sum(v) / len(v)) for c, v in d.items()})

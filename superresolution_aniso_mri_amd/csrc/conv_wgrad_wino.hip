@@ -138,12 +138,25 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
     const int chA = (((l15 >> 2) ^ sw) << 2) + (l15 & 3);          // float offset of block 0's channel in pixels with (col >> 1) even
     const int chB = (((l15 >> 2) ^ sw ^ 4) << 2) + (l15 & 3);      // ... with (col >> 1) odd
 
+    // debug build of the same loop (a.dbgbuf != nullptr, AESR_WGRAD_WINO_DBG=1): cycles per wave spent staging, in the unhidden first
+    // operands of a tile, in the pair loop and at the barrier
+    const bool stamp = a.dbgbuf != nullptr;
+    long long tph[5] = {0, 0, 0, 0, 0}, tq = 0;
+#define WW_STAMP(k)                                                 \
+    if (stamp) {                                                    \
+        const long long t_ = (long long)__builtin_amdgcn_s_memtime(); \
+        tph[k] += t_ - tq;                                          \
+        tq = t_;                                                    \
+    }
+    if (stamp) tq = (long long)__builtin_amdgcn_s_memtime();
     int tile = split, buf = 0;
     if (tile < a.ntiles) stage(tile, 0);
     __syncthreads();
+    WW_STAMP(4)
     while (tile < a.ntiles) {
         const int next = tile + a.S;
         if (next < a.ntiles) stage(next, buf ^ 1);                 // lands before the barrier at the end of this tile
+        WW_STAMP(0)
         const float* xbuf = ldsX0 + buf * XFL;
         const float* dbuf = ldsD0 + buf * DFL;
 
@@ -223,6 +236,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
         const int nst = nks > wave ? (nks - wave + 3) >> 2 : 0;            // k-steps of this wave: wave, wave + 4, ...
         const int npair = nst >> 1;
         if (npair > 0) operands(wave, 1.f, V[0], M[0]);
+        WW_STAMP(1)
         for (int s2 = 0; s2 < npair; ++s2) {
             const int ks = wave + 8 * s2;
             __builtin_amdgcn_sched_barrier(0);
@@ -241,11 +255,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
             mfmas(V[1], M[1]);
         }
 #undef WW_DEAL
+        WW_STAMP(2)
         __syncthreads();            // every wave is done with `buf`; the next tile is complete in `buf ^ 1`
+        WW_STAMP(3)
         buf ^= 1;
         tile = next;
     }
 
+    if (stamp && lane == 0)
+        for (int k = 0; k < 5; ++k) a.dbgbuf[(blockIdx.x * 4 + wave) * 5 + k] = (float)tph[k];
     // ---- epilogue: signs of A, dg = G^T dU G, sum of the four waves through LDS, ONE slab per workgroup ----
     // G^T = [[1, 1/2, 1/2, 0], [0, 1/2, -1/2, 0], [0, 1/2, 1/2, 1]]
     f32x4 dg[9][2][2];
@@ -363,6 +381,25 @@ int aesr_launch_conv_wgrad_wino(const WgradArgs& a, hipStream_t st) {
         attr_set[dev_] = true;
     }
     dim3 grid(a.S * (a.CinP / 32) * (a.CoutP / 32));
+    if (getenv("AESR_WGRAD_WINO_DBG") && grid.x <= 4096) {     // debug: per-phase cycle stamps, printed after a host sync
+        static float* dbuf = nullptr;
+        if (!dbuf) (void)hipMalloc(&dbuf, 4096 * 4 * 5 * sizeof(float));
+        WgradArgs b = a;
+        b.dbgbuf = dbuf;
+        hipLaunchKernelGGL(conv_wgrad_wino_f32, grid, dim3(256), shmem, st, b);
+        (void)hipStreamSynchronize(st);
+        static float host[4096 * 4 * 5];
+        (void)hipMemcpy(host, dbuf, (size_t)grid.x * 4 * 5 * sizeof(float), hipMemcpyDeviceToHost);
+        double s5[5] = {0, 0, 0, 0, 0};
+        for (unsigned i = 0; i < grid.x * 4; ++i) for (int k = 0; k < 5; ++k) s5[k] += host[i * 5 + k];
+        const double visits = (double)((a.ntiles + a.S - 1) / a.S);
+        const int nks = (a.TH >> 1) * (a.TW >> 3);
+        fprintf(stderr, "[wgrad-wino stamps] grid=%u tile %dx%d S=%d (%.0f visits, %d k-steps = %d MFMA cycles per wave and visit) per visit, cycles: "
+                "stage %.0f | first operands %.0f | pair loop %.0f | barrier %.0f || first fill %.0f\n", grid.x, a.TH, a.TW, a.S, visits, nks,
+                nks / 4 * 64 * 32, s5[0] / grid.x / 4 / visits, s5[1] / grid.x / 4 / visits, s5[2] / grid.x / 4 / visits, s5[3] / grid.x / 4 / visits,
+                s5[4] / grid.x / 4);
+        return AESR_OK;
+    }
     hipLaunchKernelGGL(conv_wgrad_wino_f32, grid, dim3(256), shmem, st, a);
     AESR_LAUNCH_CHECK("conv_wgrad_wino_f32");
     return AESR_OK;
