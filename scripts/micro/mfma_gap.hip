@@ -2,6 +2,7 @@
 // instructions of one kind behind every MFMA -- how many hide in the 32-cycle gap of this MFMA?
 //   kind 0: independent v_add_f32     kind 1: dependent v_add_f32 chain     kind 2: ds_read_b32 (waited for once per 64 MFMAs)
 //   kind 3: s_add_i32 (scalar)        kind 4: v_mul_i32_i24                 kind 5: v_sub_f32 reading the previous ds_read (lgkmcnt waits)
+// Each gap's fillers stand in ONE asm statement: between separate asm statements the compiler puts an s_nop (4 more cycles).
 // build + run:  hipcc -O3 --offload-arch=gfx950 scripts/micro/mfma_gap.hip -o /tmp/mfma_gap && /tmp/mfma_gap
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -25,9 +26,12 @@ __global__ __launch_bounds__(256, 1) void k(float* out, long long* cyc, int iter
 #pragma unroll
         for (int j = 0; j < 64; ++j) {
             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[j]) : "v"(a0), "v"(b0));
+            if constexpr (KIND == 0 && NF > 0) {
+                asm volatile(".rept %8\n\tv_add_f32 %0, %6, %7\n\tv_add_f32 %1, %6, %7\n\t.endr\n\t.rept %9\n\tv_add_f32 %2, %6, %7\n\t.endr"
+                             : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]) : "v"(a0), "v"(b0), "i"(NF / 2), "i"(NF & 1));
+            }
 #pragma unroll
             for (int n = 0; n < NF; ++n) {
-                if constexpr (KIND == 0) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f[n]) : "v"(a0), "v"(b0));
                 if constexpr (KIND == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[0]) : "v"(b0));
                 if constexpr (KIND == 2) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f[n]) : "v"(lp), "i"(n * 256));
                 if constexpr (KIND == 3) asm volatile("s_add_i32 %0, %0, 1" : "+s"(si));
@@ -70,11 +74,10 @@ __global__ __launch_bounds__(256, 1) void kg(float* out, long long* cyc, int ite
 #pragma unroll
                 for (int j = j0; j < j0 + G; ++j) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[j]) : "v"(a0), "v"(b0));
             }
-#pragma unroll
-            for (int n = 0; n < NF * G; ++n) {
-                if constexpr (KIND == 0 || KIND == 7) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f[n & 7]) : "v"(a0), "v"(b0));
-                if constexpr (KIND == 6) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(p[n & 3]) : "v"(pa), "v"(pa));
-            }
+            if constexpr (KIND == 0 || KIND == 7)
+                asm volatile(".rept %4\n\tv_add_f32 %0, %2, %3\n\tv_add_f32 %1, %2, %3\n\t.endr" : "=v"(f[0]), "=v"(f[1]) : "v"(a0), "v"(b0), "i"(NF * G / 2));
+            if constexpr (KIND == 6)
+                asm volatile(".rept %3\n\tv_pk_add_f32 %0, %2, %2\n\tv_pk_add_f32 %1, %2, %2\n\t.endr" : "=v"(p[0]), "=v"(p[1]) : "v"(pa), "i"(NF * G / 2));
         }
     }
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
@@ -116,8 +119,8 @@ __global__ __launch_bounds__(512, 1) void k2(float* out, long long* cyc, int ite
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[j]) : "v"(a0), "v"(b0));
-#pragma unroll
-            for (int n = 0; n < NF; ++n) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f[n]) : "v"(a0), "v"(b0));
+            if constexpr (NF > 0)
+                asm volatile(".rept %4\n\tv_add_f32 %0, %2, %3\n\t.endr\n\t.rept %5\n\tv_add_f32 %1, %2, %3\n\t.endr" : "=v"(f[0]), "=v"(f[1]) : "v"(a0), "v"(b0), "i"((NF + 1) / 2), "i"(NF / 2));
         }
     }
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
@@ -141,8 +144,8 @@ static void run2() {
     double s = 0, smax = 0;
     for (int i = 0; i < 256; ++i) { long long m = 0; for (int w = 0; w < 8; ++w) { s += h[i * 8 + w]; if (h[i * 8 + w] > m) m = h[i * 8 + w]; } smax += m; }
     const double per = s / 2048 / iters / 32, pmax = smax / 256 / iters / 32;
-    printf("two waves per SIMD, %d fillers (+ as many s_nop) per gap: mean %.1f, slowest wave %.1f cycles per MFMA of a wave = %.1f per MFMA of the SIMD (%.0f%% of the pipe); one wave alone would take %.1f\n",
-           NF, per, pmax, pmax / 2, 6400.0 / pmax, 32.0 + (NF ? 4.3 + 8.0 * NF : 0.0));
+    printf("two waves per SIMD, %d v_add_f32 per gap: mean %.1f, slowest wave %.1f cycles per MFMA of a wave = %.1f per MFMA of the SIMD (%.0f%% of the pipe); one wave alone would take %.1f\n",
+           NF, per, pmax, pmax / 2, 6400.0 / pmax, 32.0 + (NF ? 4.3 + 4.0 * NF : 0.0));
     (void)hipFree(out); (void)hipFree(cyc);
 }
 

@@ -185,24 +185,18 @@ static WgradPlan plan_wgrad_wino(int N, int H, int W, int Cin, int Cout) {
     if (S >= 8) S &= ~7;                       // multiple of 8: XCD-aware workgroup order
     if (S < 1) S = 1;
     double best = 1e300;
-    p.TH = 4; p.TW = 32; p.S = S;
-    for (int TW = 8; TW <= 32; TW += 8) {
-        for (int TH = 2; TH <= 16; TH += 2) {
-            if ((TH + 2) * round_up(TW + 2, 4) * 8 > 256 * 12 || TH * TW * 8 > 256 * 8 || aesr_wgrad_wino_lds_bytes(TH, TW) > (size_t)160 * 1024) break;
-            const int ntiles = N * ceil_div(H, TH) * ceil_div(W, TW);
-            const int s = S < ntiles ? S : ntiles;
-            const double rounds = (double)ceil_div(ntiles, s);
-            const int nks = (TH / 2) * (TW / 8);
-            if (nks % 8 != 0) continue;             // an even number of k-steps per wave: the kernel's operand buffers keep fixed roles
-            // per visit: a wave's k-steps (64 MFMAs + both transforms, ~3200 cycles each at the clock this instruction mix
-            // holds) + DMA issue, the unpipelined first operands and the barrier (~2500); fitted to scripts/wgrad_wino_tiles.sh
-            const double t = rounds * (ceil_div(nks, 4) * 3200.0 + 2500.0);
-            if (t < best) { best = t; p.TH = TH; p.TW = TW; p.S = s; }
-        }
+    p.TH = 16; p.TW = 8; p.S = S;
+    for (int v = 0; v < 2; ++v) {
+        const int TH = v ? 8 : 16, TW = v ? 16 : 8;                 // the kernel's two tiles (aesr_wgrad_wino_tile_ok): 8 k-steps, 2 per wave
+        const int ntiles = N * ceil_div(H, TH) * ceil_div(W, TW);
+        const int s = S < ntiles ? S : ntiles;
+        // per visit: 128 MFMAs of a wave (4 096 cycles) + ~270 other instructions, which this chip does not overlap with them
+        const double t = (double)ceil_div(ntiles, s) * (4096.0 + 1300.0);
+        if (t < best) { best = t; p.TH = TH; p.TW = TW; p.S = s; }
     }
     if (const char* e = getenv("AESR_WGRAD_WINO_TILE")) {     // experiment knob: "TH,TW"
         int th = 0, tw = 0;
-        if (sscanf(e, "%d,%d", &th, &tw) == 2 && th > 0 && tw > 0 && tw % 8 == 0 && th % 2 == 0) {
+        if (sscanf(e, "%d,%d", &th, &tw) == 2 && aesr_wgrad_wino_tile_ok(th, tw)) {
             p.TH = th; p.TW = tw;
             const int ntiles = N * ceil_div(H, p.TH) * ceil_div(W, p.TW);
             p.S = S < ntiles ? S : ntiles;

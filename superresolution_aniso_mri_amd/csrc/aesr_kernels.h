@@ -53,6 +53,7 @@ struct WgradArgs {
 int aesr_launch_conv_wgrad(const WgradArgs& a, int KS, int variant, hipStream_t st);
 int aesr_launch_conv_wgrad_wino(const WgradArgs& a, hipStream_t st);
 size_t aesr_wgrad_wino_lds_bytes(int TH, int TW);
+bool aesr_wgrad_wino_tile_ok(int TH, int TW);
 #define REDUCE_MAX_JOBS 16
 struct ReduceJob { const float* slab; float* dw; float* db; int nslab, KS2, Cin, CinP, Cout, CoutP, block0; };
 struct ReduceTable { int njobs, nblocks; ReduceJob job[REDUCE_MAX_JOBS]; };

@@ -6,20 +6,29 @@
 // The 16 positions xi are 16 GEMMs with M = ci, N = co, K = tiles: 16 MFMA flops-blocks per tile instead of the 36 of the
 // direct form (conv_wgrad.hip) -- 2.25x fewer matrix-core flops.
 //
+// What bounds it (scripts/micro/mfma_gap.hip, profiles/r02_micro_mfma_gap.txt): on gfx950 v_mfma_f32_16x16x4_f32 and the vector
+// ALU do NOT overlap -- one wave per SIMD pays 32 cycles per MFMA plus ~4.3 per other instruction, wherever it stands -- so the
+// kernel is built to issue FEW instructions besides its MFMAs:
 //  * one 4-wave workgroup per CU, ONE wave per SIMD with the whole 512-register budget: a wave keeps the accumulators of all 16
-//    positions for a 32 ci x 32 co block (256 accumulator registers) and takes every 4th k-step (a k-step = 4 horizontally
-//    adjacent tiles = the K of one MFMA); with 2 ci x 2 co blocks per wave one input transform feeds 32 MFMAs and one dM
-//    transform 32: ~2 other instructions per MFMA, produced one k-step ahead in the shadow of the previous step's 64 MFMAs;
+//    positions for a 32 ci x 32 co block (256 accumulation registers, pinned by asm constraints) and takes every 4th k-step (a
+//    k-step = 4 horizontally adjacent tiles = the K of one MFMA): one input transform feeds 32 MFMAs, one dM transform 32;
+//  * both transforms run on register PAIRS with v_pk_add_f32 and its source-select / negate modifiers (two adds per instruction,
+//    no shuffles: the LDS reads already deliver vertical pixel pairs, ds_read2st64_b32): 48 instructions per 64 MFMAs.  dM is
+//    built with the sign-free matrix A' = [[1,0],[1,1],[1,-1],[0,1]] (A's last row negated); the signs (-1)^(i==3) (-1)^(j==3)
+//    are applied once, in the epilogue.  The bias gradient is one of the dM sums (dY00 + dY01 + dY10 + dY11);
 //  * the X patch and the dY tile go global -> LDS by DMA (buffer_load ... lds), pixel-major as they lie in memory
-//    ([pixel][32 channels]), double buffered: the next spatial tile lands while this one is consumed, ONE barrier per tile, no
-//    staging registers and no transposing pass.  Lane (channel = lane & 15, tile = lane >> 4) reads single floats: two lanes of
-//    a half-wave that differ in the tile would hit the same 16 banks, so the DMA source swaps the two 16-channel halves of every
-//    other pixel pair (slot = quad ^ 4*((col >> 1) & 1)): tiles t and t + 1 then read from opposite bank halves -- conflict free;
-//  * the transforms run in registers; dM is built with the sign-free matrix A' = [[1,0],[1,1],[1,-1],[0,1]] (A's last row
-//    negated) and the signs (-1)^(i==3) (-1)^(j==3) are applied once, in the epilogue, to the accumulators;
+//    ([row][pixel][32 channels]); one DMA instruction of a wave = 8 pixels of ONE row, and a wave always fetches the same
+//    8-pixel segment: everything per lane (channel slot, column bound, the folded Upsample's source column) is computed once per
+//    tile, a DMA costs 4 instructions.  Rows outside the image are answered by the range check of a per-image buffer resource.
+//    The DMA source swaps the two 16-channel halves of every other pixel pair (slot = quad ^ 4*((col >> 1) & 1)) so the lanes
+//    of a half-wave (channel = lane & 15, tile = lane >> 4) read conflict free;
+//  * tile v lives in LDS buffer v & 1.  The barrier of a tile stands before its LAST k-step: by then every wave has the last
+//    operands it needs from the buffer in registers and tile v + 1 has landed, so the last k-step already fetches the first
+//    operands of tile v + 1 and issues the DMA of tile v + 2 into the buffer just freed -- a whole k-step (> 2 000 cycles) before
+//    anything waits for it.  No prologue per tile, no fetch burst;
 //  * epilogue: dg = G^T dU G per lane (16 -> 9 values), the four waves' partial sums are added through LDS in a fixed order,
 //    ONE slab per workgroup in the layout of conv_wgrad.hip ([split][tap | bias][ci][co]); wgrad_reduce_kernel sums the slabs
-//    (bitwise reproducible, no atomics).  The bias gradient is the sum of the dY values the lanes read anyway.
+//    (bitwise reproducible, no atomics).
 //
 // Replaces autograd's conv2d weight-gradient for the 3x3 layers of networks/acai_vanilla.py:49-102 with >= 32 channels.
 #include <stdio.h>
@@ -31,43 +40,52 @@
 #include "aesr_kernels.h"
 
 constexpr int WW_OOB = 0x70000000;
-#ifndef WW_G
-#define WW_G 8                  // MFMAs issued back to back
-#endif
-
-__device__ __forceinline__ void ww_dma(__amdgpu_buffer_rsrc_t rs, float* lds_wave_base, int byte_off) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, byte_off, 0, 0, 0);
-}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
 template <int... I, class F>
 __device__ __forceinline__ void ww_for(std::integer_sequence<int, I...>, F&& f) {
     (f(std::integral_constant<int, I>{}), ...);
 }
+template <int N, class F>
+__device__ __forceinline__ void ww_rep(F&& f) { ww_for(std::make_integer_sequence<int, N>{}, f); }
 
-// A spatial tile this workgroup visits.  All uniform (SGPRs).  The two streams get per-IMAGE buffer resources: the hardware range
-// check of the resource then answers "row outside the image" by itself (zero, no fetch).
+__device__ __forceinline__ void ww_dma(__amdgpu_buffer_rsrc_t rs, float* lds_wave_base, int byte_off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, byte_off, 0, 0, 0);
+}
+
+// v_pk_add_f32 forms (checked on the device by scripts/micro/pk_mods.hip); a = (a.lo, a.hi), b likewise
+// (the operands are bound to locals first: clang rejects enclosing-function variables as asm operands inside nested generic lambdas)
+#define WW_PK(dst, a, b, mods)                                                          \
+    do {                                                                                \
+        f32x2& d_ = dst;                                                                \
+        const f32x2 a_ = a, b_ = b;                                                     \
+        asm volatile("v_pk_add_f32 %0, %1, %2 " mods : "=v"(d_) : "v"(a_), "v"(b_));    \
+    } while (0)
+#define WW_M_ADD ""                                                                 /* (a.lo + b.lo, a.hi + b.hi) */
+#define WW_M_SUB "neg_lo:[0,1] neg_hi:[0,1]"                                        /* (a.lo - b.lo, a.hi - b.hi) */
+#define WW_M_T01 "op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]"           /* (a.lo - b.lo, a.hi + b.lo) */
+#define WW_M_T23 "op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]"           /* (b.lo - a.hi, a.hi - b.hi) */
+#define WW_M_LL "op_sel:[0,0] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[0,1]"            /* (a.lo + b.lo, a.lo - b.lo) */
+#define WW_M_HH "op_sel:[1,1] op_sel_hi:[1,1] neg_lo:[0,0] neg_hi:[0,1]"            /* (a.hi + b.hi, a.hi - b.hi) */
+#define WW_M_SELF "op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]"          /* with b = a: (a.lo + a.hi, a.lo - a.hi) */
+
+// A spatial tile this workgroup visits; all uniform (SGPRs)
 struct WwTile {
     int n, ty, tx;              // image, tile row, tile column
-    const char* xb;             // start of image n of x / of dy
-    const char* db;
-    int orgx, orgd;             // byte offset of the patch / tile origin inside the image, or the out-of-range marker past the last tile
-    int x0;                     // first column of the tile
 };
 
 template <int TH, int TW, bool STAMP>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
     constexpr int CIT = 32, COT = 32;
-    constexpr int PH = TH + 2, PWL = (TW + 2 + 3) & ~3, TWL = TW;     // LDS row strides in PIXELS (multiples of 4: the swizzle then depends on the column only)
-    // floats of one X / dY buffer, in whole DMA rounds (256 lanes x 16 B): the last round of a buffer must not spill into its
-    // neighbour, which is being read
-    constexpr int XFL = (PH * PWL * 32 + 1023) & ~1023, DFL = (TH * TWL * 32 + 1023) & ~1023;
-    constexpr int NPX = XFL >> 10, NPD = DFL >> 10, NPIECE = NPX + NPD;          // DMA rounds of a tile
-    constexpr int KPR = TW >> 3, NKS = (TH >> 1) * KPR, NST = NKS >> 2;           // k-steps per tile row / per tile / per wave and tile
-    constexpr int NSLOT = (NPIECE + NST - 1) / NST;                               // DMA rounds issued per k-step
-    static_assert(NKS % 8 == 0, "an even number of k-steps per wave: the operand buffers keep fixed roles around the loop");
-    static_assert(2 * (XFL + DFL) * 4 <= 160 * 1024, "LDS");
-    constexpr unsigned MGX = (65536 + PWL - 1) / PWL, MGD = (65536 + TWL - 1) / TWL;      // pixel -> row by multiply-high (pixel < 1820)
+    static_assert((TH == 16 && TW == 8) || (TH == 8 && TW == 16), "tiles: 8 k-steps, rows of whole 8-pixel DMA segments");
+    constexpr int PH = TH + 2, PWL = TW == 8 ? 16 : 32, TWL = TW;     // LDS row strides in pixels
+    constexpr int XFL = PH * PWL * 32, DFL = TH * TWL * 32;            // floats of one X / dY buffer
+    constexpr int KPR = TW >> 3;                                        // k-steps per tile row; 8 per tile, 2 per wave
+    constexpr int SPR = PWL / 8, SPRD = TW / 8;                         // 8-pixel DMA segments per X / dY row
+    constexpr int NXS = PH * SPR / 4, NDS = TH * SPRD / 4;              // segments a wave fetches per tile
+    constexpr int RXS = 4 / SPR, RDS = 4 / SPRD;                        // ... every RXS-th / RDS-th row
+    static_assert(2 * (XFL + DFL) * 4 <= 160 * 1024 && (PH * SPR) % 4 == 0 && (TH * SPRD) % 4 == 0, "LDS / segment split");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -90,71 +108,58 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
     float* const ldsD0 = lds + 2 * XFL;              // [2][TH][TWL][32]
     const bool do_bias = ciy == 0;
 
-    // ---- DMA: round m of a tile = 256 lanes x 16 B; lane -> (pixel (tid >> 3) + 32 m, position tid & 7) of the buffer.  Nothing per
-    // lane is kept between rounds (a descriptor table would cost 40 registers the operand pipeline needs): ~15 instructions per
-    // round rebuild it, dealt out between the MFMAs like everything else ----
+    // ---- DMA.  Wave w always fetches segment w % SPR of rows w / SPR, + RXS, ... of the X patch (segment w % SPRD of rows w / SPRD,
+    // + RDS, ... of the dY tile): per lane only the row changes between its DMAs ----
     const int sh = a.x_up2 ? 1 : 0;                                     // nearest Upsample x2 folded in: x is stored at half size, pixel (y, x) <- (y/2, x/2)
     const int xH = a.H >> sh, xW = a.W >> sh;
     const int ximg = xH * xW * a.Cin * 4, dimg = a.H * a.W * a.Cout * 4; // bytes of one image
-    const int xrow = xW * a.Cin * 4, drow = a.W * a.Cout * 4, xpx = a.Cin * 4, dpx = a.Cout * 4;
-    int prow = tid >> 3;                  // made opaque inside the loop: otherwise the compiler hoists all 20 rounds' lane terms out of it
-    const int pos16 = (tid & 7) << 4;
+    const int xrow = xW * a.Cin * 4, drow = a.W * a.Cout * 4;            // ... of one stored row
+    const int sgx = wave % SPR, rx0 = wave / SPR, sgd = wave % SPRD, rd0 = wave / SPRD;
+    const int pxl = lane >> 3, pos = lane & 7;
+    const int quad = pos ^ (((pxl >> 1) & 1) << 2);                     // channel quad ^ 4 * ((col >> 1) & 1): 8 sg does not touch bit 1 of the column
+    const int pcx = 8 * sgx + pxl, pcd = 8 * sgd + pxl;                 // this lane's patch / tile column
+    const int lcx = (((pcx - sh) >> sh) * a.Cin + ci0 + 4 * quad) * 4;  // byte offset of the lane's 16 B relative to (row start + tile column origin)
+    const int lcd = (pcd * a.Cout + co0 + 4 * quad) * 4;
     const int tpi = a.tiles_y * a.tiles_x;
     const int dS_n = a.S / tpi, dS_r = a.S - dS_n * tpi, dS_ty = dS_r / a.tiles_x, dS_tx = dS_r - dS_ty * a.tiles_x;
-    auto locate = [&](WwTile& t) {
-        const bool valid = t.n < a.N;
-        const int n = valid ? t.n : 0, y0 = t.ty * TH, x0 = t.tx * TW;
-        t.xb = (const char*)a.x + (size_t)n * ximg;
-        t.db = (const char*)a.dy + (size_t)n * dimg;
-        const int ox = ((y0 >> sh) - 1 + sh) * xrow + ((x0 >> sh) - 1 + sh) * xpx + ci0 * 4, od = y0 * drow + x0 * dpx + co0 * 4;
-        t.orgx = valid ? ox : WW_OOB;
-        t.orgd = valid ? od : WW_OOB;
-        t.x0 = x0;
-    };
     auto advance = [&](WwTile t) {
         t.tx += dS_tx;
         if (t.tx >= a.tiles_x) { t.tx -= a.tiles_x; ++t.ty; }
         t.ty += dS_ty;
         if (t.ty >= a.tiles_y) { t.ty -= a.tiles_y; ++t.n; }
         t.n += dS_n;
-        locate(t);
         return t;
     };
-    // ---- everything besides the MFMAs is cut into ATOMS of one or two instructions and dealt out by hand, a few behind every MFMA,
-    // scheduling fences in between.  ONE wave per SIMD issues in order: an instruction behind an MFMA waits until the matrix pipe
-    // takes that MFMA (32 cycles after the previous one), so whatever follows a RUN of MFMAs is not hidden by it; ~28 cycles of
-    // other work (7 instructions) behind each single MFMA are.  [measured: groups of 4 MFMAs + 10 others ran at 71 % of the pipe]
-
-    // B atoms -- one DMA round (M compile-time: stream, LDS slot) in 12 atoms; the lane state of the round in flight:
-    unsigned b_pix = 0, b_pr = 0, b_pc = 0, b_gx = 0;
-    int b_w = 0, b_sy = 0, b_sx = 0, b_rel = 0;
-    auto dma_atom = [&](auto Mc, auto Kc, const WwTile& t, int buf) {
-        constexpr int M = decltype(Mc)::value, K = decltype(Kc)::value;
-        static_assert(M < NPIECE, "round");
-        constexpr bool IS_X = M < NPX;
-        constexpr int KM = IS_X ? M : M - NPX;
-        if constexpr (K == 0) b_pix = (unsigned)prow + 32u * KM;
-        if constexpr (K == 1) b_pr = (b_pix * (IS_X ? MGX : MGD)) >> 16;
-        if constexpr (K == 2) b_pc = b_pix - b_pr * (IS_X ? PWL : TWL);
-        if constexpr (K == 3) b_w = (int)((b_pc & 2u) << 5);                             // channel quad ^ 4 * ((col >> 1) & 1), in bytes
-        if constexpr (K == 4) b_w ^= pos16;
-        if constexpr (IS_X) {
-            if constexpr (K == 5) b_sy = ((int)b_pr - sh) >> sh;                         // relative source pixel (arithmetic shift: -1 stays -1)
-            if constexpr (K == 6) b_sx = ((int)b_pc - sh) >> sh;
-            if constexpr (K == 7) b_rel = __mul24(b_sx, xpx) + b_w;
-            if constexpr (K == 8) b_rel = __mul24(b_sy, xrow) + b_rel;
-            if constexpr (K == 9) b_gx = (unsigned)(t.x0 - 1) + b_pc;
-            if constexpr (K == 10) b_rel = b_gx < (unsigned)a.W ? t.orgx + b_rel : WW_OOB;    // rows outside the image: the per-image resource says so
-            if constexpr (K == 11) ww_dma(__builtin_amdgcn_make_buffer_rsrc((void*)t.xb, 0, ximg, 0x00020000), ldsX0 + buf * XFL + KM * 1024 + wave * 256, b_rel);
-        } else {
-            if constexpr (K == 7) b_rel = __mul24((int)b_pc, dpx) + b_w;
-            if constexpr (K == 8) b_rel = __mul24((int)b_pr, drow) + b_rel;
-            if constexpr (K == 9) b_gx = (unsigned)t.x0 + b_pc;
-            if constexpr (K == 10) b_rel = b_gx < (unsigned)a.W ? t.orgd + b_rel : WW_OOB;
-            if constexpr (K == 11) ww_dma(__builtin_amdgcn_make_buffer_rsrc((void*)t.db, 0, dimg, 0x00020000), ldsD0 + buf * DFL + KM * 1024 + wave * 256, b_rel);
-        }
+    // all DMAs of one tile: per-IMAGE buffer resources (rows above / below the image fall outside their range: zero, no fetch;
+    // a tile past the last one gets an empty range: its buffer is zero-filled, so whatever is computed from it adds nothing)
+    auto fetch = [&](const WwTile& t, int buf) {
+        const bool valid = t.n < a.N;
+        const int n = valid ? t.n : 0, y0 = t.ty * TH, x0 = t.tx * TW;
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x + (size_t)n * ximg), 0, valid ? ximg : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.dy + (size_t)n * dimg), 0, valid ? dimg : 0, 0x00020000);
+        // the lane's offset inside a row, or the out-of-range marker: patch column beyond the patch or outside the image
+        const unsigned gxx = (unsigned)(x0 - 1 + pcx), gxd = (unsigned)(x0 + pcd);
+        const int offx = (pcx < TW + 2 && gxx < (unsigned)a.W) ? lcx + ((x0 >> sh) - 1 + sh) * a.Cin * 4 : WW_OOB;
+        const int offd = gxd < (unsigned)a.W ? lcd + x0 * a.Cout * 4 : WW_OOB;
+        // X rows y0 - 1 + rx0 + RXS k (source row (.) >> 1 under the folded Upsample): a running offset, two alternating steps
+        const int r0 = y0 - 1 + rx0;
+        int ux = (r0 >> sh) * xrow;                  // arithmetic shift: row -1 stays -1
+        const int step_odd = sh == 0 ? RXS * xrow : RXS == 2 ? xrow : (r0 & 1) * xrow;      // step into an odd k
+        const int step_even = sh == 0 ? RXS * xrow : RXS == 2 ? xrow : xrow - step_odd;
+        float* const xdst = ldsX0 + buf * XFL + (rx0 * PWL + 8 * sgx) * 32;
+        ww_rep<NXS>([&](auto Kc) {
+            constexpr int k = decltype(Kc)::value;
+            if constexpr (k > 0) ux += (k & 1) ? step_odd : step_even;
+            ww_dma(rs_x, xdst + k * RXS * PWL * 32, offx + ux);
+        });
+        int ud = (y0 + rd0) * drow;
+        float* const ddst = ldsD0 + buf * DFL + (rd0 * TWL + 8 * sgd) * 32;
+        ww_rep<NDS>([&](auto Kc) {
+            constexpr int k = decltype(Kc)::value;
+            if constexpr (k > 0) ud += RDS * drow;
+            ww_dma(rs_d, ddst + k * RDS * TWL * 32, offd + ud);
+        });
     };
-    constexpr int NBA = 12;                     // B atoms per round
 
     f32x4 acc[16][2][2];                    // [position][ci block][co block]: D rows = ci 4g..4g+3, column = co l15
 #pragma unroll
@@ -170,77 +175,92 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
     const int sw = (g & 1) << 2;                                   // the tile index of a k-step is 4 * kx + g: its parity is g's
     const int chA = (((l15 >> 2) ^ sw) << 2) + (l15 & 3);          // float offset of block 0's channel in pixels with (col >> 1) even
     const int chB = (((l15 >> 2) ^ sw ^ 4) << 2) + (l15 & 3);      // ... with (col >> 1) odd
-    const int lnA = 2 * g * 32 + chA, lnB = 2 * g * 32 + chB;       // + the lane's tile (2 g pixels to the right)
+    // LDS byte addresses (without the k-step's uniform part) of patch pixel (0, c) of the lane's tile (2 g pixels to the right),
+    // block i, and of dY pixel (0, e): columns 0,1 share (col >> 1) parity, 2,3 flip it
+    const unsigned lds0 = (unsigned)(unsigned long long)lds;       // the LDS offset is the low half of the flat address
+    unsigned lx[2][4], ld[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lx[i][c] = lds0 + (unsigned)(((2 * g + c) * 32 + ((c < 2 ? chA : chB) ^ (i ? 16 : 0))) * 4);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) ld[i][e] = lds0 + (unsigned)((2 * XFL + (2 * g + e) * 32 + (chA ^ (i ? 16 : 0))) * 4);
+    }
 
-    // A atoms -- the operands of one k-step: V = B^T d B of this lane's (channel, tile) for both ci blocks (block 1 = the other half
-    // of the pixel) and M' = A' dY A'^T for both co blocks; the bias gradient is the sum of the dY values read.  6 address atoms,
-    // 40 LDS reads (immediate offsets off the six lane bases), 32 + 32 transform atoms for V, 32 for M'.
-    float V[2][2][16], M[2][2][16];             // [buffer][block][position]
-    const float* a_px[2][2] = {{lds, lds}, {lds, lds}};
-    const float* a_pd[2] = {lds, lds};
-    float a_d[2][4][4], a_y[2][4], a_t[2][4][4], a_s[2], a_r[2][2];
-    constexpr int NAA = 6 + 40 + 32 + 32 + 32;
-    auto op_atom = [&](auto Kc, int xu, int du, float bw, bool weigh, float (&Vn)[2][16], float (&Mn)[2][16]) {
-        constexpr int K = decltype(Kc)::value;
-        if constexpr (K < 6) {
-            if constexpr (K == 0) a_px[0][0] = ldsX0 + xu + lnA;
-            if constexpr (K == 1) a_px[0][1] = ldsX0 + xu + lnB;
-            if constexpr (K == 2) a_px[1][0] = ldsX0 + xu + (lnA ^ 16);
-            if constexpr (K == 3) a_px[1][1] = ldsX0 + xu + (lnB ^ 16);
-            if constexpr (K == 4) a_pd[0] = ldsD0 + du + lnA;
-            if constexpr (K == 5) a_pd[1] = ldsD0 + du + (lnA ^ 16);
-        } else if constexpr (K < 38) {              // patch pixel (r, c) of the lane's tile; columns 0,1 share (col >> 1) parity, 2,3 flip it
-            constexpr int k = K - 6, i = k >> 4, c = (k >> 2) & 3, r = k & 3;
-            a_d[i][r][c] = a_px[i][c >> 1][(r * PWL + c) * 32];
-        } else if constexpr (K < 46) {
-            constexpr int k = K - 38, o = k >> 2, e = k & 3;
-            a_y[o][e] = a_pd[o][(e >> 1) * TWL * 32 + (e & 1) * 32];
-        } else if constexpr (K < 78) {              // columns: t = B^T d
-            constexpr int k = K - 46, i = k >> 4, c = (k >> 2) & 3, r = k & 3;
-            if constexpr (r == 0) a_t[i][0][c] = a_d[i][0][c] - a_d[i][2][c];
-            if constexpr (r == 1) a_t[i][1][c] = a_d[i][1][c] + a_d[i][2][c];
-            if constexpr (r == 2) a_t[i][2][c] = a_d[i][2][c] - a_d[i][1][c];
-            if constexpr (r == 3) a_t[i][3][c] = a_d[i][1][c] - a_d[i][3][c];
-        } else if constexpr (K < 110) {             // rows: V = t B
-            constexpr int k = K - 78, i = k >> 4, r = (k >> 2) & 3, c = k & 3;
-            if constexpr (c == 0) Vn[i][r * 4 + 0] = a_t[i][r][0] - a_t[i][r][2];
-            if constexpr (c == 1) Vn[i][r * 4 + 1] = a_t[i][r][1] + a_t[i][r][2];
-            if constexpr (c == 2) Vn[i][r * 4 + 2] = a_t[i][r][2] - a_t[i][r][1];
-            if constexpr (c == 3) Vn[i][r * 4 + 3] = a_t[i][r][1] - a_t[i][r][3];
-        } else {                                    // M' rows {y0}, {y0 + y1}, {y0 - y1}, {y1} (y0 = top pixel pair, y1 = bottom), then the same along columns
-            constexpr int k = K - 110, o = k >> 4, e = k & 15;
-            const float y00 = a_y[o][0], y01 = a_y[o][1], y10 = a_y[o][2], y11 = a_y[o][3];
-            if constexpr (e == 0) a_s[0] = y00 + y01;
-            if constexpr (e == 1) a_s[1] = y10 + y11;
-            if constexpr (e == 2) a_s[0] = a_s[0] + a_s[1];
-            if constexpr (e == 3) accb[o] += weigh ? bw * a_s[0] : a_s[0];
-            if constexpr (e == 4) a_r[0][0] = y00 + y10;
-            if constexpr (e == 5) a_r[0][1] = y01 + y11;
-            if constexpr (e == 6) a_r[1][0] = y00 - y10;
-            if constexpr (e == 7) a_r[1][1] = y01 - y11;
-            if constexpr (e >= 8) {
-                constexpr int i = (e - 8) >> 1;
-                const float r0 = i == 0 ? y00 : i == 1 ? a_r[0][0] : i == 2 ? a_r[1][0] : y10;
-                const float r1 = i == 0 ? y01 : i == 1 ? a_r[0][1] : i == 2 ? a_r[1][1] : y11;
-                if constexpr ((e & 1) == 0) { Mn[o][i * 4 + 0] = r0; Mn[o][i * 4 + 1] = r0 + r1; }
-                else { Mn[o][i * 4 + 3] = r1; Mn[o][i * 4 + 2] = r0 - r1; }
-            }
-        }
+    // operands of a k-step, as register pairs.  V = B^T d B of block i: Vp[i][s][k] = (V[2s][k], V[2s+1][k]) -> positions
+    // 8 s + k and 8 s + 4 + k.  M' = A' dY A'^T of block o: Mp[o][0..3] = Ya = (y00, y10), Yb = (y01, y11), Ra = (y00 + y10,
+    // y00 - y10), Rb likewise; Mp[o][4 + r] = (row r: a + b, a - b) with rows (a, b) = (Ya.lo, Yb.lo), (Ra.lo, Rb.lo),
+    // (Ra.hi, Rb.hi), (Ya.hi, Yb.hi).  M'[4 r + 0..3] = a, a + b, a - b, b.
+    f32x2 Vp[2][2][2][4], Mp[2][2][8];      // [buffer][block]...
+    f32x2 P[2][4][2];                       // raw patch pairs [block][column][(d0, d1) | (d2, d3)]
+    // LDS reads of k-step ks = wave + 4 j of the tile in buffer `buf` (uniform float offsets xu / du): 20 ds_read2st64_b32
+    auto op_read = [&](int xu, int du, int nb) {
+        ww_rep<8>([&](auto Kc) {
+            constexpr int i = decltype(Kc)::value >> 2, c = decltype(Kc)::value & 3;
+            const unsigned ad = lx[i][c] + (unsigned)(xu * 4);
+            f32x2 &p0_ = P[i][c][0], &p1_ = P[i][c][1];
+            asm volatile("ds_read2st64_b32 %0, %2 offset0:%3 offset1:%4\n\tds_read2st64_b32 %1, %2 offset0:%5 offset1:%6"
+                         : "=&v"(p0_), "=&v"(p1_) : "v"(ad), "n"(0), "n"(PWL / 2), "n"(PWL), "n"(3 * PWL / 2));
+        });
+        ww_rep<4>([&](auto Kc) {
+            constexpr int o = decltype(Kc)::value >> 1, e = decltype(Kc)::value & 1;
+            const unsigned ad = ld[o][e] + (unsigned)(du * 4);
+            f32x2& y_ = Mp[nb][o][e];
+            asm volatile("ds_read2st64_b32 %0, %1 offset0:0 offset1:%2" : "=&v"(y_) : "v"(ad), "n"(TWL / 2));
+        });
     };
-    // LDS float offsets of k-step ks = wave + 4 j of the tile in buffer `buf`: tile (tyl, 4 kx + g) has its top-left patch pixel at
-    // (2 tyl, 8 kx + 2 g)
+    // both transforms of the operands read: 48 v_pk_add_f32 + 2 adds for the bias gradient
+    auto op_transform = [&](int nb) {
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        ww_rep<2>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            f32x2 T[2][4];                  // [rows 0,1 | rows 2,3][column]
+            ww_rep<4>([&](auto Cc) {
+                constexpr int c = decltype(Cc)::value;
+                WW_PK(T[0][c], P[i][c][0], P[i][c][1], WW_M_T01);      // (d0 - d2, d1 + d2)
+                WW_PK(T[1][c], P[i][c][0], P[i][c][1], WW_M_T23);      // (d2 - d1, d1 - d3)
+            });
+            ww_rep<2>([&](auto Sc) {
+                constexpr int s_ = decltype(Sc)::value;
+                WW_PK(Vp[nb][i][s_][0], T[s_][0], T[s_][2], WW_M_SUB);
+                WW_PK(Vp[nb][i][s_][1], T[s_][1], T[s_][2], WW_M_ADD);
+                WW_PK(Vp[nb][i][s_][2], T[s_][2], T[s_][1], WW_M_SUB);
+                WW_PK(Vp[nb][i][s_][3], T[s_][1], T[s_][3], WW_M_SUB);
+            });
+        });
+        ww_rep<2>([&](auto Oc) {
+            constexpr int o = decltype(Oc)::value;
+            WW_PK(Mp[nb][o][2], Mp[nb][o][0], Mp[nb][o][0], WW_M_SELF);
+            WW_PK(Mp[nb][o][3], Mp[nb][o][1], Mp[nb][o][1], WW_M_SELF);
+            WW_PK(Mp[nb][o][4], Mp[nb][o][0], Mp[nb][o][1], WW_M_LL);
+            WW_PK(Mp[nb][o][7], Mp[nb][o][0], Mp[nb][o][1], WW_M_HH);
+            WW_PK(Mp[nb][o][5], Mp[nb][o][2], Mp[nb][o][3], WW_M_LL);
+            WW_PK(Mp[nb][o][6], Mp[nb][o][2], Mp[nb][o][3], WW_M_HH);
+            accb[o] += Mp[nb][o][5][0];     // (y00 + y10) + (y01 + y11)
+        });
+    };
+    // MFMAs [Q0, Q0 + N) of the 64 of a k-step: A = V (M = ci), B = M' (N = co), K = the 4 tiles of the k-step.  The accumulators
+    // are pinned to the accumulation registers ("+a"): left to itself the allocator moves parts of them through the (full) vector
+    // registers and scratch.  Operands are a k-step old and an accumulator is touched once per k-step: no MFMA hazard is near.
+    auto mfmas = [&](auto Q0c, auto Nc, int cb) {
+        ww_rep<decltype(Nc)::value>([&](auto Dc) {
+            constexpr int q = decltype(Q0c)::value + decltype(Dc)::value, x = q >> 2, i = (q >> 1) & 1, o = q & 1;
+            constexpr int r = x >> 2, k = x & 3;
+            constexpr int mi = k == 0 ? (r == 0 || r == 3 ? 0 : 2) : k == 3 ? (r == 0 || r == 3 ? 1 : 3) : 4 + r;
+            constexpr int mh = k == 0 || k == 3 ? (r >= 2 ? 1 : 0) : k - 1;
+            f32x4& acc_ = acc[x][i][o];
+            const float va_ = Vp[cb][i][r >> 1][k][r & 1], vb_ = Mp[cb][o][mi][mh];
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc_) : "v"(va_), "v"(vb_));
+        });
+    };
+    // uniform LDS float offsets of k-step ks = wave + 4 j: tile (tyl, 4 kx + g) has its top-left patch pixel at (2 tyl, 8 kx + 2 g)
     auto step_xu = [&](int j, int buf) { const int ks = wave + 4 * j, tyl = ks / KPR, kx = ks - tyl * KPR; return buf * XFL + ((2 * tyl) * PWL + 8 * kx) * 32; };
     auto step_du = [&](int j, int buf) { const int ks = wave + 4 * j, tyl = ks / KPR, kx = ks - tyl * KPR; return buf * DFL + ((2 * tyl) * TWL + 8 * kx) * 32; };
+    using C0 = std::integral_constant<int, 0>;
+    using C16 = std::integral_constant<int, 16>;
+    using C32 = std::integral_constant<int, 32>;
 
-    // DMA rounds per k-step of the window a tile is fetched in (it opens behind the barrier that frees its buffer -- position 0 is
-    // the LAST k-step of the tile before the previous one -- and closes at the next barrier): front-loaded, the rounds issued
-    // last have a whole k-step (>= 2048 cycles) to land
-    constexpr int NR0 = NST == 2 ? NPIECE : 8, NR1 = NST == 2 ? 0 : 7, NR2 = NST == 2 ? 0 : NPIECE - 15;
-    static_assert(NST == 2 || NST == 4, "window");
-    static_assert(NR2 >= 0 && NR0 * NBA <= 2 * 64 + 16, "rounds per k-step");
-
-    // debug instantiation of the same loop (STAMP, AESR_WGRAD_WINO_DBG=1): cycles per wave in the k-step loop and at the barrier.
-    // Compile-time: a branch here would split the loop body into blocks and the compiler sinks the transforms across them.
+    // debug instantiation of the same loop (STAMP, AESR_WGRAD_WINO_DBG=1): cycles per wave in the k-step loop and at the barrier
     long long tph[3] = {0, 0, 0}, tq = 0;
 #define WW_STAMP(k)                                                   \
     if constexpr (STAMP) {                                            \
@@ -250,10 +270,6 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
     }
     if constexpr (STAMP) tq = (long long)__builtin_amdgcn_s_memtime();
 
-    // ---- the pipeline.  Tile v lives in buffer v & 1.  The barrier of tile v stands before its LAST k-step: by then every wave has
-    // read the last operands it needs from buffer v & 1 (they are in registers) and tile v + 1 has landed in the other buffer,
-    // so the last k-step already fetches the first operands of tile v + 1, and the DMA rounds of tile v + 2 start into buffer
-    // v & 1 right behind the barrier -- spread over k-steps, never as a burst. ----
     WwTile t0, t1, t2;
     {
         t0.n = split / tpi;
@@ -261,75 +277,45 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
         t0.ty = rem / a.tiles_x;
         t0.tx = rem - t0.ty * a.tiles_x;
         if (split >= a.ntiles) t0.n = a.N;
-        locate(t0);
     }
     t1 = advance(t0);
     t2 = advance(t1);
-    ww_for(std::make_integer_sequence<int, NPIECE>{}, [&](auto Mc) {
-        ww_for(std::make_integer_sequence<int, NBA>{}, [&](auto Kc) { dma_atom(Mc, Kc, t0, 0); });
-    });
-    ww_for(std::make_integer_sequence<int, NR0>{}, [&](auto Mc) {
-        ww_for(std::make_integer_sequence<int, NBA>{}, [&](auto Kc) { dma_atom(Mc, Kc, t1, 1); });
-    });
+    fetch(t0, 0);
+    fetch(t1, 1);
     __syncthreads();
     int buf = 0;
-    {
-        const int xu = step_xu(0, 0), du = step_du(0, 0);
-        ww_for(std::make_integer_sequence<int, NAA>{}, [&](auto Kc) { op_atom(Kc, xu, du, 1.f, false, V[0], M[0]); });
-    }
+    op_read(step_xu(0, 0), step_du(0, 0), 0);
+    op_transform(0);
     WW_STAMP(2)
     if (t0.n < a.N) do {
-        asm volatile("" : "+v"(prow));
-        ww_for(std::make_integer_sequence<int, NST>{}, [&](auto Jc) {
-            constexpr int j = decltype(Jc)::value;
-            constexpr bool LAST = j == NST - 1;
-            if constexpr (LAST) {
-                WW_STAMP(0)
-                __syncthreads();
-                WW_STAMP(1)
-            }
-            // this k-step: MFMAs on V/M[j & 1]; the operands of the next one (the first of the next tile behind the barrier) into the
-            // other pair; DMA rounds [R0, R0 + NR) of tile v + 1 (v + 2 behind the barrier)
-            constexpr int NR = LAST ? NR0 : j == 0 ? NR1 : j == 1 ? NR2 : 0;
-            constexpr int R0 = LAST ? 0 : j == 0 ? NR0 : NR0 + NR1;
-            constexpr int NB = NR * NBA;
-            const int xu = LAST ? step_xu(0, buf ^ 1) : step_xu(j + 1, buf), du = LAST ? step_du(0, buf ^ 1) : step_du(j + 1, buf);
-            const float bw = t1.n < a.N ? 1.f : 0.f;
-            const WwTile& tt = LAST ? t2 : t1;
-            const int tb = LAST ? buf : buf ^ 1;
-            __builtin_amdgcn_sched_barrier(0);
-            // groups of WW_G MFMAs, then the atoms of WW_G slots: on this chip the f32 MFMA and the vector ALU do not overlap (a filler
-            // costs its 4 issue cycles wherever it stands, scripts/micro/mfma_gap.hip) and every MFMA -> VALU switch costs ~4 more
-            ww_for(std::make_integer_sequence<int, 64 / WW_G>{}, [&](auto Qc) {
-                constexpr int q0 = decltype(Qc)::value * WW_G;
-                ww_for(std::make_integer_sequence<int, WW_G>{}, [&](auto Dc) {
-                    constexpr int q = q0 + decltype(Dc)::value, x = q >> 2, i = (q >> 1) & 1, o = q & 1;
-                    // the accumulators are pinned to the accumulation registers ("+a"): left to itself the allocator moves parts of
-                    // them through the (full) vector registers and scratch.  Operands are a k-step old and an accumulator is touched
-                    // once per k-step, so no MFMA hazard is near an asm statement.
-                    f32x4& acc_ = acc[x][i][o];
-                    const float va_ = V[j & 1][i][x], vb_ = M[j & 1][o][x];
-                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc_) : "v"(va_), "v"(vb_));
-                });
-                constexpr int A0 = q0 * NAA / 64, A1 = (q0 + WW_G) * NAA / 64;
-                ww_for(std::make_integer_sequence<int, A1 - A0>{}, [&](auto Kc) {
-                    op_atom(std::integral_constant<int, A0 + decltype(Kc)::value>{}, xu, du, bw, LAST, V[(j + 1) & 1], M[(j + 1) & 1]);
-                });
-                constexpr int B0 = q0 * NB / 64, B1 = (q0 + WW_G) * NB / 64;
-                ww_for(std::make_integer_sequence<int, B1 - B0>{}, [&](auto Kc) {
-                    constexpr int b = B0 + decltype(Kc)::value;
-                    dma_atom(std::integral_constant<int, R0 + b / NBA>{}, std::integral_constant<int, b % NBA>{}, tt, tb);
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        });
+        // k-step 0 of the tile: MFMAs on operand set 0, the operands of k-step 1 into set 1
+        __builtin_amdgcn_sched_barrier(0);
+        op_read(step_xu(1, buf), step_du(1, buf), 1);
+        mfmas(C0{}, C16{}, 0);
+        op_transform(1);
+        mfmas(C16{}, std::integral_constant<int, 48>{}, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        WW_STAMP(0)
+        __syncthreads();            // tile v + 1 has landed; nobody reads buffer `buf` any more
+        WW_STAMP(1)
+        // k-step 1: MFMAs on set 1, the first operands of the NEXT tile into set 0, the DMA of the tile after it into `buf`
+        __builtin_amdgcn_sched_barrier(0);
+        op_read(step_xu(0, buf ^ 1), step_du(0, buf ^ 1), 0);
+        mfmas(C0{}, C16{}, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(t2, buf);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(C16{}, C16{}, 1);
+        op_transform(0);
+        mfmas(C32{}, C32{}, 1);
+        __builtin_amdgcn_sched_barrier(0);
         t0 = t1;
         t1 = t2;
         t2 = advance(t2);
         buf ^= 1;
     } while (t0.n < a.N);
     WW_STAMP(0)
-    __syncthreads();            // DMA rounds still in flight (zero fills past the last tile) must land before the exchange reuses the LDS
+    __syncthreads();            // DMAs still in flight (zero fills past the last tile) must land before the exchange reuses the LDS
     if (STAMP && lane == 0)
         for (int k = 0; k < 3; ++k) a.dbgbuf[(blockIdx.x * 4 + wave) * 3 + k] = (float)tph[k];
 
@@ -409,17 +395,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
 }
 
 size_t aesr_wgrad_wino_lds_bytes(int TH, int TW) {
-    const size_t xfl = ((size_t)(TH + 2) * round_up(TW + 2, 4) * 32 + 1023) & ~(size_t)1023;
-    const size_t dfl = ((size_t)TH * round_up(TW, 4) * 32 + 1023) & ~(size_t)1023;
+    const size_t xfl = (size_t)(TH + 2) * (TW == 8 ? 16 : 32) * 32, dfl = (size_t)TH * TW * 32;
     const size_t bufs = 2 * (xfl + dfl) * sizeof(float);
     const size_t exch = ((size_t)3 * 36 * 64 * 4 + 3 * 32) * sizeof(float);
     return bufs > exch ? bufs : exch;
 }
 
-// the tiles the kernel is built for: (TH / 2) * (TW / 8) k-steps a multiple of 8, both double buffers within 160 KB
-bool aesr_wgrad_wino_tile_ok(int TH, int TW) {
-    return (TH == 16 && TW == 8) || (TH == 8 && TW == 16) || (TH == 16 && TW == 16) || (TH == 4 && TW == 32) || (TH == 8 && TW == 32);
-}
+// the tiles the kernel is built for: 8 k-steps ((TH / 2) * (TW / 8)), rows of whole 8-pixel DMA segments split evenly over 4 waves
+bool aesr_wgrad_wino_tile_ok(int TH, int TW) { return (TH == 16 && TW == 8) || (TH == 8 && TW == 16); }
 
 template <int TH, int TW>
 static int launch_wgrad_wino(const WgradArgs& a, hipStream_t st) {
@@ -471,7 +454,7 @@ int aesr_launch_conv_wgrad_wino(const WgradArgs& a, hipStream_t st) {
         return AESR_ERR_ARG;
     }
     if (!aesr_wgrad_wino_tile_ok(a.TH, a.TW) || a.pad != 1 || a.Ho != a.H || a.Wo != a.W) {
-        aesr_set_error("conv_wgrad_wino: tile %dx%d is not one of 16x8, 8x16, 16x16, 4x32, 8x32 (or not 3x3 / padding 1)", a.TH, a.TW);
+        aesr_set_error("conv_wgrad_wino: tile %dx%d is not 16x8 or 8x16 (or not 3x3 / padding 1)", a.TH, a.TW);
         return AESR_ERR_ARG;
     }
     if (a.CinP % 32 != 0 || a.CoutP % 32 != 0 || a.Cin != a.CinP || a.Cout != a.CoutP || a.S < 1 || a.S > a.ntiles ||
@@ -479,9 +462,6 @@ int aesr_launch_conv_wgrad_wino(const WgradArgs& a, hipStream_t st) {
         aesr_set_error("conv_wgrad_wino: channel counts must be multiples of 32 and the tile grid consistent (S=%d, %d tiles)", a.S, a.ntiles);
         return AESR_ERR_ARG;
     }
-    if (a.TH == 16 && a.TW == 8) return launch_wgrad_wino<16, 8>(a, st);
-    if (a.TH == 8 && a.TW == 16) return launch_wgrad_wino<8, 16>(a, st);
-    if (a.TH == 16 && a.TW == 16) return launch_wgrad_wino<16, 16>(a, st);
-    if (a.TH == 4 && a.TW == 32) return launch_wgrad_wino<4, 32>(a, st);
-    return launch_wgrad_wino<8, 32>(a, st);
+    if (a.TH == 16) return launch_wgrad_wino<16, 8>(a, st);
+    return launch_wgrad_wino<8, 16>(a, st);
 }
