@@ -31,8 +31,12 @@ struct WinoArgs {
     int flags;                   // experiment switches (AESR_WINO_FLAGS)
     int in_up2;                  // the input is stored at half resolution: pixel (y, x) reads (y/2, x/2) (nearest Upsample x2 folded in)
     int out_sum2;                // store the sum of every 2x2 output tile at half resolution (adjoint of that Upsample)
+    int bpi, nblk;               // resident-filter kernel (conv_wino_res.hip): 8x8-output blocks per image / in all, filled by its launcher
+    unsigned m_bpi;              // ceil(2^32 / bpi) (0: bpi == 1)
 };
 int aesr_launch_conv_wino(const WinoArgs& a, hipStream_t st);
+bool aesr_wino_res_ok(const WinoArgs& a);                        // few input channels: the filter stays resident, waves run on their own
+int aesr_launch_conv_wino_res(const WinoArgs& a, hipStream_t st);
 size_t aesr_wino_lds_bytes(int patch_pixels);
 
 #define PACK_MAX_JOBS 32

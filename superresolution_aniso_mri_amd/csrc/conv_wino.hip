@@ -527,6 +527,7 @@ int aesr_launch_conv_wino(const WinoArgs& a_in, hipStream_t st) {
         aesr_set_error("conv_wino: tile dimensions exceed the packed-coordinate range");
         return AESR_ERR_ARG;
     }
+    if (aesr_wino_res_ok(a)) return aesr_launch_conv_wino_res(a, st);      // Cin <= 32: resident filter, independent waves (conv_wino_res.hip)
     a.regs_y = ceil_div(ceil_div(a.H, 2), a.THt);
     a.regs_x = ceil_div(ceil_div(a.W, 2), a.TWt);
     a.nitems = ceil_div(a.N, a.TI) * a.regs_y * a.regs_x * (a.CoutP / WN_TN);

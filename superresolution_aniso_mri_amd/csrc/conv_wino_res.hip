@@ -1,0 +1,325 @@
+// Winograd F(2x2, 3x3) convolution for layers with FEW input channels (Cin <= 32): the transformed filter stays resident in LDS
+// and every wave runs on its own -- no barrier after the prologue.
+//
+// The general kernel (conv_wino.hip) streams 16-channel chunks of patch + U through LDS for an 8-wave work item and meets at a
+// barrier per chunk.  With Cin = 32 an item is only 2 chunks long, so the item epilogue (output transform, activation, stores,
+// re-zeroing 128 accumulators, the next item's address work) -- during which all 8 waves leave the matrix pipe idle TOGETHER --
+// was 30 % of the kernel (AESR_WINO_DBG stamps: 7.9 k of 27 k cycles per item), and on gfx950 the f32 MFMA shares its pipe with the
+// vector ALU (scripts/micro/mfma_gap.hip), so nothing hides inside a wave either.  Here:
+//  * all of U for the workgroup's 32 output channels (<= 2 chunks = 64 KB) is loaded ONCE per workgroup; workgroup b serves the
+//    cout tile b % ncot for its whole life;
+//  * a work item belongs to ONE wave: 4 x 4 Winograd tiles (8 x 8 outputs) x 32 output channels, the same 128 accumulators per
+//    wave as in conv_wino.hip.  The wave fetches its own 10 x 10-pixel patch by DMA (buffer_load ... lds, one instruction per
+//    patch row of 16 pixel slots, 4 instructions of address work each) into its own 10 KB of LDS and waits only on its own
+//    vmcnt: the patch buffer is free again as soon as its 16 ds_read_b128 have returned (the raw tile lives in registers while
+//    it is transformed), so the NEXT chunk's patch is requested before this chunk's 128 MFMAs start -- single buffered, a whole
+//    chunk of matrix work ahead;
+//  * the two waves of a SIMD drift apart (the older one is served first), so one's epilogue, stores and mask loads run beside
+//    the other's MFMAs without any scheduling effort;
+//  * patch rows are pitched 1040 B and the DMA source swaps channel quads q <-> q ^ 1 in pixels 4..7 and 12..15 of a row: the
+//    16 lanes of a ds_read_b128 phase (16 tiles, one channel quad) then hit 16 different 16-byte bank groups -- conflict free
+//    (conv_wino.hip pays 4-way conflicts for its register-free DMA).
+// Everything else (U packing, the per-lane transforms, the bias in the accumulator of position (1,1), the derivative mask, the
+// folded Upsample in both directions) is conv_wino.hip's; results are bit-identical in exact arithmetic and equal to rounding.
+//
+// Replaces the ATen/cuDNN conv2d calls behind networks/acai_vanilla.py:55-56,87-88,96 (the 32-channel layers) forward and as
+// data gradient.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "aesr_kernels.h"
+
+constexpr int WR_NT = 512;          // threads per workgroup: 8 independent waves, 2 per SIMD
+constexpr int WR_TN = 32;           // output channels of a workgroup
+constexpr int WR_NB = 2;
+constexpr int WR_WFL = 16 * 4 * WR_TN * 4;      // floats of one U chunk (16 positions x 16 ci x 32 co) = 8192
+constexpr int WR_RP = 260;          // floats between patch rows: 16 pixel slots x 16 channels + 4 (shifts a row by one 16-byte bank group)
+constexpr int WR_PFL = 10 * WR_RP;  // floats of a wave's patch buffer (10 rows)
+constexpr int WR_OOB = 0x70000000;
+
+__device__ __forceinline__ void wr_dma(__amdgpu_buffer_rsrc_t rs, float* lds_wave_base, int byte_off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, byte_off, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 wr_ld(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+}
+__device__ __forceinline__ void wr_st(__amdgpu_buffer_rsrc_t rs, int byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), rs, byte_off, 0, 0);
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int ncot = a.CoutP / WR_TN, nchunks = a.CinP >> 4;
+    const int cot = blockIdx.x % ncot, wgc = blockIdx.x / ncot, nwgc = gridDim.x / ncot;
+    const int co0 = cot * WR_TN;
+    float* const ldsW = lds;                                        // [nchunks][16 positions][4][32][4]
+    float* const ldsP = lds + nchunks * WR_WFL + wave * WR_PFL;     // this wave's patch: [10 rows][16 pixel slots][16 ch] (+ pitch)
+    float* const ldsBias = lds + nchunks * WR_WFL + 8 * WR_PFL;     // [32]
+
+    const int sh = a.in_up2 ? 1 : 0;
+    const int inH = a.H >> sh, inW = a.W >> sh;                                              // stored size of the input tensor
+    const int outH = a.out_sum2 ? a.H >> 1 : a.H, outW = a.out_sum2 ? a.W >> 1 : a.W;        // stored size of the output tensor
+    const int inimg = inH * inW * a.Cin * 4, inrow = inW * a.Cin * 4;                        // bytes of an input image / row
+    // (sizes through readfirstlane: a 64-bit product lands in vector registers, and a resource there costs a waterfall loop per access)
+    const int wbytes = __builtin_amdgcn_readfirstlane(16 * a.CinP * a.CoutP * 4);
+    const int obytes = __builtin_amdgcn_readfirstlane(a.N * outH * outW * a.Cout * 4), ybytes = __builtin_amdgcn_readfirstlane(a.N * a.H * a.W * a.Cout * 4);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.upk, 0, wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, obytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ys = __builtin_amdgcn_make_buffer_rsrc((void*)(MASK ? a.ysave : a.out), 0, ybytes, 0x00020000);
+
+    // ---- prologue: the workgroup's U block(s) and bias, once ----
+    if (tid < WR_TN) ldsBias[tid] = (a.bias && co0 + tid < a.Cout) ? a.bias[co0 + tid] : 0.f;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const int wbase = (int)(((size_t)cc * ncot + cot) * (WR_WFL * 4));
+#pragma unroll
+        for (int j = 0; j < WR_WFL / 4 / WR_NT; ++j) wr_dma(rs_w, ldsW + cc * WR_WFL + j * (WR_NT * 4) + wave * 256, wbase + (tid + WR_NT * j) * 16);
+    }
+
+    // ---- per-lane maps ----
+    // DMA: lane -> pixel slot lane >> 2 of a patch row, channel quad (lane & 3) ^ ((slot >> 2) & 1)
+    const int dpx = lane >> 2, dq = (lane & 3) ^ ((dpx >> 2) & 1);
+    const int lcd = (((dpx - sh) >> sh) * a.Cin + 4 * dq) * 4;          // bytes from (row start + item column origin); arithmetic shift: -1 stays -1
+    // MFMA B operand: lane -> tile l15 = (ty, tx) of the 4 x 4 block, channel quad g; patch pixel (2 ty + i, 2 tx + j)
+    const int ty = l15 >> 2, tx = l15 & 3;
+    const int offA = (2 * ty) * WR_RP + (2 * tx) * 16 + ((g ^ (tx >> 1)) << 2);                  // columns j = 0, 1
+    const int offB = (2 * ty) * WR_RP + (2 * tx) * 16 + ((g ^ (((2 * tx + 2) >> 2) & 1)) << 2);  // columns j = 2, 3
+    const float* wbl = ldsW + (g * WR_TN + l15) * 4;                    // + chunk * WFL + xi * 512 + nb * 64
+
+    const float mslope = a.mask_act == ACT_LRELU ? a.slope : (a.mask_act == ACT_RELU ? 0.f : 1.f);
+    const float nslope = a.act == ACT_LRELU ? a.slope : (a.act == ACT_RELU ? 0.f : 1.f);      // ACT_NONE / ACT_SIGMOID: identity
+    const bool sigm = a.act == ACT_SIGMOID;
+
+    // item k of this wave: block wgc + nwgc * (wave + 8 k) of the N x BY x BX blocks of 8 x 8 outputs (a partial last round lands on
+    // wave 0 of many workgroups, not on all waves of a few)
+#define WR_DIV(x, m) ((m) ? (int)__umulhi((unsigned)(x), (m)) : (int)(x))          /* m == 0: divisor 1 */
+    int item = wgc + nwgc * wave;
+    const int istep = nwgc * 8;
+    // the patch of (item, chunk) -> this wave's LDS buffer: 10 DMAs; out-of-range rows / columns deliver zeros
+    int in_n = 0, in_y0 = 0, in_x0 = 0;
+    auto locate = [&](int it) {
+        in_n = WR_DIV(it, a.m_bpi);
+        const int rem = it - in_n * a.bpi;
+        const int by = WR_DIV(rem, a.m_regs_x);
+        in_y0 = by * 8;
+        in_x0 = (rem - by * a.regs_x) * 8;
+    };
+    auto fetch = [&](int, int cc) {
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in + (size_t)in_n * inimg), 0, inimg, 0x00020000);
+        const unsigned gx = (unsigned)(in_x0 - 1 + dpx);
+        const int off = (dpx < 10 && gx < (unsigned)a.W && cc * 16 + 4 * dq < a.Cin) ? lcd + ((in_x0 >> sh) - 1 + sh) * a.Cin * 4 + cc * 64 : WR_OOB;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const int urow = ((in_y0 - 1 + r) >> sh) * inrow;           // row -1 stays -1: outside the image's resource
+            wr_dma(rs_in, ldsP + r * WR_RP, off + urow);
+        }
+    };
+    if (item < a.nblk) {
+        locate(item);
+        fetch(item, 0);
+    }
+    __syncthreads();            // U and bias are in LDS (every wave waited for its own part); the only barrier of the kernel
+
+    f32x4 acc[16][WR_NB];
+#define WR_INIT_ACC()                                                                                  \
+    {                                                                                                  \
+        _Pragma("unroll") for (int x = 0; x < 16; ++x)                                                 \
+            _Pragma("unroll") for (int nb = 0; nb < WR_NB; ++nb) acc[x][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; \
+        _Pragma("unroll") for (int nb = 0; nb < WR_NB; ++nb) acc[5][nb] = *(const f32x4*)(ldsBias + nb * 16 + 4 * g); \
+    }
+    WR_INIT_ACC()
+
+    int cc = 0;
+    bool after_stores = false;
+    while (item < a.nblk) {
+        // ---- the 4x4 input pixels of this lane's tile, 4 channels each ----
+        // the DMAs of this patch are the oldest outstanding memory operations; the previous item's stores may still be in flight
+        if (after_stores) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        f32x4 t[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[i][j] = *(const f32x4*)(ldsP + (j < 2 ? offA : offB) + i * WR_RP + j * 16);
+        const float* wb = wbl + cc * WR_WFL;
+        f32x4 wnx[WR_NB];
+#pragma unroll
+        for (int nb = 0; nb < WR_NB; ++nb) wnx[nb] = *(const f32x4*)(wb + nb * 64);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the patch is in registers: request the next one (next chunk, or chunk 0 of the next item) into the same buffer
+        const int cur_item = item, cur_n = in_n, cur_y0 = in_y0, cur_x0 = in_x0;
+        const bool last = cc + 1 == nchunks;
+        if (last) {
+            item += istep;
+            if (item < a.nblk) {
+                locate(item);
+                fetch(item, 0);
+            }
+        } else {
+            fetch(item, cc + 1);
+        }
+        (void)cur_item;
+        // row half of the transform (B^T d)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 d0 = t[0][j], d1 = t[1][j], d2 = t[2][j], d3 = t[3][j];
+            t[0][j] = d0 + (-d2);
+            t[1][j] = d1 + d2;
+            t[2][j] = d2 + (-d1);
+            t[3][j] = d1 + (-d3);
+        }
+        // column half, one position ahead of the MFMAs that consume it: V[i][j] = (t[i] B)[j]
+#define WR_V(i, j) ((j) == 0 ? t[i][0] + (-t[i][2]) : (j) == 1 ? t[i][1] + t[i][2] : (j) == 2 ? t[i][2] + (-t[i][1]) : t[i][1] + (-t[i][3]))
+        f32x4 vnx = WR_V(0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xi = i * 4 + j;
+                f32x4 wc[WR_NB];
+#pragma unroll
+                for (int nb = 0; nb < WR_NB; ++nb) wc[nb] = wnx[nb];
+                const f32x4 vc = vnx;
+                if (xi + 1 < 16) {
+#pragma unroll
+                    for (int nb = 0; nb < WR_NB; ++nb) wnx[nb] = *(const f32x4*)(wb + (xi + 1) * (4 * WR_TN * 4) + nb * 64);
+                    vnx = WR_V((xi + 1) >> 2, (xi + 1) & 3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nb = 0; nb < WR_NB; ++nb)
+                        acc[xi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nb][r], vc[r], acc[xi][nb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef WR_V
+        after_stores = false;
+        if (!last) {
+            ++cc;
+            continue;
+        }
+        cc = 0;
+        // ---- item finished: output transform Y = A^T M A, activation, (data gradient) derivative mask, store ----------
+        {
+            const int y0 = cur_y0 + 2 * ty, x0 = cur_x0 + 2 * tx;
+            int ob[2][2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    ob[p][q] = (y0 + p < a.H && x0 + q < a.W) ? ((cur_n * a.H + y0 + p) * a.W + x0 + q) * a.Cout * 4 : WR_OOB;
+#pragma unroll
+            for (int nb = 0; nb < WR_NB; ++nb) {
+                const int co = co0 + nb * 16 + 4 * g;
+                const int cob = co < a.Cout ? co * 4 : WR_OOB;
+                f32x4 ys[2][2];
+                if (MASK) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) ys[p][q] = wr_ld(rs_ys, ob[p][q] + cob);
+                }
+                f32x4 P[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    P[0][j] = acc[0 + j][nb] + acc[4 + j][nb] + acc[8 + j][nb];
+                    P[1][j] = acc[4 + j][nb] - acc[8 + j][nb] - acc[12 + j][nb];
+                }
+                if (a.out_sum2) {
+                    // adjoint of the nearest Upsample(x2) in front of this layer's forward: the 2x2 tile collapses to one pixel
+                    const f32x4 s = (P[0][0] + P[1][0]) + 2.f * (P[0][1] + P[1][1]) - (P[0][3] + P[1][3]);
+                    const int obs = (y0 < a.H && x0 < a.W) ? ((cur_n * outH + (y0 >> 1)) * outW + (x0 >> 1)) * a.Cout * 4 : WR_OOB;
+                    wr_st(rs_out, obs + cob, s);
+                    continue;
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    f32x4 Y[2];
+                    Y[0] = P[p][0] + P[p][1] + P[p][2];
+                    Y[1] = P[p][1] - P[p][2] - P[p][3];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        f32x4 o = Y[q];
+                        // none / ReLU / LeakyReLU as ONE branch-free form: max(x, x * slope) for 0 <= slope <= 1
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], o[e] * nslope);
+                        if (sigm) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = 1.f / (1.f + expf(-o[e]));
+                        }
+                        if (MASK) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] *= (ys[p][q][e] > 0.f ? 1.f : mslope);
+                        }
+                        wr_st(rs_out, ob[p][q] + cob, o);
+                    }
+                }
+            }
+        }
+        after_stores = !MASK && !a.out_sum2;        // exactly 8 stores follow the next patch's DMAs (the mask loads were waited for)
+        WR_INIT_ACC()
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no DMA may still be writing this workgroup's LDS when it is released
+#undef WR_INIT_ACC
+#undef WR_DIV
+}
+
+size_t aesr_wino_res_lds_bytes(int CinP) { return ((size_t)(CinP >> 4) * WR_WFL + 8 * WR_PFL + WR_TN) * sizeof(float); }
+
+bool aesr_wino_res_ok(const WinoArgs& a) {
+    static const bool enabled = !(getenv("AESR_WINO_RES") && atoi(getenv("AESR_WINO_RES")) == 0);
+    return enabled && a.CinP <= 32 && a.CinP % 16 == 0 && a.CoutP % WR_TN == 0 && a.CoutP / WR_TN <= 256;
+}
+
+template <bool MASK>
+static int wino_res_launch_one(const WinoArgs& a, hipStream_t st) {
+    const size_t shmem = aesr_wino_res_lds_bytes(a.CinP);
+    static bool attr_set[AESR_MAX_DEVICES] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= AESR_MAX_DEVICES) dev_ = 0;
+    if (!attr_set[dev_]) {
+        const hipError_t e_ = hipFuncSetAttribute((const void*)conv_wino_res_f32<MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e_ != hipSuccess) {
+            aesr_set_error("conv_wino_res_f32: hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KB) failed: %s", hipGetErrorString(e_));
+            return AESR_ERR_HIP;
+        }
+        attr_set[dev_] = true;
+    }
+    const int ncot = a.CoutP / WR_TN;
+    int grid = 256 / ncot * ncot;                          // one workgroup per CU, a whole number of them per cout tile
+    if (const char* e = getenv("AESR_WINO_GRID")) grid = atoi(e) / ncot * ncot;
+    const int per_cot = ceil_div(a.nblk, 8);               // more workgroups than 8-wave rounds of blocks would idle
+    if (grid / ncot > per_cot) grid = per_cot * ncot;
+    if (grid < ncot) grid = ncot;
+    hipLaunchKernelGGL((conv_wino_res_f32<MASK>), dim3(grid), dim3(WR_NT), shmem, st, a);
+    AESR_LAUNCH_CHECK("conv_wino_res_f32");
+    return AESR_OK;
+}
+
+// called by aesr_launch_conv_wino (which has validated the arguments) when aesr_wino_res_ok(a)
+int aesr_launch_conv_wino_res(const WinoArgs& a_in, hipStream_t st) {
+    WinoArgs a = a_in;
+    a.TI = 1; a.THt = 4; a.TWt = 4;
+    a.regs_y = ceil_div(a.H, 8);
+    a.regs_x = ceil_div(a.W, 8);
+    a.bpi = a.regs_y * a.regs_x;
+    a.nblk = a.N * a.bpi;
+    a.nitems = a.nblk * (a.CoutP / WR_TN);
+    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((((unsigned long long)1 << 32) + d - 1) / d); };
+    a.m_bpi = magic(a.bpi); a.m_regs_x = magic(a.regs_x);
+    // the wave's item index runs up to nblk + 8 * 256 past the end before it is compared: exactness of the multiply-high division
+    if (((unsigned long long)a.nblk + 4096) * (unsigned)(a.bpi + a.regs_x) >= ((unsigned long long)1 << 31) || (size_t)a.H * a.W * a.Cin * 4 >= (size_t)0x10000000) {
+        aesr_set_error("conv_wino_res: %d blocks exceed the exact range of the item decomposition (or images of 256 MB and more)", a.nblk);
+        return AESR_ERR_UNSUPPORTED;
+    }
+    if (aesr_wino_res_lds_bytes(a.CinP) > (size_t)160 * 1024) {
+        aesr_set_error("conv_wino_res: %d input channels do not fit the resident filter", a.CinP);
+        return AESR_ERR_ARG;
+    }
+    return a.ysave ? wino_res_launch_one<true>(a, st) : wino_res_launch_one<false>(a, st);
+}
