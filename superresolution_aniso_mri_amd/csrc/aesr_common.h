@@ -4,6 +4,21 @@
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// a - b on four floats as TWO v_pk_add_f32 with the negate modifiers: the compiler turns every vector subtraction into four
+// scalar v_sub_f32 (it only packs additions), and beside f32 MFMAs every vector instruction costs matrix-pipe time
+// (scripts/micro/mfma_gap.hip).  Bit-identical to the scalar subtraction.
+__device__ __forceinline__ f32x4 aesr_sub4(f32x4 a, f32x4 b) {
+#ifdef __HIP_DEVICE_COMPILE__
+    const f32x2_t alo = a.xy, ahi = a.zw, blo = b.xy, bhi = b.zw;
+    f32x2_t rlo, rhi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(rlo) : "v"(alo), "v"(blo));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(rhi) : "v"(ahi), "v"(bhi));
+    return (f32x4){rlo.x, rlo.y, rhi.x, rhi.y};
+#else
+    return a - b;           // host pass of the single-source compile: never executed
+#endif
+}
 
 #define AESR_OK 0
 #define AESR_ERR_ARG 1

@@ -27,6 +27,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "aesr_kernels.h"
 
 constexpr int WR_NT = 512;          // threads per workgroup: 8 independent waves, 2 per SIMD
@@ -124,14 +126,6 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
     __syncthreads();            // U and bias are in LDS (every wave waited for its own part); the only barrier of the kernel
 
     f32x4 acc[16][WR_NB];
-#define WR_INIT_ACC()                                                                                  \
-    {                                                                                                  \
-        _Pragma("unroll") for (int x = 0; x < 16; ++x)                                                 \
-            _Pragma("unroll") for (int nb = 0; nb < WR_NB; ++nb) acc[x][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; \
-        _Pragma("unroll") for (int nb = 0; nb < WR_NB; ++nb) acc[5][nb] = *(const f32x4*)(ldsBias + nb * 16 + 4 * g); \
-    }
-    WR_INIT_ACC()
-
     int cc = 0;
     bool after_stores = false;
     while (item < a.nblk) {
@@ -166,37 +160,46 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x4 d0 = t[0][j], d1 = t[1][j], d2 = t[2][j], d3 = t[3][j];
-            t[0][j] = d0 + (-d2);
+            t[0][j] = aesr_sub4(d0, d2);
             t[1][j] = d1 + d2;
-            t[2][j] = d2 + (-d1);
-            t[3][j] = d1 + (-d3);
+            t[2][j] = aesr_sub4(d2, d1);
+            t[3][j] = aesr_sub4(d1, d3);
         }
-        // column half, one position ahead of the MFMAs that consume it: V[i][j] = (t[i] B)[j]
-#define WR_V(i, j) ((j) == 0 ? t[i][0] + (-t[i][2]) : (j) == 1 ? t[i][1] + t[i][2] : (j) == 2 ? t[i][2] + (-t[i][1]) : t[i][1] + (-t[i][3]))
-        f32x4 vnx = WR_V(0, 0);
+        // column half, one position ahead of the MFMAs that consume it: V[i][j] = (t[i] B)[j].  In the FIRST chunk of an item the
+        // MFMA of each accumulator's first use takes 0 (the bias in position (1,1)) as its C operand: nothing is zeroed between items
+#define WR_V(i, j) ((j) == 0 ? aesr_sub4(t[i][0], t[i][2]) : (j) == 1 ? t[i][1] + t[i][2] : (j) == 2 ? aesr_sub4(t[i][2], t[i][1]) : aesr_sub4(t[i][1], t[i][3]))
+        auto positions = [&](auto firstc) {
+            constexpr bool FIRST = decltype(firstc)::value;
+            f32x4 vnx = WR_V(0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int xi = i * 4 + j;
-                f32x4 wc[WR_NB];
+                for (int j = 0; j < 4; ++j) {
+                    const int xi = i * 4 + j;
+                    f32x4 wc[WR_NB];
 #pragma unroll
-                for (int nb = 0; nb < WR_NB; ++nb) wc[nb] = wnx[nb];
-                const f32x4 vc = vnx;
-                if (xi + 1 < 16) {
+                    for (int nb = 0; nb < WR_NB; ++nb) wc[nb] = wnx[nb];
+                    const f32x4 vc = vnx;
+                    if (xi + 1 < 16) {
 #pragma unroll
-                    for (int nb = 0; nb < WR_NB; ++nb) wnx[nb] = *(const f32x4*)(wb + (xi + 1) * (4 * WR_TN * 4) + nb * 64);
-                    vnx = WR_V((xi + 1) >> 2, (xi + 1) & 3);
+                        for (int nb = 0; nb < WR_NB; ++nb) wnx[nb] = *(const f32x4*)(wb + (xi + 1) * (4 * WR_TN * 4) + nb * 64);
+                        vnx = WR_V((xi + 1) >> 2, (xi + 1) & 3);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int nb = 0; nb < WR_NB; ++nb) {
+                            f32x4 c = acc[xi][nb];
+                            if (FIRST && r == 0) c = xi == 5 ? *(const f32x4*)(ldsBias + nb * 16 + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                            acc[xi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nb][r], vc[r], c, 0, 0, 0);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int nb = 0; nb < WR_NB; ++nb)
-                        acc[xi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nb][r], vc[r], acc[xi][nb], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
             }
-        }
+        };
+        if (cc == 0) positions(std::true_type{});
+        else positions(std::false_type{});
 #undef WR_V
         after_stores = false;
         if (!last) {
@@ -228,11 +231,11 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     P[0][j] = acc[0 + j][nb] + acc[4 + j][nb] + acc[8 + j][nb];
-                    P[1][j] = acc[4 + j][nb] - acc[8 + j][nb] - acc[12 + j][nb];
+                    P[1][j] = aesr_sub4(aesr_sub4(acc[4 + j][nb], acc[8 + j][nb]), acc[12 + j][nb]);
                 }
                 if (a.out_sum2) {
                     // adjoint of the nearest Upsample(x2) in front of this layer's forward: the 2x2 tile collapses to one pixel
-                    const f32x4 s = (P[0][0] + P[1][0]) + 2.f * (P[0][1] + P[1][1]) - (P[0][3] + P[1][3]);
+                    const f32x4 s = aesr_sub4((P[0][0] + P[1][0]) + 2.f * (P[0][1] + P[1][1]), P[0][3] + P[1][3]);
                     const int obs = (y0 < a.H && x0 < a.W) ? ((cur_n * outH + (y0 >> 1)) * outW + (x0 >> 1)) * a.Cout * 4 : WR_OOB;
                     wr_st(rs_out, obs + cob, s);
                     continue;
@@ -241,13 +244,14 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
                 for (int p = 0; p < 2; ++p) {
                     f32x4 Y[2];
                     Y[0] = P[p][0] + P[p][1] + P[p][2];
-                    Y[1] = P[p][1] - P[p][2] - P[p][3];
+                    Y[1] = aesr_sub4(aesr_sub4(P[p][1], P[p][2]), P[p][3]);
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         f32x4 o = Y[q];
                         // none / ReLU / LeakyReLU as ONE branch-free form: max(x, x * slope) for 0 <= slope <= 1
+                        const f32x4 os = o * nslope;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], o[e] * nslope);
+                        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], os[e]);
                         if (sigm) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] = 1.f / (1.f + expf(-o[e]));
@@ -262,10 +266,8 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
             }
         }
         after_stores = !MASK && !a.out_sum2;        // exactly 8 stores follow the next patch's DMAs (the mask loads were waited for)
-        WR_INIT_ACC()
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no DMA may still be writing this workgroup's LDS when it is released
-#undef WR_INIT_ACC
 #undef WR_DIV
 }
 
