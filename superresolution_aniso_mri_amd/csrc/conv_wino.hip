@@ -35,6 +35,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "aesr_kernels.h"
 
 constexpr int WN_S = 16;            // LDS floats per patch pixel: 16 channels, no padding (the DMA destination is lane-linear)
@@ -228,42 +230,48 @@ __global__ __launch_bounds__(WN_NT, 2) void conv_wino_f32(WinoArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x4 d0 = t[0][j], d1 = t[1][j], d2 = t[2][j], d3 = t[3][j];
-                t[0][j] = d0 - d2;
+                t[0][j] = aesr_sub4(d0, d2);
                 t[1][j] = d1 + d2;
-                t[2][j] = d2 - d1;
-                t[3][j] = d1 - d3;
+                t[2][j] = aesr_sub4(d2, d1);
+                t[3][j] = aesr_sub4(d1, d3);
             }
             // column half of the transform, one position ahead of the MFMAs that consume it: V[i][j] = (t[i] B)[j]
-#define WN_V(i, j) ((j) == 0 ? t[i][0] - t[i][2] : (j) == 1 ? t[i][1] + t[i][2] : (j) == 2 ? t[i][2] - t[i][1] : t[i][1] - t[i][3])
-            f32x4 vnx = WN_V(0, 0);
+#define WN_V(i, j) ((j) == 0 ? aesr_sub4(t[i][0], t[i][2]) : (j) == 1 ? t[i][1] + t[i][2] : (j) == 2 ? aesr_sub4(t[i][2], t[i][1]) : aesr_sub4(t[i][1], t[i][3]))
+            // (taking 0 / the bias as the C operand in the first chunk of an item instead of zeroing the accumulators -- what
+            // conv_wino_res.hip does -- needs a second copy of this block: 4-17 registers spilled here, where the staging maps live)
+            auto positions = [&]() {
+                f32x4 vnx = WN_V(0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int xi = i * 4 + j;
-                    // software pipeline, pinned with sched_barrier: the weight fragments and the transformed operand of position
-                    // xi + 1 are produced BEFORE the 8 MFMAs of position xi (left alone, the scheduler sinks the LDS reads to
-                    // just before their first use); inside the two groups the compiler's own order is kept (a fully
-                    // hand-interleaved order pinned per MFMA and a
-                    // sched_group_barrier deal-out both measured 0-3 % slower: profiles/r02_wino_experiments.txt)
-                    f32x4 wc[WN_NB];
+                    for (int j = 0; j < 4; ++j) {
+                        const int xi = i * 4 + j;
+                        // software pipeline, pinned with sched_barrier: the weight fragments and the transformed operand of position
+                        // xi + 1 are produced BEFORE the 8 MFMAs of position xi (left alone, the scheduler sinks the LDS reads to
+                        // just before their first use); inside the two groups the compiler's own order is kept (a fully
+                        // hand-interleaved order pinned per MFMA and a sched_group_barrier deal-out both measured 0-3 % slower:
+                        // profiles/r02_wino_experiments.txt)
+                        f32x4 wc[WN_NB];
 #pragma unroll
-                    for (int nb = 0; nb < WN_NB; ++nb) wc[nb] = wnx[nb];
-                    const f32x4 vc = vnx;
-                    if (xi + 1 < 16) {
+                        for (int nb = 0; nb < WN_NB; ++nb) wc[nb] = wnx[nb];
+                        const f32x4 vc = vnx;
+                        if (xi + 1 < 16) {
 #pragma unroll
-                        for (int nb = 0; nb < WN_NB; ++nb) wnx[nb] = *(const f32x4*)(wb + (xi + 1) * (4 * WN_TN * 4) + nb * 64);
-                        vnx = WN_V((xi + 1) >> 2, (xi + 1) & 3);
+                            for (int nb = 0; nb < WN_NB; ++nb) wnx[nb] = *(const f32x4*)(wb + (xi + 1) * (4 * WN_TN * 4) + nb * 64);
+                            vnx = WN_V((xi + 1) >> 2, (xi + 1) & 3);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int nb = 0; nb < WN_NB; ++nb) {
+                                acc[xi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nb][r], vc[r], acc[xi][nb], 0, 0, 0);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int nb = 0; nb < WN_NB; ++nb)
-                            acc[xi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nb][r], vc[r], acc[xi][nb], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
-            }
+            };
+            positions();
 #undef WN_V
         }
         WN_STAMP(0)
@@ -314,12 +322,12 @@ __global__ __launch_bounds__(WN_NT, 2) void conv_wino_f32(WinoArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     P[0][j] = acc[0 + j][nb] + acc[4 + j][nb] + acc[8 + j][nb];
-                    P[1][j] = acc[4 + j][nb] - acc[8 + j][nb] - acc[12 + j][nb];
+                    P[1][j] = aesr_sub4(aesr_sub4(acc[4 + j][nb], acc[8 + j][nb]), acc[12 + j][nb]);
                 }
                 if (a.out_sum2) {
                     // adjoint of the nearest Upsample(x2) in front of this layer's forward: the 2x2 tile collapses to one pixel
                     // (the sum of A^T M A over its four entries = the corner combination below); no activation, no mask
-                    const f32x4 s = (P[0][0] + P[1][0]) + 2.f * (P[0][1] + P[1][1]) - (P[0][3] + P[1][3]);
+                    const f32x4 s = aesr_sub4((P[0][0] + P[1][0]) + 2.f * (P[0][1] + P[1][1]), P[0][3] + P[1][3]);
                     const int obs = (okn && y0 < a.H && x0 < a.W) ? ((n * outH + (y0 >> 1)) * outW + (x0 >> 1)) * a.Cout * 4 : WN_OOB;
                     wn_st(rs_out, obs + cob, s);
                     continue;
@@ -328,14 +336,15 @@ __global__ __launch_bounds__(WN_NT, 2) void conv_wino_f32(WinoArgs a) {
                 for (int p = 0; p < 2; ++p) {
                     f32x4 Y[2];
                     Y[0] = P[p][0] + P[p][1] + P[p][2];
-                    Y[1] = P[p][1] - P[p][2] - P[p][3];
+                    Y[1] = aesr_sub4(aesr_sub4(P[p][1], P[p][2]), P[p][3]);
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         f32x4 o = Y[q];
-                        // none / ReLU / LeakyReLU as ONE branch-free form (x > 0 ? x : x * nslope); a per-element switch on the
-                        // activation code costs a chain of uniform branches per element (~1000 instructions per item)
+                        // none / ReLU / LeakyReLU as ONE branch-free form, max(x, x * slope) for 0 <= slope <= 1; a per-element switch on
+                        // the activation code costs a chain of uniform branches per element (~1000 instructions per item)
+                        const f32x4 os = o * nslope;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : o[e] * nslope;
+                        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], os[e]);
                         if (sigm) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] = 1.f / (1.f + expf(-o[e]));
@@ -509,6 +518,10 @@ int aesr_launch_conv_wino(const WinoArgs& a_in, hipStream_t st) {
     }
     if ((size_t)a.N * a.H * a.W * a.Cin >= (size_t)0x1C000000 || (size_t)a.N * a.H * a.W * a.Cout >= (size_t)0x1C000000) {
         aesr_set_error("conv_wino: tensors of 469M elements (1.75 GB) or more need 64-bit indexing (not built)");
+        return AESR_ERR_UNSUPPORTED;
+    }
+    if (a.act == ACT_LRELU && !(a.slope >= 0.f && a.slope <= 1.f)) {
+        aesr_set_error("conv_wino: the fused LeakyReLU is max(x, slope * x): slope %g is outside [0, 1] (use aesr_conv2d_fwd)", (double)a.slope);
         return AESR_ERR_UNSUPPORTED;
     }
     if (a.ysave && a.mask_act == ACT_SIGMOID) {
