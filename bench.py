@@ -224,39 +224,42 @@ def main():
         run(min(opt.steps, 5), 0)
         summ = engine.PROFILER.summary()
         engine.PROFILER = None
-        # dominant kernel = the convolution kernel family with the most time in the step (forward + data-gradient launches)
-        kname = max(("conv_wino_f32", "conv_igemm_f32"), key=lambda n: summ.get(n, {"ms": 0.0})["ms"])
+        # dominant kernel = the MFMA convolution kernel with the most time in the step.  Kinds are the library's kernels:
+        # conv_wino_f32 / conv_wino_res_f32 (Winograd forward + data gradient, streamed / resident filter), conv_wgrad_wino_f32
+        # (Winograd weight gradient), conv_igemm_f32 / conv_wgrad_f32 (direct forms, where the Winograd ones do not apply)
+        nst = max(1, min(opt.steps, 5))
+        kinds = ("conv_wino_f32", "conv_wino_res_f32", "conv_wgrad_wino_f32", "conv_igemm_f32", "conv_wgrad_f32")
+        kname = max(kinds, key=lambda n: summ.get(n, {"ms": 0.0})["ms"])
         k = summ.get(kname, {"launches": 0, "flops": 0.0, "ms": 1e-9})
         ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["launches"] else 0.0
-        roofline = {"bound": "mfma", "kernel": "%s (forward + data-gradient launches)" % kname, "achieved": round(ach, 2),
+        wino = "wino" in kname
+        roofline = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                    "traffic": None, "launches_per_step": k["launches"] // max(1, min(opt.steps, 5)),
+                    "traffic": None, "launches_per_step": k["launches"] // nst,
                     "avg_launch_us": round(1e3 * k["ms"] / max(1, k["launches"]), 2),
                     "algorithmic_gflop_per_launch": round(k["flops"] / max(1, k["launches"]) / 1e9, 3),
+                    "kernel_ms_per_step": round(k["ms"] / nst, 3),
                     "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
                     "flop_basis": ("algorithmic (direct 3x3 convolution: 2*N*H*W*Cout*9*Cin per launch); the kernel is Winograd F(2x2,3x3) "
-                                   "and executes 1/2.25 of these on the matrix cores, so the fraction of the MFMA peak can exceed 1"
-                                   if kname == "conv_wino_f32" else "algorithmic = executed"),
-                    "measured": "HIP events around every launch, %d instrumented steps after the timed region" % min(opt.steps, 5)}
-        o = summ.get("conv_igemm_f32" if kname == "conv_wino_f32" else "conv_wino_f32")
-        if o and o["launches"]:
-            roofline["other_conv_kernel"] = {"kernel": "conv_igemm_f32" if kname == "conv_wino_f32" else "conv_wino_f32",
-                                             "achieved": round(o["flops"] / (o["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(o["ms"] / min(opt.steps, 5), 3)}
-        w = summ.get("conv_wgrad_f32")
-        if w and w["launches"]:
-            roofline["wgrad_achieved"] = round(w["flops"] / (w["ms"] * 1e-3) / 1e12, 2)
-            roofline["wgrad_ms_per_step"] = round(w["ms"] / min(opt.steps, 5), 3)
-        roofline["kernel_ms_per_step"] = round(k["ms"] / max(1, min(opt.steps, 5)), 3)
+                                   "and executes 1/2.25 of these on the matrix cores, so the fraction of the MFMA peak can exceed 1; "
+                                   "executed_frac = frac / 2.25" if wino else "algorithmic = executed"),
+                    "measured": "HIP events around every launch, %d instrumented steps after the timed region" % nst}
+        if wino:
+            roofline["executed_frac"] = round(ach / 2.25 / PEAK_F32_MFMA_TFLOPS, 4)
+        roofline["other_kernels"] = [
+            {"kernel": n, "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(v["ms"] / nst, 3),
+             "launches_per_step": v["launches"] // nst}
+            for n, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]) if n != kname and n in kinds and v["launches"]]
         # HBM-side bytes per launch of the same kernel: PMC counters cannot be read from inside this process; they come from the
         # committed rocprofv3 --pmc passes of this very command (scripts/pmc_traffic.py -> profiles/), N=1 and B=12 only
-        tpath = os.path.join(ROOT, "profiles", "r01_%s_hbm_traffic.json" % opt.config)
+        tpath = os.path.join(ROOT, "profiles", "r02_%s_hbm_traffic.json" % opt.config)
         if opt.gpus == 1 and B == 12 and opt.config in ("c2", "c3") and os.path.exists(tpath):
             tk = json.load(open(tpath))["kernels"]
-            ig = [v for name, v in tk.items() if kname in name]
+            ig = [v for name, v in tk.items() if (kname + "<") in name or (kname + "(") in name]
             nl = sum(v["launches_per_step"] for v in ig)
             if nl > 0:
                 roofline["traffic"] = round(sum(v["MB_per_step"] for v in ig) / nl * 1e6)
-                roofline["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_%s_hbm_traffic.json)" % opt.config
+                roofline["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_%s_hbm_traffic.json)" % opt.config
 
     if dp.rank != 0:
         dp.shutdown()

@@ -10,3 +10,4 @@ rocprofv3 --kernel-trace -d /tmp/prof_$TAG -o res -- python3 $GRAFT_REPO_ROOT/be
 DB=$(find /tmp/prof_$TAG -name "*.db" | head -1)
 python3 $GRAFT_REPO_ROOT/scripts/kstats.py $DB 8 > $OUT/${TAG}_kernel_stats.txt
 head -60 $OUT/${TAG}_kernel_stats.txt
+python3 $GRAFT_REPO_ROOT/scripts/kseq.py $DB 8 > $OUT/${TAG}_kernel_seq.txt

@@ -200,18 +200,18 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
             const unsigned ad = lx[i][c] + (unsigned)(xu * 4);
             f32x2 &p0_ = P[i][c][0], &p1_ = P[i][c][1];
             asm volatile("ds_read2st64_b32 %0, %2 offset0:%3 offset1:%4\n\tds_read2st64_b32 %1, %2 offset0:%5 offset1:%6"
-                         : "=&v"(p0_), "=&v"(p1_) : "v"(ad), "n"(0), "n"(PWL / 2), "n"(PWL), "n"(3 * PWL / 2));
+                         : "=&v"(p0_), "=&v"(p1_) : "v"(ad), "n"(0), "n"(PWL / 2), "n"(PWL), "n"(3 * PWL / 2) : "memory");
         });
         ww_rep<4>([&](auto Kc) {
             constexpr int o = decltype(Kc)::value >> 1, e = decltype(Kc)::value & 1;
             const unsigned ad = ld[o][e] + (unsigned)(du * 4);
             f32x2& y_ = Mp[nb][o][e];
-            asm volatile("ds_read2st64_b32 %0, %1 offset0:0 offset1:%2" : "=&v"(y_) : "v"(ad), "n"(TWL / 2));
+            asm volatile("ds_read2st64_b32 %0, %1 offset0:0 offset1:%2" : "=&v"(y_) : "v"(ad), "n"(TWL / 2) : "memory");
         });
     };
     // both transforms of the operands read: 48 v_pk_add_f32 + 2 adds for the bias gradient
     auto op_transform = [&](int nb) {
-        asm volatile("s_waitcnt lgkmcnt(0)");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         ww_rep<2>([&](auto Ic) {
             constexpr int i = decltype(Ic)::value;
             f32x2 T[2][4];                  // [rows 0,1 | rows 2,3][column]
@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
     t2 = advance(t1);
     fetch(t0, 0);
     fetch(t1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
     op_read(step_xu(0, 0), step_du(0, 0), 0);
@@ -296,6 +297,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
         mfmas(C16{}, std::integral_constant<int, 48>{}, 0);
         __builtin_amdgcn_sched_barrier(0);
         WW_STAMP(0)
+        // The wait is OURS to place: the LDS reads of this kernel are asm statements the compiler does not see, so its own
+        // bookkeeping finds no reader of the DMA'd bytes and leaves __syncthreads() a bare s_barrier -- a wave then read tile
+        // v + 1 before another wave's DMA had landed (rare wrong tiles at 36 x 162 x 162, never at the small test sizes).
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();            // tile v + 1 has landed; nobody reads buffer `buf` any more
         WW_STAMP(1)
         // k-step 1: MFMAs on set 1, the first operands of the NEXT tile into set 0, the DMA of the tile after it into `buf`
@@ -315,6 +320,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
         buf ^= 1;
     } while (t0.n < a.N);
     WW_STAMP(0)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();            // DMAs still in flight (zero fills past the last tile) must land before the exchange reuses the LDS
     if (STAMP && lane == 0)
         for (int k = 0; k < 3; ++k) a.dbgbuf[(blockIdx.x * 4 + wave) * 3 + k] = (float)tph[k];

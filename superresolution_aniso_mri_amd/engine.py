@@ -64,6 +64,16 @@ def wino_ok(cin, cout, ks, pad, transpose):
     return bool(USE_WINO and lib.aesr_conv2d_wino_supported(int(cin), int(cout), int(ks), int(pad), int(transpose)))
 
 
+def wino_kind(cin, cout, transpose):
+    """Profiler label of the Winograd kernel the library runs for a layer (conv_wino.hip / conv_wino_res.hip)."""
+    return "conv_wino_res_f32" if lib.aesr_conv2d_wino_kernel(int(cin), int(cout), 3, 1, int(transpose)) == 2 else "conv_wino_f32"
+
+
+def wgrad_kind(cin, cout, ks, pad):
+    """... of the weight-gradient kernel (conv_wgrad_wino.hip for 3x3 / padding 1 with both channel counts multiples of 32)."""
+    return "conv_wgrad_wino_f32" if (ks == 3 and pad == 1 and lib.aesr_conv2d_wgrad_up2_supported(int(cin), int(cout))) else "conv_wgrad_f32"
+
+
 def _pb(kind, flops):
     if PROFILER is not None:
         PROFILER.begin(kind, flops)
@@ -367,7 +377,7 @@ class SequentialRunner:
                 out = _empty((N, Ho, Wo, s.cout), x)
                 bias = s.mod.bias
                 if s.in_up2:
-                    _pb("conv_wino_f32", 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
+                    _pb(wino_kind(s.cin, s.cout, 0), 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
                     check(lib.aesr_conv2d_wino_fwd_up2(ptr(cur), ptr(s.packed_w), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, s.act,
                                                        s.slope, stream()), "aesr_conv2d_wino_fwd_up2")
                     _pe()
@@ -375,7 +385,7 @@ class SequentialRunner:
                     check(lib.aesr_conv2d_cout1_fwd(ptr(cur), ptr(s.mod.weight), ptr(bias), ptr(out), N, H, W, s.cin, s.act,
                                                     s.slope, stream()), "aesr_conv2d_cout1_fwd")
                 elif s.wino_fwd:
-                    _pb("conv_wino_f32", 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
+                    _pb(wino_kind(s.cin, s.cout, 0), 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
                     check(lib.aesr_conv2d_wino_fwd(ptr(cur), ptr(s.packed_w), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, s.act,
                                                    s.slope, stream()), "aesr_conv2d_wino_fwd")
                     _pe()
@@ -518,7 +528,7 @@ class SequentialRunner:
                 if s.cin % 4 == 0 and s.cout % 4 == 0:
                     nws = lib.aesr_conv2d_wgrad_workspace_floats(N, H, W, s.cin, s.cout, s.ks, s.pad)
                     ws = _empty((nws,), g)
-                    _pb("conv_wgrad_f32", 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
+                    _pb(wgrad_kind(s.cin, s.cout, s.ks, s.pad), 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
                     if s.s2d:        # its result is re-laid out right below: reduce at once
                         check(lib.aesr_conv2d_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout, s.ks,
                                                     s.pad, stream()), "aesr_conv2d_wgrad")
@@ -554,7 +564,7 @@ class SequentialRunner:
                 if s.in_up2:
                     # adjoint of the folded upsampling: 2x2 block sums of the data gradient, at half resolution (no mask: the
                     # producer is a BatchNorm)
-                    _pb("conv_wino_f32", 2.0 * N * H * W * s.cin * 9 * s.cout)
+                    _pb(wino_kind(s.cin, s.cout, 1), 2.0 * N * H * W * s.cin * 9 * s.cout)
                     check(lib.aesr_conv2d_wino_dgrad_sum2(ptr(g), ptr(s.packed_wt), ptr(dx), N, H, W, s.cin, s.cout, stream()),
                           "aesr_conv2d_wino_dgrad_sum2")
                     _pe()
@@ -562,7 +572,7 @@ class SequentialRunner:
                     check(lib.aesr_conv2d_smallcin_dgrad(ptr(g), ptr(s.mod.weight), ptr(dx), N, H, W, s.cin, s.cout, s.ks,
                                                          s.pad, 0, None, stream()), "aesr_conv2d_smallcin_dgrad")
                 elif s.wino_dgrad:
-                    _pb("conv_wino_f32", 2.0 * N * H * W * s.cin * 9 * s.cout)
+                    _pb(wino_kind(s.cin, s.cout, 1), 2.0 * N * H * W * s.cin * 9 * s.cout)
                     check(lib.aesr_conv2d_wino_dgrad(ptr(g), ptr(s.packed_wt), ptr(mask), ptr(dx), N, H, W, s.cin, s.cout, mask_act,
                                                      mslope, stream()), "aesr_conv2d_wino_dgrad")
                     _pe()
