@@ -215,6 +215,18 @@ int aesr_lerp_cat_bwd(const float* g, const float* a_from, const float* a_to, fl
 int aesr_mse_fwd(const float* a, const float* b, double* partial, float* loss, size_t n, void* stream);
 /* da = 2*(a-b)*gloss[0]/n */
 int aesr_mse_bwd(const float* a, const float* b, const float* gloss, float* da, size_t n, void* stream);
+/* The three mean-squared errors of the ae_combined step (reconstruction kwatsch/base_trainer.py:177, synthesis
+ * kwatsch/cardiac/trainer_ae.py:123 weighted by the device scalar lam[0], and the logged latent distance :181) in ONE launch:
+ * out[0] = m1 + lam * m2, out[1] = m1, out[2] = lam * m2, out[3] = m3 with m_k = mean((a_k - b_k)^2) (a3 may be NULL: m3 = 0).
+ * workspace: AESR_MSE3_WS doubles that the caller zeroes ONCE before the first call (the kernel leaves them consistent); the sums
+ * are fp64 and added in a fixed order (bitwise reproducible).  aesr_mse3_bwd: the gradient of out[0] times gloss[0]:
+ * d1 = 2 (a1 - b1) gloss / n1, d2 = 2 lam (a2 - b2) gloss / n2 (d1, d2 may be the two parts of one tensor). */
+#define AESR_MSE3_NPART 256
+#define AESR_MSE3_WS (3 * AESR_MSE3_NPART + 1)
+int aesr_mse3_fwd(const float* a1, const float* b1, size_t n1, const float* a2, const float* b2, size_t n2, const float* a3,
+                  const float* b3, size_t n3, const float* lam, double* workspace, float* out4, void* stream);
+int aesr_mse3_bwd(const float* a1, const float* b1, size_t n1, const float* a2, const float* b2, size_t n2, const float* lam,
+                  const float* gloss, float* d1, float* d2, void* stream);
 /* loss[0] = mean |a-b| (F.l1_loss of kwatsch/lap_pyramid_loss.py:65); partial: AESR_MSE_NPART doubles.  da = sign(a-b)*gloss[0]/n. */
 int aesr_l1_fwd(const float* a, const float* b, double* partial, float* loss, size_t n, void* stream);
 int aesr_l1_bwd(const float* a, const float* b, const float* gloss, float* da, size_t n, void* stream);

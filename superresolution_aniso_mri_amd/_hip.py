@@ -87,6 +87,8 @@ SIGNATURES = {
     "aesr_lerp_cat_bwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
     "aesr_mse_fwd": (c_int, [P, P, P, P, c_size_t, P]),
     "aesr_mse_bwd": (c_int, [P, P, P, P, c_size_t, P]),
+    "aesr_mse3_fwd": (c_int, [P, P, c_size_t, P, P, c_size_t, P, P, c_size_t, P, P, P, P]),
+    "aesr_mse3_bwd": (c_int, [P, P, c_size_t, P, P, c_size_t, P, P, P, P, P]),
     "aesr_row_mean_fwd": (c_int, [P, P, c_int, c_size_t, P]),
     "aesr_row_mean_bwd": (c_int, [P, P, c_int, c_size_t, P]),
     "aesr_l1_fwd": (c_int, [P, P, P, P, c_size_t, P]),
@@ -128,6 +130,7 @@ BN_NONE, BN_POOL, BN_UP = 0, 1, 2
 RS_POOL, RS_NEAREST, RS_BILINEAR = 1, 2, 3
 BN_NWG = 512
 MSE_NPART = 512
+MSE3_WS = 3 * 256 + 1            # doubles (AESR_MSE3_WS)
 LPIPS_NCH = 64
 
 

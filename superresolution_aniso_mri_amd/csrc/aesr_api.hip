@@ -887,6 +887,21 @@ int aesr_mse_fwd(const float* a, const float* b, double* partial, float* loss, s
     return aesr_launch_mse_fwd(a, b, partial, AESR_MSE_NPART, loss, n, (hipStream_t)stream);
 }
 
+int aesr_mse3_fwd(const float* a1, const float* b1, size_t n1, const float* a2, const float* b2, size_t n2, const float* a3,
+                  const float* b3, size_t n3, const float* lam, double* workspace, float* out4, void* stream) {
+    AESR_CHECK_ARG(a1 && b1 && n1 > 0 && a2 && b2 && n2 > 0 && (!a3 || (b3 && n3 > 0)) && lam && workspace && out4, "aesr_mse3_fwd: bad arguments");
+    const float* a[3] = {a1, a2, a3};
+    const float* b[3] = {b1, b2, a3 ? b3 : nullptr};
+    const size_t n[3] = {n1, n2, a3 ? n3 : 1};
+    return aesr_launch_mse3_fwd(a, b, n, lam, workspace, out4, (hipStream_t)stream);
+}
+
+int aesr_mse3_bwd(const float* a1, const float* b1, size_t n1, const float* a2, const float* b2, size_t n2, const float* lam,
+                  const float* gloss, float* d1, float* d2, void* stream) {
+    AESR_CHECK_ARG(a1 && b1 && n1 > 0 && a2 && b2 && n2 > 0 && lam && gloss && d1 && d2, "aesr_mse3_bwd: bad arguments");
+    return aesr_launch_mse3_bwd(a1, b1, n1, a2, b2, n2, lam, gloss, d1, d2, (hipStream_t)stream);
+}
+
 int aesr_mse_bwd(const float* a, const float* b, const float* gloss, float* da, size_t n, void* stream) {
     AESR_CHECK_ARG(a && b && gloss && da && n > 0, "aesr_mse_bwd: bad arguments");
     return aesr_launch_mse_bwd(a, b, gloss, da, n, (hipStream_t)stream);

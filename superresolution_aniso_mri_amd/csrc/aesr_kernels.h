@@ -159,6 +159,9 @@ int aesr_launch_lerp_bwd(const float* dmix, const float* af, const float* at, fl
 int aesr_launch_lerp_cat_fwd(const float* z, const float* af, const float* at, float* zcat, int B, size_t per, hipStream_t st);
 int aesr_launch_lerp_cat_bwd(const float* g, const float* af, const float* at, float* dz, int B, size_t per, hipStream_t st);
 int aesr_launch_mse_fwd(const float* a, const float* b, double* partial, int np, float* out, size_t n, hipStream_t st);
+int aesr_launch_mse3_fwd(const float* const* a, const float* const* b, const size_t* n, const float* lam, double* ws, float* out, hipStream_t st);
+int aesr_launch_mse3_bwd(const float* a1, const float* b1, size_t n1, const float* a2, const float* b2, size_t n2, const float* lam,
+                         const float* g, float* d1, float* d2, hipStream_t st);
 int aesr_launch_mse_bwd(const float* a, const float* b, const float* g, float* da, size_t n, hipStream_t st);
 int aesr_launch_act_bwd(const float* dout, const float* y, float* dpre, size_t n, int act, float slope, hipStream_t st);
 int aesr_launch_adam(float* p, const float* g, float* m, float* v, float* state, size_t n, float lr, float beta1, float beta2,

@@ -4,6 +4,7 @@
 //   mse      F.mse_loss(a, b) mean (kwatsch/base_trainer.py:177) + gradient, upstream scalar read on device
 //   act_bwd  dpre = dout * act'(y) from the saved activation output (sigmoid of networks/acai_vanilla.py:98)
 //   adam     torch.optim.Adam single-tensor semantics on one flat fp32 buffer (kwatsch/trainer_ae.py:29-30)
+#include "../../include/aesr_hip.h"
 #include "aesr_kernels.h"
 
 // ---- lerp ---------------------------------------------------------------------------------------------------
@@ -87,6 +88,93 @@ __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ 
                                                       float two_over_n) {
     const float k = two_over_n * g[0];
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) da[i] = (a[i] - b[i]) * k;
+}
+
+// ---- the three mean-squared errors of the ae_combined step in ONE launch -------------------------------------------------
+// out[0] = m1 + lam * m2, out[1] = m1, out[2] = lam * m2, out[3] = m3 (m_k = mean((a_k - b_k)^2), fp64 sums).  Every block leaves
+// its three partial sums in `ws`, takes a ticket, and the block that draws the last one adds the partials up in block order:
+// bitwise reproducible (no floating-point atomics), one graph node instead of the six of three aesr_mse_fwd calls + the torch
+// glue that combined them.  ws[3 * gridDim.x] is the ticket counter: zero before the first launch, left at zero.
+struct Mse3Args {
+    const float* a[3]; const float* b[3]; size_t n[3];
+    const float* lam; double* ws; float* out;
+};
+__global__ __launch_bounds__(256) void mse3_fwd_kernel(Mse3Args p) {
+    __shared__ double red[3][4];
+    __shared__ unsigned ticket;
+    double s[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float* a = p.a[k];
+        const float* b = p.b[k];
+        if (!a) continue;
+        const size_t n4 = p.n[k] >> 2;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            const f32x4 d = *(const f32x4*)(a + 4 * i) - *(const f32x4*)(b + 4 * i);
+            s[k] += ((double)(d[0] * d[0]) + (double)(d[1] * d[1])) + ((double)(d[2] * d[2]) + (double)(d[3] * d[3]));
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (p.n[k] & 3)) {
+            const float d = a[4 * n4 + threadIdx.x] - b[4 * n4 + threadIdx.x];
+            s[k] += (double)(d * d);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_down(s[k], o, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s[k];
+    }
+    __syncthreads();
+    unsigned* counter = (unsigned*)(p.ws + 3 * gridDim.x);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p.ws[3 * blockIdx.x + k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
+        __threadfence();
+        ticket = atomicAdd(counter, 1u);
+    }
+    __syncthreads();
+    if (ticket != gridDim.x - 1) return;
+    __threadfence();
+    double t[3] = {0.0, 0.0, 0.0};
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] += __hip_atomic_load(p.ws + 3 * i + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t[k] += __shfl_down(t[k], o, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = t[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) m[k] = p.a[k] ? ((red[k][0] + red[k][1]) + (red[k][2] + red[k][3])) / (double)p.n[k] : 0.0;
+        const float m1 = (float)m[0], m2w = p.lam[0] * (float)m[1];
+        p.out[0] = m1 + m2w;
+        p.out[1] = m1;
+        p.out[2] = m2w;
+        p.out[3] = (float)m[2];
+        *counter = 0u;
+    }
+}
+
+// gradient of out[0] of mse3_fwd with respect to a1 and a2: d1 = g * 2 (a1 - b1) / n1, d2 = g * lam * 2 (a2 - b2) / n2
+__global__ __launch_bounds__(256) void mse3_bwd_kernel(const float* __restrict__ a1, const float* __restrict__ b1, size_t n1,
+                                                       const float* __restrict__ a2, const float* __restrict__ b2, size_t n2,
+                                                       const float* __restrict__ lam, const float* __restrict__ g,
+                                                       float* __restrict__ d1, float* __restrict__ d2, float k1, float k2) {
+    const float g1 = k1 * g[0], g2 = k2 * g[0] * lam[0];
+    const size_t q1 = n1 >> 2, q2 = n2 >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < q1 + q2; i += (size_t)gridDim.x * 256) {
+        if (i < q1) *(f32x4*)(d1 + 4 * i) = (*(const f32x4*)(a1 + 4 * i) - *(const f32x4*)(b1 + 4 * i)) * g1;
+        else *(f32x4*)(d2 + 4 * (i - q1)) = (*(const f32x4*)(a2 + 4 * (i - q1)) - *(const f32x4*)(b2 + 4 * (i - q1))) * g2;
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < (n1 & 3)) d1[4 * q1 + threadIdx.x] = (a1[4 * q1 + threadIdx.x] - b1[4 * q1 + threadIdx.x]) * g1;
+        if (threadIdx.x < (n2 & 3)) d2[4 * q2 + threadIdx.x] = (a2[4 * q2 + threadIdx.x] - b2[4 * q2 + threadIdx.x]) * g2;
+    }
 }
 
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ y,
@@ -204,6 +292,24 @@ int aesr_launch_mse_fwd(const float* a, const float* b, double* partial, int np,
 int aesr_launch_mse_bwd(const float* a, const float* b, const float* g, float* da, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(mse_bwd_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, st, a, b, g, da, n, (float)(2.0 / (double)n));
     AESR_LAUNCH_CHECK("mse_bwd");
+    return AESR_OK;
+}
+
+int aesr_launch_mse3_fwd(const float* const* a, const float* const* b, const size_t* n, const float* lam, double* ws, float* out,
+                         hipStream_t st) {
+    Mse3Args p;
+    for (int k = 0; k < 3; ++k) { p.a[k] = a[k]; p.b[k] = b[k]; p.n[k] = n[k]; }
+    p.lam = lam; p.ws = ws; p.out = out;
+    hipLaunchKernelGGL(mse3_fwd_kernel, dim3(AESR_MSE3_NPART), dim3(256), 0, st, p);
+    AESR_LAUNCH_CHECK("mse3_fwd");
+    return AESR_OK;
+}
+
+int aesr_launch_mse3_bwd(const float* a1, const float* b1, size_t n1, const float* a2, const float* b2, size_t n2, const float* lam,
+                         const float* g, float* d1, float* d2, hipStream_t st) {
+    hipLaunchKernelGGL(mse3_bwd_kernel, dim3(grid_for((n1 + n2) / 4 + 1, 2048)), dim3(256), 0, st, a1, b1, n1, a2, b2, n2, lam, g, d1, d2,
+                       (float)(2.0 / (double)n1), (float)(2.0 / (double)n2));
+    AESR_LAUNCH_CHECK("mse3_bwd");
     return AESR_OK;
 }
 

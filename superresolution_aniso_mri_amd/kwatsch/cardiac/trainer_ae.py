@@ -85,6 +85,16 @@ class CombinedStepMixin(object):
         self._log("loss_ae_dist_extra", loss_img, is_test)
         return loss_img
 
+    def _fused_mse_losses(self):
+        """True when every loss of the step is a plain mean-squared error (README recipe ae_combined with the MSE synthesis
+        loss: no LPIPS, no Laplacian pyramid, no masks): the loss block then runs as ops.combined_mse.  AESR_FUSED_LOSS=0 keeps
+        the term-by-term path."""
+        if os.environ.get("AESR_FUSED_LOSS", "1") == "0":
+            return False
+        percept = self.percept_criterion is not None and ("perceptual" in (self.ae_loss_func, self.image_mix_loss_func))
+        return not (percept or getattr(self, "laploss", None) is not None or self.args.get("get_masks")
+                    or self.args.get("use_extra_latent_loss"))
+
     def _step_core(self, batch_item, eval_mode):
         """The ae_combined step on device-resident inputs; logs through ``_log`` and returns the tensors callers keep."""
         x, between = batch_item["image"], batch_item["slice_between"]
@@ -95,6 +105,20 @@ class CombinedStepMixin(object):
         # dec(z[2B]) and dec(z_mix[B]): one batched pass, two statistic groups; its input [z | z_mix] comes from one kernel
         zcat = ops.lerp_cat(z, a_from, a_to)
         z_mix = zcat[2 * B:]
+        if self._fused_mse_losses():
+            # all three mean-squared errors, their weighted sum and (backward) the whole gradient of the decoder output: two
+            # launches instead of fifteen small ones (ops.combined_mse); same quantities, same log keys, same order
+            o3 = self.model.decode_cat(zcat, [2 * B, B], merge=True)[0]
+            out, s_mix = o3[:2 * B], o3[2 * B:]
+            loss, l_rec, l_img, loss_latent = ops.combined_mse(o3, x, between, z_mix.detach(), z_ref.detach(), self._lambda_tensor())
+            self._log("loss_ae_dist", l_rec)
+            if self._log_extra_total:
+                self._log("loss_ae_extra", l_img)
+            self._log("loss_ae_dist_extra", l_img)
+            self._backward_and_step(loss, eval_mode)
+            self._log("loss_ae", loss)
+            self._log("loss_latent_1", loss_latent)
+            return {"z_mix": z_mix, "s_mix": s_mix, "out": out}
         out, s_mix = self.model.decode_cat(zcat, [2 * B, B])
         loss_ae = self.get_loss(x, out, is_test=False)["loss_ae"]
         loss_latent = ops.mse_loss(z_mix.detach(), z_ref.detach())

@@ -122,7 +122,7 @@ class HipAE(nn.Module):
         x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=0)
         return self._pass_batched(name, x, [t.shape[0] for t in xs], needs_grad)
 
-    def _pass_batched(self, name, x_nhwc, splits, needs_grad):
+    def _pass_batched(self, name, x_nhwc, splits, needs_grad, merge=False):
         nstart = [0]
         for n in splits:
             nstart.append(nstart[-1] + int(n))
@@ -130,14 +130,16 @@ class HipAE(nn.Module):
         if not self.training:
             nstart = [0, nstart[-1]]          # eval: running statistics, groups are irrelevant
             ngrad = nstart[-1] if ngrad > 0 else 0
-        return engine.run_pass_groups(self._runner(name), x_nhwc, list(splits), nstart, ngrad, train=self.training)
+        outs = [sum(int(n) for n in splits)] if merge else list(splits)     # merge: ONE output tensor, the statistic groups stay
+        return engine.run_pass_groups(self._runner(name), x_nhwc, outs, nstart, ngrad, train=self.training)
 
-    def decode_cat(self, zcat, splits, needs_grad=None):
-        """``decode_multi`` on sub-batches that already sit in one tensor (``ops.lerp_cat``): no concatenation pass."""
+    def decode_cat(self, zcat, splits, needs_grad=None, merge=False):
+        """``decode_multi`` on sub-batches that already sit in one tensor (``ops.lerp_cat``): no concatenation pass.  ``merge``
+        returns the outputs of all sub-batches as ONE tensor (a list of one), still with per-sub-batch BatchNorm statistics."""
         needs_grad = [True] * len(splits) if needs_grad is None else needs_grad
         if sum(int(n) for n in splits) != zcat.shape[0]:
             raise ValueError("splits %s do not add up to the batch size %d" % (list(splits), zcat.shape[0]))
-        return self._pass_batched("dec", engine.to_nhwc(zcat), splits, needs_grad)
+        return self._pass_batched("dec", engine.to_nhwc(zcat), splits, needs_grad, merge=merge)
 
     def encode_multi(self, images, needs_grad=None):
         return self._pass("enc", images, needs_grad)

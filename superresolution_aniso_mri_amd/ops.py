@@ -144,6 +144,63 @@ def mse_loss(a, b):
     return _MseFn.apply(an, bn)
 
 
+_MSE3_WS = {}
+
+
+def _mse3_workspace(device):
+    """Partial sums + ticket counter of aesr_mse3_fwd: zeroed ONCE (the kernel leaves it consistent), one per device, allocated
+    outside any graph capture (the first, eager steps)."""
+    key = str(device)
+    if key not in _MSE3_WS:
+        _MSE3_WS[key] = torch.zeros(_hip.MSE3_WS, device=device, dtype=torch.float64)
+    return _MSE3_WS[key]
+
+
+class _CombinedMseFn(torch.autograd.Function):
+    """total = mse(o3[:n1], x) + lam * mse(o3[n1:], between), plus the logged mse(z_mix, z_ref), in ONE launch; the backward writes
+    the whole gradient of o3 in one launch (no split / cat of the decoder's two sub-batches)."""
+
+    @staticmethod
+    def forward(ctx, o3, x, between, z_mix, z_ref, lam):
+        n1, n2 = x.numel(), between.numel()
+        if o3.numel() != n1 + n2:
+            raise ValueError("combined_mse: %d outputs for %d + %d targets" % (o3.numel(), n1, n2))
+        res = torch.empty(4, device=o3.device, dtype=torch.float32)
+        flat = o3.reshape(-1)
+        check(lib.aesr_mse3_fwd(ptr(flat), ptr(x), n1, ptr(flat[n1:]), ptr(between), n2, ptr(z_mix), ptr(z_ref),
+                                z_mix.numel() if z_mix is not None else 0, ptr(lam), ptr(_mse3_workspace(o3.device)), ptr(res), stream()),
+              "aesr_mse3_fwd")
+        ctx.save_for_backward(o3, x, between, lam)
+        outs = tuple(res[i].reshape(()) for i in range(4))
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g, *_unused):
+        o3, x, between, lam = ctx.saved_tensors
+        n1, n2 = x.numel(), between.numel()
+        g = g.reshape(1).contiguous().float()
+        d = torch.empty_like(o3)
+        flat, dflat = o3.reshape(-1), d.reshape(-1)
+        check(lib.aesr_mse3_bwd(ptr(flat), ptr(x), n1, ptr(flat[n1:]), ptr(between), n2, ptr(lam), ptr(g), ptr(dflat), ptr(dflat[n1:]),
+                                stream()), "aesr_mse3_bwd")
+        return d, None, None, None, None, None
+
+
+def combined_mse(o3, x, between, z_mix, z_ref, lam):
+    """The loss block of the ae_combined step with MSE losses (kwatsch/cardiac/trainer_ae.py:160-182 of the reference):
+    o3 = the decoder's batched output [recon(x) | synthesized between-slices] (logical NCHW), x / between their targets, lam the
+    synthesis weight as a device scalar.  Returns (total, loss_rec, lam * loss_img, loss_latent) as 0-dim device tensors; only
+    ``total`` carries a gradient (to o3)."""
+    o3n = engine.to_nhwc(o3)
+    xn, bn = engine.to_nhwc(x), engine.to_nhwc(between)
+    zm, zr = _flat_pair(z_mix, z_ref)
+    for t, what in ((o3n, "decoder output"), (xn, "image"), (bn, "slice_between"), (zm, "z_mix"), (zr, "z_ref"), (lam, "lambda")):
+        _hip.require_gpu_tensor(t, "combined_mse " + what)
+    total, l_rec, l_img, l_lat = _CombinedMseFn.apply(o3n, xn, bn, zm, zr, lam.reshape(1))
+    return total, l_rec, l_img, l_lat
+
+
 class _RowMeanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -675,3 +675,49 @@ def test_conv_wino_baseline_size_repeatable(hip, case):
             douts.append(dx)
         assert torch.equal(douts[0], douts[1]) and torch.equal(douts[0], douts[2])
         assert float((douts[0].double() - dref.permute(0, 2, 3, 1)).norm() / dref.norm()) < 2e-6
+
+
+@pytest.mark.parametrize("sizes", [(24 * 160 * 160, 12 * 160 * 160, 12 * 128 * 20 * 20), (1003, 517, 0), (5, 3, 2)])
+def test_combined_mse_loss_block(hip, sizes):
+    """aesr_mse3_fwd / _bwd (the loss block of the ae_combined step with MSE losses, one launch each) against torch in fp64;
+    repeated calls are bitwise equal (fixed-order sums, the ticket counter is left at zero) and the autograd wrapper matches
+    the term-by-term ops."""
+    from superresolution_aniso_mri_amd import ops
+    n1, n2, n3 = sizes
+    g = torch.Generator(device="cuda").manual_seed(n1)
+    a1, b1 = torch.rand(n1, device="cuda", generator=g), torch.rand(n1, device="cuda", generator=g)
+    a2, b2 = torch.rand(n2, device="cuda", generator=g), torch.rand(n2, device="cuda", generator=g)
+    a3, b3 = (torch.rand(n3, device="cuda", generator=g), torch.rand(n3, device="cuda", generator=g)) if n3 else (None, None)
+    lam = torch.tensor([0.05], device="cuda")
+    ws = torch.zeros(hip.MSE3_WS, dtype=torch.float64, device="cuda")
+    outs = []
+    for _ in range(3):
+        out = torch.full((4,), float("nan"), device="cuda")
+        hip.check(hip.lib.aesr_mse3_fwd(hip.ptr(a1), hip.ptr(b1), n1, hip.ptr(a2), hip.ptr(b2), n2, hip.ptr(a3), hip.ptr(b3), n3, hip.ptr(lam),
+                                        hip.ptr(ws), hip.ptr(out), hip.stream()), "mse3_fwd")
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    m1, m2 = float(((a1.double() - b1.double()) ** 2).mean()), float(((a2.double() - b2.double()) ** 2).mean())
+    m3 = float(((a3.double() - b3.double()) ** 2).mean()) if n3 else 0.0
+    want = np.array([m1 + 0.05 * m2, m1, 0.05 * m2, m3])
+    np.testing.assert_allclose(outs[0].numpy(), want, rtol=3e-7, atol=1e-12)
+    gl = torch.tensor([0.7], device="cuda")
+    d = torch.full((n1 + n2,), float("nan"), device="cuda")
+    hip.check(hip.lib.aesr_mse3_bwd(hip.ptr(a1), hip.ptr(b1), n1, hip.ptr(a2), hip.ptr(b2), n2, hip.ptr(lam), hip.ptr(gl), hip.ptr(d),
+                                    hip.ptr(d[n1:]), hip.stream()), "mse3_bwd")
+    ref = torch.cat([(a1.double() - b1.double()) * (2 * 0.7 / n1), (a2.double() - b2.double()) * (2 * 0.7 * 0.05 / n2)])
+    assert rel_l2(d, ref) < 1e-6
+    if n3 and n1 % 2 == 0:
+        # the autograd wrapper on image-shaped tensors against the term-by-term ops (kwatsch/cardiac/trainer_ae.py path)
+        B, H = 4, 12
+        o3 = torch.rand(3 * B, 1, H, H, device="cuda", generator=g).requires_grad_(True)
+        x, btw = torch.rand(2 * B, 1, H, H, device="cuda", generator=g), torch.rand(B, 1, H, H, device="cuda", generator=g)
+        zm, zr = torch.rand(B, 8, 3, 3, device="cuda", generator=g), torch.rand(B, 8, 3, 3, device="cuda", generator=g)
+        total, l1, l2, l3 = ops.combined_mse(o3, x, btw, zm, zr, lam.reshape(()))
+        total.backward()
+        o3r = o3.detach().clone().requires_grad_(True)
+        t2 = ops.mse_loss(o3r[:2 * B], x) + lam.reshape(()) * ops.mse_loss(btw, o3r[2 * B:])
+        t2.backward()
+        assert abs(float(total) - float(t2)) <= 2e-7 * float(t2) and abs(float(l3) - float(ops.mse_loss(zm, zr))) <= 2e-7
+        assert abs(float(l1) + float(l2) - float(total)) <= 1e-7
+        assert rel_l2(o3.grad, o3r.grad) < 1e-6
