@@ -277,11 +277,12 @@ int aesr_ssim_mse(const float* a, const float* b, double* workspace, double* ssi
  * handed over pre-transformed: U = G g G^T, packed by aesr_conv2d_wino_pack_many (job.transpose: 0 forward, 1 data gradient;
  * job.KS must be 3) into aesr_conv2d_wino_packed_floats floats. */
 int aesr_conv2d_wino_supported(int Cin, int Cout, int KS, int pad, int transpose);
-/* Which kernel serves a layer (for profilers and benchmarks; same arguments as aesr_conv2d_wino_supported): 0 = not supported,
- * 1 = conv_wino_f32 (16-channel chunks streamed through LDS, csrc/conv_wino.hip), 2 = conv_wino_res_f32 (K-side channels <= 32:
- * the transformed filter stays resident in LDS, independent waves, csrc/conv_wino_res.hip; AESR_WINO_RES=0 disables it).  The
+/* Which kernel serves a layer of H x W outputs (for profilers and benchmarks; the other arguments as aesr_conv2d_wino_supported):
+ * 0 = not supported, 1 = conv_wino_f32 (16-channel chunks streamed through LDS, csrc/conv_wino.hip), 2 = conv_wino_res_f32 (the
+ * transformed filter stays resident in LDS, independent waves, csrc/conv_wino_res.hip: K-side channels <= 32, or <= 64 where
+ * 8 x 8-output blocks tile the image with <= 10 % padding; AESR_WINO_RES=0 disables it, =1 keeps it to <= 32 channels).  The
  * LeakyReLU fused into these kernels is max(x, slope * x): slope must lie in [0, 1] (AESR_ERR_UNSUPPORTED otherwise). */
-int aesr_conv2d_wino_kernel(int Cin, int Cout, int KS, int pad, int transpose);
+int aesr_conv2d_wino_kernel(int H, int W, int Cin, int Cout, int KS, int pad, int transpose);
 size_t aesr_conv2d_wino_packed_floats(int Cout, int Cin, int transpose);
 int aesr_conv2d_wino_pack_many(const aesr_pack_job* jobs_host, int njobs, void* stream);
 int aesr_conv2d_wino_fwd(const float* in, const float* upacked, const float* bias, float* out, int N, int H, int W, int Cin,

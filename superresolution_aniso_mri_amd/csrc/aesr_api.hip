@@ -414,9 +414,10 @@ int aesr_conv2d_wino_supported(int Cin, int Cout, int KS, int pad, int transpose
     return KS == 3 && pad == 1 && kin > 0 && nout > 0 && kin % 16 == 0 && nout % 32 == 0;
 }
 
-int aesr_conv2d_wino_kernel(int Cin, int Cout, int KS, int pad, int transpose) {
-    if (!aesr_conv2d_wino_supported(Cin, Cout, KS, pad, transpose)) return 0;
+int aesr_conv2d_wino_kernel(int H, int W, int Cin, int Cout, int KS, int pad, int transpose) {
+    if (!aesr_conv2d_wino_supported(Cin, Cout, KS, pad, transpose) || H < 1 || W < 1) return 0;
     WinoArgs a = {};
+    a.H = H; a.W = W;
     a.CinP = round_up(transpose ? Cout : Cin, 16);
     a.CoutP = round_up(transpose ? Cin : Cout, 32);
     return aesr_wino_res_ok(a) ? 2 : 1;

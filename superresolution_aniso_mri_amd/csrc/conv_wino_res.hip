@@ -1,4 +1,4 @@
-// Winograd F(2x2, 3x3) convolution for layers with FEW input channels (Cin <= 32): the transformed filter stays resident in LDS
+// Winograd F(2x2, 3x3) convolution for layers with FEW input channels (Cin <= 64): the transformed filter stays resident in LDS
 // and every wave runs on its own -- no barrier after the prologue.
 //
 // The general kernel (conv_wino.hip) streams 16-channel chunks of patch + U through LDS for an 8-wave work item and meets at a
@@ -6,8 +6,8 @@
 // re-zeroing 128 accumulators, the next item's address work) -- during which all 8 waves leave the matrix pipe idle TOGETHER --
 // was 30 % of the kernel (AESR_WINO_DBG stamps: 7.9 k of 27 k cycles per item), and on gfx950 the f32 MFMA shares its pipe with the
 // vector ALU (scripts/micro/mfma_gap.hip), so nothing hides inside a wave either.  Here:
-//  * all of U for the workgroup's 32 output channels (<= 2 chunks = 64 KB) is loaded ONCE per workgroup; workgroup b serves the
-//    cout tile b % ncot for its whole life;
+//  * all of U for the workgroup's output channels (64 KB: 32 couts x <= 32 input channels, or 16 couts x <= 64) is loaded ONCE per
+//    workgroup; workgroup b serves the cout tile b % ncot for its whole life;
 //  * a work item belongs to ONE wave: 4 x 4 Winograd tiles (8 x 8 outputs) x 32 output channels, the same 128 accumulators per
 //    wave as in conv_wino.hip.  The wave fetches its own 10 x 10-pixel patch by DMA (buffer_load ... lds, one instruction per
 //    patch row of 16 pixel slots, 4 instructions of address work each) into its own 10 KB of LDS and waits only on its own
@@ -32,9 +32,7 @@
 #include "aesr_kernels.h"
 
 constexpr int WR_NT = 512;          // threads per workgroup: 8 independent waves, 2 per SIMD
-constexpr int WR_TN = 32;           // output channels of a workgroup
-constexpr int WR_NB = 2;
-constexpr int WR_WFL = 16 * 4 * WR_TN * 4;      // floats of one U chunk (16 positions x 16 ci x 32 co) = 8192
+// TN = output channels of a workgroup: 32 (K side <= 32 channels: <= 64 KB of filter) or 16 (K side <= 64 channels: 64 KB)
 constexpr int WR_RP = 260;          // floats between patch rows: 16 pixel slots x 16 channels + 4 (shifts a row by one 16-byte bank group)
 constexpr int WR_PFL = 10 * WR_RP;  // floats of a wave's patch buffer (10 rows)
 constexpr int WR_OOB = 0x70000000;
@@ -49,8 +47,10 @@ __device__ __forceinline__ void wr_st(__amdgpu_buffer_rsrc_t rs, int byte_off, f
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), rs, byte_off, 0, 0);
 }
 
-template <bool MASK>
+template <int WR_TN, bool MASK>
 __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
+    constexpr int WR_NB = WR_TN / 16;
+    constexpr int WR_WFL = 16 * 4 * WR_TN * 4;      // floats of one U chunk (16 positions x 16 ci x TN co)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,10 +75,14 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
 
     // ---- prologue: the workgroup's U block(s) and bias, once ----
     if (tid < WR_TN) ldsBias[tid] = (a.bias && co0 + tid < a.Cout) ? a.bias[co0 + tid] : 0.f;
+    // packed layout [chunk][32-cout tile][position][ci / 4][32 couts][4]: a 16-cout workgroup takes one half of every 32-cout row
     for (int cc = 0; cc < nchunks; ++cc) {
-        const int wbase = (int)(((size_t)cc * ncot + cot) * (WR_WFL * 4));
+        const int wbase = (int)(((size_t)cc * (a.CoutP / 32) + (co0 >> 5)) * (8192 * 4)) + ((co0 >> 4) & 1) * (WR_TN == 16 ? 256 : 0);
 #pragma unroll
-        for (int j = 0; j < WR_WFL / 4 / WR_NT; ++j) wr_dma(rs_w, ldsW + cc * WR_WFL + j * (WR_NT * 4) + wave * 256, wbase + (tid + WR_NT * j) * 16);
+        for (int j = 0; j < WR_WFL / 4 / WR_NT; ++j) {
+            const int pc = tid + WR_NT * j;                        // 16-byte piece -> (row of TN couts x 4, piece in the row)
+            wr_dma(rs_w, ldsW + cc * WR_WFL + j * (WR_NT * 4) + wave * 256, wbase + ((pc / WR_TN) * 128 + (pc % WR_TN) * 4) * 4);
+        }
     }
 
     // ---- per-lane maps ----
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
     while (item < a.nblk) {
         // ---- the 4x4 input pixels of this lane's tile, 4 channels each ----
         // the DMAs of this patch are the oldest outstanding memory operations; the previous item's stores may still be in flight
-        if (after_stores) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (after_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * WR_NB) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         f32x4 t[4][4];
 #pragma unroll
@@ -265,27 +269,34 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
                 }
             }
         }
-        after_stores = !MASK && !a.out_sum2;        // exactly 8 stores follow the next patch's DMAs (the mask loads were waited for)
+        after_stores = !MASK && !a.out_sum2;        // exactly 4 NB stores follow the next patch's DMAs
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no DMA may still be writing this workgroup's LDS when it is released
 #undef WR_DIV
 }
 
-size_t aesr_wino_res_lds_bytes(int CinP) { return ((size_t)(CinP >> 4) * WR_WFL + 8 * WR_PFL + WR_TN) * sizeof(float); }
+static int wino_res_tn(int CinP) { return CinP <= 32 ? 32 : 16; }
+size_t aesr_wino_res_lds_bytes(int CinP) { return ((size_t)(CinP >> 4) * (256 * wino_res_tn(CinP)) + 8 * WR_PFL + 32) * sizeof(float); }
 
 bool aesr_wino_res_ok(const WinoArgs& a) {
-    static const bool enabled = !(getenv("AESR_WINO_RES") && atoi(getenv("AESR_WINO_RES")) == 0);
-    return enabled && a.CinP <= 32 && a.CinP % 16 == 0 && a.CoutP % WR_TN == 0 && a.CoutP / WR_TN <= 256;
+    // AESR_WINO_RES: 0 = never, 1 = K side <= 32 channels only, unset / 2 = up to 64 channels (16-cout workgroups)
+    static const int level = getenv("AESR_WINO_RES") ? atoi(getenv("AESR_WINO_RES")) : 2;
+    if (level <= 0 || a.CinP % 16 != 0 || a.CoutP % 32 != 0 || a.CoutP / 16 > 256) return false;
+    if (a.CinP <= 32) return true;
+    // 16-cout workgroups pay twice the transform work per MFMA: worth it only where the 8 x 8-output blocks tile the image with
+    // little waste (measured: 40 x 40 and 80 x 80 layers 5-13 % faster than the streamed kernel, 81 x 81 (+18 % padding) 5 % slower)
+    const double waste = (double)(ceil_div(a.H, 8) * 8) * (ceil_div(a.W, 8) * 8) / ((double)a.H * a.W);
+    return level >= 2 && a.CinP <= 64 && waste <= 1.10;
 }
 
-template <bool MASK>
+template <int WR_TN, bool MASK>
 static int wino_res_launch_one(const WinoArgs& a, hipStream_t st) {
     const size_t shmem = aesr_wino_res_lds_bytes(a.CinP);
     static bool attr_set[AESR_MAX_DEVICES] = {};
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= AESR_MAX_DEVICES) dev_ = 0;
     if (!attr_set[dev_]) {
-        const hipError_t e_ = hipFuncSetAttribute((const void*)conv_wino_res_f32<MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t e_ = hipFuncSetAttribute((const void*)conv_wino_res_f32<WR_TN, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e_ != hipSuccess) {
             aesr_set_error("conv_wino_res_f32: hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KB) failed: %s", hipGetErrorString(e_));
             return AESR_ERR_HIP;
@@ -298,7 +309,7 @@ static int wino_res_launch_one(const WinoArgs& a, hipStream_t st) {
     const int per_cot = ceil_div(a.nblk, 8);               // more workgroups than 8-wave rounds of blocks would idle
     if (grid / ncot > per_cot) grid = per_cot * ncot;
     if (grid < ncot) grid = ncot;
-    hipLaunchKernelGGL((conv_wino_res_f32<MASK>), dim3(grid), dim3(WR_NT), shmem, st, a);
+    hipLaunchKernelGGL((conv_wino_res_f32<WR_TN, MASK>), dim3(grid), dim3(WR_NT), shmem, st, a);
     AESR_LAUNCH_CHECK("conv_wino_res_f32");
     return AESR_OK;
 }
@@ -311,7 +322,8 @@ int aesr_launch_conv_wino_res(const WinoArgs& a_in, hipStream_t st) {
     a.regs_x = ceil_div(a.W, 8);
     a.bpi = a.regs_y * a.regs_x;
     a.nblk = a.N * a.bpi;
-    a.nitems = a.nblk * (a.CoutP / WR_TN);
+    const int TN = wino_res_tn(a.CinP);
+    a.nitems = a.nblk * (a.CoutP / TN);
     auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((((unsigned long long)1 << 32) + d - 1) / d); };
     a.m_bpi = magic(a.bpi); a.m_regs_x = magic(a.regs_x);
     // the wave's item index runs up to nblk + 8 * 256 past the end before it is compared: exactness of the multiply-high division
@@ -323,5 +335,6 @@ int aesr_launch_conv_wino_res(const WinoArgs& a_in, hipStream_t st) {
         aesr_set_error("conv_wino_res: %d input channels do not fit the resident filter", a.CinP);
         return AESR_ERR_ARG;
     }
-    return a.ysave ? wino_res_launch_one<true>(a, st) : wino_res_launch_one<false>(a, st);
+    if (TN == 32) return a.ysave ? wino_res_launch_one<32, true>(a, st) : wino_res_launch_one<32, false>(a, st);
+    return a.ysave ? wino_res_launch_one<16, true>(a, st) : wino_res_launch_one<16, false>(a, st);
 }

@@ -465,6 +465,8 @@ WINO_CASES = [
     (1, 1, 1, 16, 32),          # a single pixel
     (2, 2, 3, 48, 96),          # Cin = 3 chunks, Cout = 3 cout tiles
     (1, 33, 130, 32, 32),       # wide image: regions that straddle the right border
+    (3, 40, 40, 64, 128),       # resident-filter kernel with 16-cout workgroups (K side 64 channels, blocks tile the image exactly)
+    (2, 16, 24, 48, 96),        # ... three chunks, six 16-cout tiles
 ]
 
 
@@ -643,7 +645,7 @@ def test_conv_wgrad_wino_baseline_size_repeatable(hip, case):
     assert float((outs[0][1].double() - dy.double().sum((0, 1, 2))).norm() / dy.double().sum((0, 1, 2)).norm()) < 2e-6
 
 
-@pytest.mark.parametrize("case", [(36, 162, 162, 32, 32), (36, 160, 160, 32, 64), (36, 81, 81, 64, 64), (36, 40, 40, 128, 128)])
+@pytest.mark.parametrize("case", [(36, 162, 162, 32, 32), (36, 160, 160, 32, 64), (36, 81, 81, 64, 64), (36, 80, 80, 64, 64), (36, 40, 40, 128, 128)])
 def test_conv_wino_baseline_size_repeatable(hip, case):
     """Forward (resident-filter kernel for Cin = 32, streamed kernel above) and masked data gradient at 36 images."""
     N, H, W, Cin, Cout = case
