@@ -216,7 +216,11 @@ __global__ __launch_bounds__(WN_NT, 2) void conv_wino_f32(WinoArgs a) {
         const float* pb = ldsP0 + buf * PPS;
         const float* wb = ldsW0 + buf * WN_WFL + (g * WN_TN + l15) * 4;        // + xi * (4*TN*4) + nb*64
         const bool do_load = l_item < nitems;
-        if (do_load) WN_STAGE(l_item, l_cc, ldsP0 + (buf ^ 1) * PPS, ldsW0 + (buf ^ 1) * WN_WFL)      // lands before the barrier below
+        // the staging DMAs of the next chunk (7-9 per wave, ~100 cycles of issue each) are NOT issued by all waves at once: the
+        // waves that are served first (0-3) put theirs behind their first position row, so that a SIMD whose one wave is
+        // stalled at the DMA queue has the other one in its MFMAs
+        const bool stage_late = !(a.flags & 4) && wave < 4 && wave_active;        // AESR_WINO_FLAGS=4: everybody stages first (A/B)
+        if (do_load && !stage_late) WN_STAGE(l_item, l_cc, ldsP0 + (buf ^ 1) * PPS, ldsW0 + (buf ^ 1) * WN_WFL)      // lands before the barrier below
         if (wave_active) {
             // ---- the 4x4 input pixels of this lane's tile, 4 channels each, and the row half of the transform (B^T d) ----
             f32x4 t[4][4];
@@ -239,10 +243,10 @@ __global__ __launch_bounds__(WN_NT, 2) void conv_wino_f32(WinoArgs a) {
 #define WN_V(i, j) ((j) == 0 ? aesr_sub4(t[i][0], t[i][2]) : (j) == 1 ? t[i][1] + t[i][2] : (j) == 2 ? aesr_sub4(t[i][2], t[i][1]) : aesr_sub4(t[i][1], t[i][3]))
             // (taking 0 / the bias as the C operand in the first chunk of an item instead of zeroing the accumulators -- what
             // conv_wino_res.hip does -- needs a second copy of this block: 4-17 registers spilled here, where the staging maps live)
-            auto positions = [&]() {
-                f32x4 vnx = WN_V(0, 0);
+            f32x4 vnx = WN_V(0, 0);
+            auto positions = [&](auto I0c, auto I1c) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = decltype(I0c)::value; i < decltype(I1c)::value; ++i) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int xi = i * 4 + j;
@@ -271,7 +275,9 @@ __global__ __launch_bounds__(WN_NT, 2) void conv_wino_f32(WinoArgs a) {
                     }
                 }
             };
-            positions();
+            positions(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            if (do_load && stage_late) WN_STAGE(l_item, l_cc, ldsP0 + (buf ^ 1) * PPS, ldsW0 + (buf ^ 1) * WN_WFL)
+            positions(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
 #undef WN_V
         }
         WN_STAMP(0)
