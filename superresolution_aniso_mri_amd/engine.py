@@ -75,7 +75,10 @@ def wgrad_kind(cin, cout, ks, pad):
 
 
 def _pb(kind, flops):
+    """``kind``: a kernel label, or ("wino" | "wgrad", layer arguments...) resolved through the library only while profiling."""
     if PROFILER is not None:
+        if isinstance(kind, tuple):
+            kind = wino_kind(*kind[1:]) if kind[0] == "wino" else wgrad_kind(*kind[1:])
         PROFILER.begin(kind, flops)
 
 
@@ -377,7 +380,7 @@ class SequentialRunner:
                 out = _empty((N, Ho, Wo, s.cout), x)
                 bias = s.mod.bias
                 if s.in_up2:
-                    _pb(wino_kind(Ho, Wo, s.cin, s.cout, 0), 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
+                    _pb(("wino", Ho, Wo, s.cin, s.cout, 0), 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
                     check(lib.aesr_conv2d_wino_fwd_up2(ptr(cur), ptr(s.packed_w), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, s.act,
                                                        s.slope, stream()), "aesr_conv2d_wino_fwd_up2")
                     _pe()
@@ -385,7 +388,7 @@ class SequentialRunner:
                     check(lib.aesr_conv2d_cout1_fwd(ptr(cur), ptr(s.mod.weight), ptr(bias), ptr(out), N, H, W, s.cin, s.act,
                                                     s.slope, stream()), "aesr_conv2d_cout1_fwd")
                 elif s.wino_fwd:
-                    _pb(wino_kind(Ho, Wo, s.cin, s.cout, 0), 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
+                    _pb(("wino", Ho, Wo, s.cin, s.cout, 0), 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
                     check(lib.aesr_conv2d_wino_fwd(ptr(cur), ptr(s.packed_w), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, s.act,
                                                    s.slope, stream()), "aesr_conv2d_wino_fwd")
                     _pe()
@@ -528,7 +531,7 @@ class SequentialRunner:
                 if s.cin % 4 == 0 and s.cout % 4 == 0:
                     nws = lib.aesr_conv2d_wgrad_workspace_floats(N, H, W, s.cin, s.cout, s.ks, s.pad)
                     ws = _empty((nws,), g)
-                    _pb(wgrad_kind(s.cin, s.cout, s.ks, s.pad), 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
+                    _pb(("wgrad", s.cin, s.cout, s.ks, s.pad), 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
                     if s.s2d:        # its result is re-laid out right below: reduce at once
                         check(lib.aesr_conv2d_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout, s.ks,
                                                     s.pad, stream()), "aesr_conv2d_wgrad")
@@ -564,7 +567,7 @@ class SequentialRunner:
                 if s.in_up2:
                     # adjoint of the folded upsampling: 2x2 block sums of the data gradient, at half resolution (no mask: the
                     # producer is a BatchNorm)
-                    _pb(wino_kind(H, W, s.cin, s.cout, 1), 2.0 * N * H * W * s.cin * 9 * s.cout)
+                    _pb(("wino", H, W, s.cin, s.cout, 1), 2.0 * N * H * W * s.cin * 9 * s.cout)
                     check(lib.aesr_conv2d_wino_dgrad_sum2(ptr(g), ptr(s.packed_wt), ptr(dx), N, H, W, s.cin, s.cout, stream()),
                           "aesr_conv2d_wino_dgrad_sum2")
                     _pe()
@@ -572,7 +575,7 @@ class SequentialRunner:
                     check(lib.aesr_conv2d_smallcin_dgrad(ptr(g), ptr(s.mod.weight), ptr(dx), N, H, W, s.cin, s.cout, s.ks,
                                                          s.pad, 0, None, stream()), "aesr_conv2d_smallcin_dgrad")
                 elif s.wino_dgrad:
-                    _pb(wino_kind(H, W, s.cin, s.cout, 1), 2.0 * N * H * W * s.cin * 9 * s.cout)
+                    _pb(("wino", H, W, s.cin, s.cout, 1), 2.0 * N * H * W * s.cin * 9 * s.cout)
                     check(lib.aesr_conv2d_wino_dgrad(ptr(g), ptr(s.packed_wt), ptr(mask), ptr(dx), N, H, W, s.cin, s.cout, mask_act,
                                                      mslope, stream()), "aesr_conv2d_wino_dgrad")
                     _pe()
