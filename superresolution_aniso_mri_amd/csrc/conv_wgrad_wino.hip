@@ -41,6 +41,9 @@
 
 constexpr int WW_OOB = 0x70000000;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef WW_ABL
+#define WW_ABL 0                // timing-only ablations of the tile loop (scripts/wgrad_ablation.sh): 1 no DMA, 2 no transforms, 3 no LDS reads, 4 MFMAs only
+#endif
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
 template <int... I, class F>
@@ -147,11 +150,18 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
         const int step_odd = sh == 0 ? RXS * xrow : RXS == 2 ? xrow : (r0 & 1) * xrow;      // step into an odd k
         const int step_even = sh == 0 ? RXS * xrow : RXS == 2 ? xrow : xrow - step_odd;
         float* const xdst = ldsX0 + buf * XFL + (rx0 * PWL + 8 * sgx) * 32;
+        int uxk[NXS];
         ww_rep<NXS>([&](auto Kc) {
             constexpr int k = decltype(Kc)::value;
             if constexpr (k > 0) ux += (k & 1) ? step_odd : step_even;
-            ww_dma(rs_x, xdst + k * RXS * PWL * 32, offx + ux);
+            uxk[k] = ux;
         });
+        if (pcx < TW + 2) {         // lanes past the patch's last column take no part: a DMA of 16 lanes issues faster than one of 64
+            ww_rep<NXS>([&](auto Kc) {
+                constexpr int k = decltype(Kc)::value;
+                ww_dma(rs_x, xdst + k * RXS * PWL * 32, offx + uxk[k]);
+            });
+        }
         int ud = (y0 + rd0) * drow;
         float* const ddst = ldsD0 + buf * DFL + (rd0 * TWL + 8 * sgd) * 32;
         ww_rep<NDS>([&](auto Kc) {
@@ -291,9 +301,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
     if (t0.n < a.N) do {
         // k-step 0 of the tile: MFMAs on operand set 0, the operands of k-step 1 into set 1
         __builtin_amdgcn_sched_barrier(0);
+#if WW_ABL != 3 && WW_ABL != 4
         op_read(step_xu(1, buf), step_du(1, buf), 1);
+#endif
         mfmas(C0{}, C16{}, 0);
+#if WW_ABL != 2 && WW_ABL != 4
         op_transform(1);
+#endif
         mfmas(C16{}, std::integral_constant<int, 48>{}, 0);
         __builtin_amdgcn_sched_barrier(0);
         WW_STAMP(0)
@@ -305,13 +319,19 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
         WW_STAMP(1)
         // k-step 1: MFMAs on set 1, the first operands of the NEXT tile into set 0, the DMA of the tile after it into `buf`
         __builtin_amdgcn_sched_barrier(0);
+#if WW_ABL != 3 && WW_ABL != 4
         op_read(step_xu(0, buf ^ 1), step_du(0, buf ^ 1), 0);
+#endif
         mfmas(C0{}, C16{}, 1);
         __builtin_amdgcn_sched_barrier(0);
+#if WW_ABL != 1 && WW_ABL != 4
         fetch(t2, buf);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         mfmas(C16{}, C16{}, 1);
+#if WW_ABL != 2 && WW_ABL != 4
         op_transform(0);
+#endif
         mfmas(C32{}, C32{}, 1);
         __builtin_amdgcn_sched_barrier(0);
         t0 = t1;
