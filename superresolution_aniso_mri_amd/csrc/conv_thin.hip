@@ -23,13 +23,17 @@
 #include "aesr_kernels.h"
 
 #define THIN_TH 8
+#ifndef THIN_ETH
+#define THIN_ETH 16              // rows of an expand tile: the patch staging and the 18 filter / bias loads of a thread are per tile
+#endif
 #define THIN_XS 68
 
 __host__ __device__ __forceinline__ int thin_tw(int C4) { return 256 / C4 < 64 ? 256 / C4 : 64; }
 
+template <int TH = THIN_TH>
 __device__ __forceinline__ void thin_stage(const ThinArgs& a, float (*xs)[THIN_XS], int n, int y0, int x0, int TW) {
     const int PW = TW + 2;
-    for (int q = threadIdx.x; q < (THIN_TH + 2) * PW; q += 256) {
+    for (int q = threadIdx.x; q < (TH + 2) * PW; q += 256) {
         const int r = q / PW, c = q - r * PW;
         const int sy = y0 + r - 1 - a.ps, sx = x0 + c - 1 - a.ps;
         float v = 0.f;
@@ -39,7 +43,7 @@ __device__ __forceinline__ void thin_stage(const ThinArgs& a, float (*xs)[THIN_X
 }
 
 __global__ __launch_bounds__(256) void thin_expand_kernel(ThinArgs a) {
-    __shared__ float xs[THIN_TH + 2][THIN_XS];
+    __shared__ float xs[THIN_ETH + 2][THIN_XS];
     const int C4 = a.C >> 2, TW = thin_tw(C4);
     const int tid = threadIdx.x, c4 = tid % C4, pl = tid / C4;
     int tile = blockIdx.x;
@@ -47,8 +51,8 @@ __global__ __launch_bounds__(256) void thin_expand_kernel(ThinArgs a) {
     tile /= a.tiles_x;
     const int ty = tile % a.tiles_y;
     const int n = tile / a.tiles_y;
-    const int y0 = ty * THIN_TH, x0 = tx * TW;
-    thin_stage(a, xs, n, y0, x0, TW);
+    const int y0 = ty * THIN_ETH, x0 = tx * TW;
+    thin_stage<THIN_ETH>(a, xs, n, y0, x0, TW);
     f32x4 w[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) w[t] = *(const f32x4*)(a.w + t * a.C + c4 * 4);
@@ -62,8 +66,12 @@ __global__ __launch_bounds__(256) void thin_expand_kernel(ThinArgs a) {
     const int ox = x0 + pl;
     if (pl >= TW || ox >= a.Wo) return;
     const bool xedge = a.be && (ox == 0 || ox == a.Wo - 1);
-#pragma unroll
-    for (int r = 0; r < THIN_TH; ++r) {
+    // none / ReLU / LeakyReLU as one branch-free form max(v, v * slope) (0 <= slope <= 1); the sigmoid keeps its own path
+    const bool sigm = a.act == ACT_SIGMOID;
+    const float nslope = a.act == ACT_LRELU ? a.slope : (a.act == ACT_RELU ? 0.f : 1.f);
+    const bool fastact = !sigm && nslope >= 0.f && nslope <= 1.f;
+#pragma unroll 4
+    for (int r = 0; r < THIN_ETH; ++r) {
         const int oy = y0 + r;
         if (oy >= a.Ho) break;
         f32x4 acc = bfull;
@@ -81,8 +89,13 @@ __global__ __launch_bounds__(256) void thin_expand_kernel(ThinArgs a) {
             for (int e = 0; e < 4; ++e) acc[e] = fmaf(w[t][e], v, acc[e]);
         }
         const size_t o = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.C + c4 * 4;
+        if (fastact) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = act_apply(acc[e], a.act, a.slope);
+            for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], acc[e] * nslope);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = act_apply(acc[e], a.act, a.slope);
+        }
         if (a.ysave) {
             const f32x4 ys = *(const f32x4*)(a.ysave + o);
 #pragma unroll
@@ -359,7 +372,7 @@ int aesr_launch_thin_expand(ThinArgs a, hipStream_t st) {
         return AESR_ERR_ARG;
     }
     const int TW = thin_tw(a.C / 4);
-    a.tiles_y = ceil_div(a.Ho, THIN_TH);
+    a.tiles_y = ceil_div(a.Ho, THIN_ETH);
     a.tiles_x = ceil_div(a.Wo, TW);
     a.ntiles = a.N * a.tiles_y * a.tiles_x;
     hipLaunchKernelGGL(thin_expand_kernel, dim3(a.ntiles), dim3(256), 0, st, a);
