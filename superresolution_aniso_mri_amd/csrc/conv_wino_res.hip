@@ -275,8 +275,18 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
 #undef WR_DIV
 }
 
-static int wino_res_tn(int CinP) { return CinP <= 32 ? 32 : 16; }
-size_t aesr_wino_res_lds_bytes(int CinP) { return ((size_t)(CinP >> 4) * (256 * wino_res_tn(CinP)) + 8 * WR_PFL + 32) * sizeof(float); }
+// Output channels per workgroup.  64 K-side channels only fit with 16; with <= 32 both do, and the choice is about balance: a
+// 16-cout work item is 0.55 of a 32-cout one (half the MFMAs, the same transforms), so it wins when it saves rounds of
+// items over the 2 048 waves -- at 6 images of 160 x 160: 2 400 items = 2 rounds, or 4 800 half items = 3 x 0.55 = 1.65
+static int wino_res_tn(const WinoArgs& a) {
+    if (a.CinP > 32) return 16;
+    static const int forced = getenv("AESR_WINO_RES_TN") ? atoi(getenv("AESR_WINO_RES_TN")) : 0;
+    if (forced == 16 || forced == 32) return forced;
+    const long nblk = (long)a.N * ceil_div(a.H, 8) * ceil_div(a.W, 8);
+    const double c32 = (double)((nblk * (a.CoutP / 32) + 2047) / 2048), c16 = 0.55 * (double)((nblk * (a.CoutP / 16) + 2047) / 2048);
+    return c16 < c32 ? 16 : 32;
+}
+static size_t wino_res_lds_bytes(int CinP, int TN) { return ((size_t)(CinP >> 4) * (256 * TN) + 8 * WR_PFL + 32) * sizeof(float); }
 
 bool aesr_wino_res_ok(const WinoArgs& a) {
     // AESR_WINO_RES: 0 = never, 1 = K side <= 32 channels only, unset / 2 = up to 64 channels (16-cout workgroups)
@@ -291,7 +301,7 @@ bool aesr_wino_res_ok(const WinoArgs& a) {
 
 template <int WR_TN, bool MASK>
 static int wino_res_launch_one(const WinoArgs& a, hipStream_t st) {
-    const size_t shmem = aesr_wino_res_lds_bytes(a.CinP);
+    const size_t shmem = wino_res_lds_bytes(a.CinP, WR_TN);
     static bool attr_set[AESR_MAX_DEVICES] = {};
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= AESR_MAX_DEVICES) dev_ = 0;
@@ -322,7 +332,7 @@ int aesr_launch_conv_wino_res(const WinoArgs& a_in, hipStream_t st) {
     a.regs_x = ceil_div(a.W, 8);
     a.bpi = a.regs_y * a.regs_x;
     a.nblk = a.N * a.bpi;
-    const int TN = wino_res_tn(a.CinP);
+    const int TN = wino_res_tn(a);
     a.nitems = a.nblk * (a.CoutP / TN);
     auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((((unsigned long long)1 << 32) + d - 1) / d); };
     a.m_bpi = magic(a.bpi); a.m_regs_x = magic(a.regs_x);
@@ -331,7 +341,7 @@ int aesr_launch_conv_wino_res(const WinoArgs& a_in, hipStream_t st) {
         aesr_set_error("conv_wino_res: %d blocks exceed the exact range of the item decomposition (or images of 256 MB and more)", a.nblk);
         return AESR_ERR_UNSUPPORTED;
     }
-    if (aesr_wino_res_lds_bytes(a.CinP) > (size_t)160 * 1024) {
+    if (wino_res_lds_bytes(a.CinP, TN) > (size_t)160 * 1024) {
         aesr_set_error("conv_wino_res: %d input channels do not fit the resident filter", a.CinP);
         return AESR_ERR_ARG;
     }
