@@ -225,10 +225,10 @@ def main():
         summ = engine.PROFILER.summary()
         engine.PROFILER = None
         # dominant kernel = the MFMA convolution kernel with the most time in the step.  Kinds are the library's kernels:
-        # conv_wino_f32 / conv_wino_res_f32 (Winograd forward + data gradient, streamed / resident filter), conv_wgrad_wino_f32
+        # conv_wino_f32 / conv_wino_ring_f32 / conv_wino_res_f32 (Winograd forward + data gradient: streamed, ring, resident filter), conv_wgrad_wino_f32
         # (Winograd weight gradient), conv_igemm_f32 / conv_wgrad_f32 (direct forms, where the Winograd ones do not apply)
         nst = max(1, min(opt.steps, 5))
-        kinds = ("conv_wino_f32", "conv_wino_res_f32", "conv_wgrad_wino_f32", "conv_igemm_f32", "conv_wgrad_f32")
+        kinds = ("conv_wino_f32", "conv_wino_ring_f32", "conv_wino_res_f32", "conv_wgrad_wino_f32", "conv_igemm_f32", "conv_wgrad_f32")
         kname = max(kinds, key=lambda n: summ.get(n, {"ms": 0.0})["ms"])
         k = summ.get(kname, {"launches": 0, "flops": 0.0, "ms": 1e-9})
         ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["launches"] else 0.0

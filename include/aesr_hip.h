@@ -277,12 +277,18 @@ int aesr_ssim_mse(const float* a, const float* b, double* workspace, double* ssi
  * handed over pre-transformed: U = G g G^T, packed by aesr_conv2d_wino_pack_many (job.transpose: 0 forward, 1 data gradient;
  * job.KS must be 3) into aesr_conv2d_wino_packed_floats floats. */
 int aesr_conv2d_wino_supported(int Cin, int Cout, int KS, int pad, int transpose);
-/* Which kernel serves a layer of H x W outputs (for profilers and benchmarks; the other arguments as aesr_conv2d_wino_supported):
+/* Which kernel serves a layer of N images of H x W outputs (for profilers and benchmarks; the other arguments as aesr_conv2d_wino_supported):
  * 0 = not supported, 1 = conv_wino_f32 (16-channel chunks streamed through LDS, csrc/conv_wino.hip), 2 = conv_wino_res_f32 (the
  * transformed filter stays resident in LDS, independent waves, csrc/conv_wino_res.hip: K-side channels <= 32, or <= 64 where
- * 8 x 8-output blocks tile the image with <= 10 % padding; AESR_WINO_RES=0 disables it, =1 keeps it to <= 32 channels).  The
+ * 8 x 8-output blocks tile the image with <= 10 % padding; AESR_WINO_RES=0 disables it, =1 keeps it to <= 32 channels),
+ * 3 = conv_wino_ring_f32 (filter chunks through a three-slot LDS ring, independent waves with per-wave patches,
+ * csrc/conv_wino_ring.hip: the other layers where the launcher's cost estimate for it is below kernel 1's -- layers whose image
+ * 8 x 8-output blocks tile well and that fill at least a round of work items; AESR_WINO_RING=0: never, =2: always).  The
  * LeakyReLU fused into these kernels is max(x, slope * x): slope must lie in [0, 1] (AESR_ERR_UNSUPPORTED otherwise). */
-int aesr_conv2d_wino_kernel(int H, int W, int Cin, int Cout, int KS, int pad, int transpose);
+int aesr_conv2d_wino_kernel(int N, int H, int W, int Cin, int Cout, int KS, int pad, int transpose);
+/* Watchdog of conv_wino_ring_f32's LDS arrival counters: how many waits gave up since the library was loaded (a wait that long
+ * means a protocol bug; the results of that launch are garbage).  0 in correct operation; synchronises the device. */
+unsigned int aesr_conv2d_wino_ring_timeouts(void);
 size_t aesr_conv2d_wino_packed_floats(int Cout, int Cin, int transpose);
 int aesr_conv2d_wino_pack_many(const aesr_pack_job* jobs_host, int njobs, void* stream);
 int aesr_conv2d_wino_fwd(const float* in, const float* upacked, const float* bias, float* out, int N, int H, int W, int Cin,

@@ -1,0 +1,9 @@
+#!/bin/bash
+set -e
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+timeout -k 10 300 python3 -m pytest tests/test_gpu_kernels.py -x -q -k "wino" > $OUT/ring_tests.txt 2>&1 || { tail -30 $OUT/ring_tests.txt; exit 1; }
+tail -2 $OUT/ring_tests.txt
+AESR_PLAN_DEBUG=1 timeout -k 10 200 python3 scripts/bench_wino.py vgg > $OUT/ring_vgg.txt 2>&1
+AESR_WINO_RING=0 timeout -k 10 200 python3 scripts/bench_wino.py vgg > $OUT/old_vgg.txt 2>&1
+AESR_PLAN_DEBUG=1 timeout -k 10 200 python3 scripts/bench_wino.py ae > $OUT/ring_ae.txt 2>&1
+AESR_WINO_RING=0 timeout -k 10 200 python3 scripts/bench_wino.py ae > $OUT/old_ae.txt 2>&1

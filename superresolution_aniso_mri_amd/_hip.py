@@ -102,7 +102,8 @@ SIGNATURES = {
     "aesr_ssim_mse": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_double, c_double, c_double, P]),
     "aesr_adam_step": (c_int, [P, P, P, P, P, c_size_t] + [c_float] * 5 + [P]),
     "aesr_conv2d_wino_supported": (c_int, [c_int] * 5),
-    "aesr_conv2d_wino_kernel": (c_int, [c_int] * 7),
+    "aesr_conv2d_wino_kernel": (c_int, [c_int] * 8),
+    "aesr_conv2d_wino_ring_timeouts": (ctypes.c_uint, []),
     "aesr_conv2d_wino_packed_floats": (c_size_t, [c_int, c_int, c_int]),
     "aesr_conv2d_wino_pack_many": (c_int, [ctypes.POINTER(PackJob), c_int, P]),
     "aesr_conv2d_wino_fwd": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),

@@ -414,13 +414,21 @@ int aesr_conv2d_wino_supported(int Cin, int Cout, int KS, int pad, int transpose
     return KS == 3 && pad == 1 && kin > 0 && nout > 0 && kin % 16 == 0 && nout % 32 == 0;
 }
 
-int aesr_conv2d_wino_kernel(int H, int W, int Cin, int Cout, int KS, int pad, int transpose) {
-    if (!aesr_conv2d_wino_supported(Cin, Cout, KS, pad, transpose) || H < 1 || W < 1) return 0;
+int aesr_conv2d_wino_kernel(int N, int H, int W, int Cin, int Cout, int KS, int pad, int transpose) {
+    if (!aesr_conv2d_wino_supported(Cin, Cout, KS, pad, transpose) || N < 1 || H < 1 || W < 1) return 0;
+    const int kin = transpose ? Cout : Cin, nout = transpose ? Cin : Cout;
+    const WinoPlan p = plan_wino(N, H, W, kin, nout);
     WinoArgs a = {};
-    a.H = H; a.W = W;
-    a.CinP = round_up(transpose ? Cout : Cin, 16);
-    a.CoutP = round_up(transpose ? Cin : Cout, 32);
-    return aesr_wino_res_ok(a) ? 2 : 1;
+    a.N = N; a.H = H; a.W = W; a.Cin = kin; a.Cout = nout;
+    a.CinP = p.CinP; a.CoutP = p.CoutP;
+    a.plan_cost = p.cost;
+    if (aesr_wino_res_ok(a)) return 2;
+    return aesr_wino_ring_takes(a) ? 3 : 1;
+}
+
+unsigned int aesr_conv2d_wino_ring_timeouts(void) {
+    (void)hipDeviceSynchronize();
+    return aesr_wino_ring_timeouts();
 }
 
 size_t aesr_conv2d_wino_packed_floats(int Cout, int Cin, int transpose) {
@@ -456,10 +464,11 @@ int aesr_conv2d_wino_pack_many(const aesr_pack_job* jobs_host, int njobs, void* 
 static int run_wino(const float* in, const float* upk, const float* bias, const float* ysave, float* out, int N, int H, int W,
                     int Cin, int Cout, int act, int mask_act, float slope, hipStream_t st, int in_up2 = 0, int out_sum2 = 0) {
     const WinoPlan p = plan_wino(N, H, W, Cin, Cout);
-    WinoArgs a;
+    WinoArgs a = {};
     a.in = in; a.upk = upk; a.bias = bias; a.ysave = ysave; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = p.CinP; a.Cout = Cout; a.CoutP = p.CoutP;
     a.TI = p.TI; a.THt = p.THt; a.TWt = p.TWt; a.regs_y = a.regs_x = a.nitems = 0;
+    a.plan_cost = p.cost;
     a.act = act; a.mask_act = mask_act; a.slope = slope; a.dbgbuf = nullptr; a.flags = 0; a.in_up2 = in_up2; a.out_sum2 = out_sum2;
     return aesr_launch_conv_wino(a, st);
 }

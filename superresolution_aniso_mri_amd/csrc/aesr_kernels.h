@@ -33,10 +33,19 @@ struct WinoArgs {
     int out_sum2;                // store the sum of every 2x2 output tile at half resolution (adjoint of that Upsample)
     int bpi, nblk;               // resident-filter kernel (conv_wino_res.hip): 8x8-output blocks per image / in all, filled by its launcher
     unsigned m_bpi;              // ceil(2^32 / bpi) (0: bpi == 1)
+    // ring kernel (conv_wino_ring.hip), filled by its launcher: waves per workgroup, patch row pitch / image stride / buffer size in
+    // floats, bank swizzle of the channel quads f(px) = (((px >> sw_a) & sw_m) << sw_b) & 3
+    int nw, rowP, imgP, patch_fl, sw_a, sw_m, sw_b;
+    double plan_cost;            // cost estimate (cycles) of the first streamed kernel's plan for this layer: the ring kernel runs where its own is lower
+    int nfull, tail_k;           // item list: groups of 8 blocks, then the last partial round in groups of tail_k <= 4 blocks
 };
 int aesr_launch_conv_wino(const WinoArgs& a, hipStream_t st);
 bool aesr_wino_res_ok(const WinoArgs& a);                        // few input channels: the filter stays resident, waves run on their own
 int aesr_launch_conv_wino_res(const WinoArgs& a, hipStream_t st);
+int aesr_wino_ring_mode();                                       // AESR_WINO_RING: 0 never, 1 (default) where its cost estimate is lower, 2 always
+bool aesr_wino_ring_takes(const WinoArgs& a);                    // many K-side channels: filter chunks through an LDS ring, independent waves
+int aesr_launch_conv_wino_ring(const WinoArgs& a, hipStream_t st);
+unsigned aesr_wino_ring_timeouts();                              // protocol watchdog of the ring kernel (0 unless a spin gave up)
 size_t aesr_wino_lds_bytes(int patch_pixels);
 
 #define PACK_MAX_JOBS 32

@@ -64,9 +64,11 @@ def wino_ok(cin, cout, ks, pad, transpose):
     return bool(USE_WINO and lib.aesr_conv2d_wino_supported(int(cin), int(cout), int(ks), int(pad), int(transpose)))
 
 
-def wino_kind(h, w, cin, cout, transpose):
-    """Profiler label of the Winograd kernel the library runs for a layer of h x w outputs (conv_wino.hip / conv_wino_res.hip)."""
-    return "conv_wino_res_f32" if lib.aesr_conv2d_wino_kernel(int(h), int(w), int(cin), int(cout), 3, 1, int(transpose)) == 2 else "conv_wino_f32"
+def wino_kind(n, h, w, cin, cout, transpose):
+    """Profiler label of the Winograd kernel the library runs for a layer of n images of h x w outputs (conv_wino.hip /
+    conv_wino_res.hip / conv_wino_ring.hip)."""
+    k = lib.aesr_conv2d_wino_kernel(int(n), int(h), int(w), int(cin), int(cout), 3, 1, int(transpose))
+    return {2: "conv_wino_res_f32", 3: "conv_wino_ring_f32"}.get(k, "conv_wino_f32")
 
 
 def wgrad_kind(cin, cout, ks, pad):
@@ -380,7 +382,7 @@ class SequentialRunner:
                 out = _empty((N, Ho, Wo, s.cout), x)
                 bias = s.mod.bias
                 if s.in_up2:
-                    _pb(("wino", Ho, Wo, s.cin, s.cout, 0), 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
+                    _pb(("wino", N, Ho, Wo, s.cin, s.cout, 0), 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
                     check(lib.aesr_conv2d_wino_fwd_up2(ptr(cur), ptr(s.packed_w), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, s.act,
                                                        s.slope, stream()), "aesr_conv2d_wino_fwd_up2")
                     _pe()
@@ -388,7 +390,7 @@ class SequentialRunner:
                     check(lib.aesr_conv2d_cout1_fwd(ptr(cur), ptr(s.mod.weight), ptr(bias), ptr(out), N, H, W, s.cin, s.act,
                                                     s.slope, stream()), "aesr_conv2d_cout1_fwd")
                 elif s.wino_fwd:
-                    _pb(("wino", Ho, Wo, s.cin, s.cout, 0), 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
+                    _pb(("wino", N, Ho, Wo, s.cin, s.cout, 0), 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
                     check(lib.aesr_conv2d_wino_fwd(ptr(cur), ptr(s.packed_w), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, s.act,
                                                    s.slope, stream()), "aesr_conv2d_wino_fwd")
                     _pe()
@@ -567,7 +569,7 @@ class SequentialRunner:
                 if s.in_up2:
                     # adjoint of the folded upsampling: 2x2 block sums of the data gradient, at half resolution (no mask: the
                     # producer is a BatchNorm)
-                    _pb(("wino", H, W, s.cin, s.cout, 1), 2.0 * N * H * W * s.cin * 9 * s.cout)
+                    _pb(("wino", N, H, W, s.cin, s.cout, 1), 2.0 * N * H * W * s.cin * 9 * s.cout)
                     check(lib.aesr_conv2d_wino_dgrad_sum2(ptr(g), ptr(s.packed_wt), ptr(dx), N, H, W, s.cin, s.cout, stream()),
                           "aesr_conv2d_wino_dgrad_sum2")
                     _pe()
@@ -575,7 +577,7 @@ class SequentialRunner:
                     check(lib.aesr_conv2d_smallcin_dgrad(ptr(g), ptr(s.mod.weight), ptr(dx), N, H, W, s.cin, s.cout, s.ks,
                                                          s.pad, 0, None, stream()), "aesr_conv2d_smallcin_dgrad")
                 elif s.wino_dgrad:
-                    _pb(("wino", H, W, s.cin, s.cout, 1), 2.0 * N * H * W * s.cin * 9 * s.cout)
+                    _pb(("wino", N, H, W, s.cin, s.cout, 1), 2.0 * N * H * W * s.cin * 9 * s.cout)
                     check(lib.aesr_conv2d_wino_dgrad(ptr(g), ptr(s.packed_wt), ptr(mask), ptr(dx), N, H, W, s.cin, s.cout, mask_act,
                                                      mslope, stream()), "aesr_conv2d_wino_dgrad")
                     _pe()

@@ -198,7 +198,7 @@ class PNetLin(nn.Module):
             c = convs[nconv]
             out = torch.empty((N, h, w, v), device=x.device)
             if pk["fwd_wino"][nconv]:
-                engine._pb(("wino", h, w, cin, v, 0), 2.0 * N * h * w * v * 9 * cin)
+                engine._pb(("wino", N, h, w, cin, v, 0), 2.0 * N * h * w * v * 9 * cin)
                 check(lib.aesr_conv2d_wino_fwd(ptr(cur), ptr(pk["fwd"][nconv]), ptr(c.bias), ptr(out), N, h, w, cin, v, _hip.ACT_RELU,
                                                0.0, stream()), "aesr_conv2d_wino_fwd(vgg)")
                 engine._pe()
@@ -263,7 +263,7 @@ class PNetLin(nn.Module):
             mask = None if producer_is_pool else prev
             dxs = torch.empty((B, h, w, cv.in_channels), device=dev)
             if pk["bwd_wino"][n - 1]:
-                engine._pb(("wino", h, w, cv.in_channels, cv.out_channels, 1), 2.0 * B * h * w * cv.in_channels * 9 * cv.out_channels)
+                engine._pb(("wino", B, h, w, cv.in_channels, cv.out_channels, 1), 2.0 * B * h * w * cv.in_channels * 9 * cv.out_channels)
                 check(lib.aesr_conv2d_wino_dgrad(ptr(g), ptr(pk["bwd"][n - 1]), ptr(mask), ptr(dxs), B, h, w, cv.in_channels,
                                                  cv.out_channels, _hip.ACT_RELU if mask is not None else 0, 0.0, stream()),
                       "aesr_conv2d_wino_dgrad(vgg)")

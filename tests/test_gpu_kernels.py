@@ -467,6 +467,13 @@ WINO_CASES = [
     (1, 33, 130, 32, 32),       # wide image: regions that straddle the right border
     (3, 40, 40, 64, 128),       # resident-filter kernel with 16-cout workgroups (K side 64 channels, blocks tile the image exactly)
     (2, 16, 24, 48, 96),        # ... three chunks, six 16-cout tiles
+    # ring kernel (conv_wino_ring.hip: K side of 64 and more channels where the filter is not resident)
+    (2, 81, 81, 64, 64),        # 8 x 8 blocks tile 81 x 81 with 18 % padding: ring instead of the resident kernel; partial blocks at both borders
+    (4, 20, 20, 128, 64),       # 10 x 10 tiles per image: blocks that are not 4 x 4 tiles
+    (7, 10, 10, 128, 96),       # several images per block, image count not a multiple of it, three cout tiles
+    (1, 40, 40, 256, 32),       # 16 chunks, one cout tile: fewer block groups than CUs
+    (3, 10, 10, 512, 512),      # VGG conv5: 32 chunks x 16 cout tiles
+    (2, 33, 47, 80, 160),       # 5 chunks, 5 cout tiles, odd sizes
 ]
 
 
@@ -478,9 +485,17 @@ def _pack_wino(hip, w, transpose):
     return buf
 
 
+@pytest.fixture(params=["planned", "ring"])
+def streamed_kernel(request, monkeypatch):
+    """Streamed Winograd layers on the kernel the launcher's cost estimates pick ("planned") and all on the ring kernel ("ring")."""
+    if request.param == "ring":
+        monkeypatch.setenv("AESR_WINO_RING", "2")
+    return request.param
+
+
 @pytest.mark.parametrize("case", WINO_CASES)
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
-def test_conv_wino_fwd(hip, case, act):
+def test_conv_wino_fwd(hip, case, act, streamed_kernel):
     """Forward with bias and every fused activation against an fp64 convolution (1e-5; measured 2-4e-7) and against the
     implicit-GEMM kernel of the same library."""
     N, H, W, Cin, Cout = case
@@ -511,7 +526,7 @@ def test_conv_wino_fwd(hip, case, act):
 
 @pytest.mark.parametrize("case", WINO_CASES)
 @pytest.mark.parametrize("mask_act", [0, 1, 2])
-def test_conv_wino_dgrad(hip, case, mask_act):
+def test_conv_wino_dgrad(hip, case, mask_act, streamed_kernel):
     """Data gradient (flipped / transposed filter) with the fused derivative mask of the producing activation."""
     N, H, W, Cout, Cin = case            # roles swapped so that the data-gradient constraints (Cout % 16, Cin % 32) hold
     assert hip.lib.aesr_conv2d_wino_supported(Cin, Cout, 3, 1, 1) == 1
@@ -530,6 +545,36 @@ def test_conv_wino_dgrad(hip, case, mask_act):
                                              hip.stream()), "wino_dgrad")
     torch.cuda.synchronize()
     assert rel_l2(nchw(dx), ref) < 1e-5
+
+
+def test_conv_wino_ring_kernel_selection_and_watchdog(hip, monkeypatch):
+    """Layers with many K-side channels run on the ring kernel (kernel id 3); its arrival-counter watchdog never fired in this process;
+    forced block shapes (every compile-time patch width of the kernel) give the same results as the planned ones."""
+    L = hip.lib
+    assert L.aesr_conv2d_wino_kernel(36, 40, 40, 128, 128, 3, 1, 0) == 3
+    assert L.aesr_conv2d_wino_kernel(36, 162, 162, 32, 32, 3, 1, 0) == 2
+    monkeypatch.setenv("AESR_WINO_RING", "2")           # every streamed layer on the ring kernel, whatever the cost estimates say
+    assert L.aesr_conv2d_wino_kernel(36, 81, 81, 64, 64, 3, 1, 0) == 3
+    g = torch.Generator().manual_seed(5)
+    Cin, Cout, H, W = 128, 64, 18, 22
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    up = D(_pack_wino(hip, w.cuda(), 0))
+    # the plan is cached per (N, H, W, channels): a different image count per forced shape
+    for n, shape in enumerate(["", "1,4,4", "1,3,5", "2,1,5", "2,2,4", "1,1,7", "4,1,4", "1,2,6", "1,5,3", "1,2,2"]):
+        N = 3 + n
+        if shape:
+            monkeypatch.setenv("AESR_RING_SHAPE", shape)
+        x = torch.randn(N, Cin, H, W, generator=g)
+        ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.01)
+        out = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+        hip.check(L.aesr_conv2d_wino_fwd(hip.ptr(D(nhwc(x))), hip.ptr(up), hip.ptr(b.cuda()), hip.ptr(out), N, H, W, Cin, Cout, 1, 0.01, hip.stream()),
+                  "wino_fwd " + shape)
+        torch.cuda.synchronize()
+        assert rel_l2(nchw(out), ref) < 1e-5, shape
+    monkeypatch.delenv("AESR_RING_SHAPE", raising=False)
+    monkeypatch.delenv("AESR_WINO_RING", raising=False)
+    assert L.aesr_conv2d_wino_ring_timeouts() == 0
 
 
 def test_conv_wino_argument_errors(hip):
@@ -569,8 +614,9 @@ def test_conv_wgrad_wino(hip, case):
     assert torch.equal(dw, dw2)
 
 
-@pytest.mark.parametrize("case", [(3, 80, 80, 64, 32), (2, 160, 160, 32, 32), (2, 6, 10, 32, 64), (1, 2, 2, 32, 32)])
-def test_conv_wino_folded_upsample(hip, case):
+@pytest.mark.parametrize("case", [(3, 80, 80, 64, 32), (2, 160, 160, 32, 32), (2, 6, 10, 32, 64), (1, 2, 2, 32, 32), (2, 40, 40, 128, 64),
+                                  (3, 24, 40, 64, 128), (2, 20, 12, 128, 128)])
+def test_conv_wino_folded_upsample(hip, case, streamed_kernel):
     """nearest Upsample(x2) in front of a 3x3 convolution folded into the Winograd kernels (Decoder, networks/acai_vanilla.py:92-96):
     forward and weight gradient read the half-resolution tensor through (y/2, x/2); the data gradient stores the 2x2 block sums."""
     N, H, W, Cin, Cout = case              # H, W: the convolution's (upsampled) size
@@ -645,8 +691,9 @@ def test_conv_wgrad_wino_baseline_size_repeatable(hip, case):
     assert float((outs[0][1].double() - dy.double().sum((0, 1, 2))).norm() / dy.double().sum((0, 1, 2)).norm()) < 2e-6
 
 
-@pytest.mark.parametrize("case", [(36, 162, 162, 32, 32), (36, 160, 160, 32, 64), (36, 81, 81, 64, 64), (36, 80, 80, 64, 64), (36, 40, 40, 128, 128)])
-def test_conv_wino_baseline_size_repeatable(hip, case):
+@pytest.mark.parametrize("case", [(36, 162, 162, 32, 32), (36, 160, 160, 32, 64), (36, 81, 81, 64, 64), (36, 80, 80, 64, 64), (36, 40, 40, 128, 128),
+                                  (24, 80, 80, 128, 128), (24, 20, 20, 512, 512), (6, 40, 40, 128, 128)])
+def test_conv_wino_baseline_size_repeatable(hip, case, streamed_kernel):
     """Forward (resident-filter kernel for Cin = 32, streamed kernel above) and masked data gradient at 36 images."""
     N, H, W, Cin, Cout = case
     L = hip.lib

@@ -31,13 +31,19 @@ def test_cabi_exports_every_declared_symbol():
     assert _hip.lib.aesr_conv2d_packed_floats(1, 32, 3, 0) == 9 * 32 * 16          # Cout padded to one MFMA block
     assert _hip.lib.aesr_conv2d_wgrad_workspace_floats(24, 160, 160, 32, 32, 3, 1) > 0
     # which Winograd kernel serves a layer (host-side rule, conv_wino_res.hip): resident filter for K-side channels <= 32, and
-    # <= 64 where 8 x 8-output blocks tile the image with <= 10 % padding; the streamed kernel otherwise; 0 = not a Winograd layer
+    # <= 64 where 8 x 8-output blocks tile the image with <= 10 % padding; the ring kernel (conv_wino_ring.hip; AESR_WINO_RING=0: the
+    # first streamed kernel) otherwise; 0 = not a Winograd layer
     k = _hip.lib.aesr_conv2d_wino_kernel
     if os.environ.get("AESR_WINO_RES") is None:
-        assert k(160, 160, 32, 32, 3, 1, 0) == 2 and k(81, 81, 32, 64, 3, 1, 0) == 2
-        assert k(80, 80, 64, 32, 3, 1, 0) == 2 and k(81, 81, 64, 64, 3, 1, 0) == 1 and k(40, 40, 128, 128, 3, 1, 0) == 1
-        assert k(80, 80, 32, 64, 3, 1, 1) == 2          # data gradient: the K side is Cout
-    assert k(160, 160, 3, 64, 3, 1, 0) == 0 and k(160, 160, 32, 32, 1, 0, 0) == 0
+        assert k(36, 160, 160, 32, 32, 3, 1, 0) == 2 and k(36, 81, 81, 32, 64, 3, 1, 0) == 2
+        assert k(36, 80, 80, 64, 32, 3, 1, 0) == 2
+        assert k(36, 80, 80, 32, 64, 3, 1, 1) == 2          # data gradient: the K side is Cout
+        if os.environ.get("AESR_WINO_RING") is None:
+            # streamed layers: the ring kernel where its cost estimate is lower (blocks tile the image, a round of items or more) ...
+            assert k(36, 40, 40, 128, 128, 3, 1, 0) == 3 and k(24, 80, 80, 128, 128, 3, 1, 0) == 3 and k(24, 20, 20, 512, 512, 3, 1, 0) == 3
+            # ... the first streamed kernel on 81 x 81 (18 % block padding) and on VGG conv5 (less than a round of ring items)
+            assert k(36, 81, 81, 64, 64, 3, 1, 0) == 1 and k(24, 10, 10, 512, 512, 3, 1, 0) == 1
+    assert k(36, 160, 160, 3, 64, 3, 1, 0) == 0 and k(36, 160, 160, 32, 32, 1, 0, 0) == 0
 
 
 def test_net_config_matches_reference_table():
