@@ -36,6 +36,7 @@ struct WinoArgs {
     // ring kernel (conv_wino_ring.hip), filled by its launcher: waves per workgroup, patch row pitch / image stride / buffer size in
     // floats, bank swizzle of the channel quads f(px) = (((px >> sw_a) & sw_m) << sw_b) & 3
     int nw, rowP, imgP, patch_fl, sw_a, sw_m, sw_b;
+    int xcd_map;                 // resident-filter kernel: XCD-aware workgroup -> block map (set by its launcher)
     double plan_cost;            // cost estimate (cycles) of the first streamed kernel's plan for this layer: the ring kernel runs where its own is lower
     int nfull, tail_k;           // item list: groups of 8 blocks, then the last partial round in groups of tail_k <= 4 blocks
 };

@@ -56,7 +56,15 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
     const int ncot = a.CoutP / WR_TN, nchunks = a.CinP >> 4;
-    const int cot = blockIdx.x % ncot, wgc = blockIdx.x / ncot, nwgc = gridDim.x / ncot;
+    // Workgroup -> (cout tile, spatial worker).  Workgroups b and b + 8 share an XCD (round-robin placement: speed only, never
+    // correctness): where the grid allows, XCD x takes a CONTIGUOUS run of blocks per round and all cout tiles of a block sit on it,
+    // so the 10 x 10 patches of neighbouring blocks (1.56 x the image) and the re-reads by the other cout tiles hit that XCD's L2
+    // instead of crossing the fabric (round 2 PMC: 2.4 x the algorithmic bytes read).  Otherwise: cout tile = b % ncot as before.
+    const bool xmap = a.xcd_map != 0;
+    const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3;
+    const int cot = xmap ? lw % ncot : blockIdx.x % ncot;
+    const int wgc = xmap ? lw / ncot : blockIdx.x / ncot;               // spatial worker (inside the XCD / of the grid)
+    const int nwgc = xmap ? (gridDim.x >> 3) / ncot : gridDim.x / ncot;
     const int co0 = cot * WR_TN;
     float* const ldsW = lds;                                        // [nchunks][16 positions][4][32][4]
     float* const ldsP = lds + nchunks * WR_WFL + wave * WR_PFL;     // this wave's patch: [10 rows][16 pixel slots][16 ch] (+ pitch)
@@ -102,8 +110,9 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
     // item k of this wave: block wgc + nwgc * (wave + 8 k) of the N x BY x BX blocks of 8 x 8 outputs (a partial last round lands on
     // wave 0 of many workgroups, not on all waves of a few)
 #define WR_DIV(x, m) ((m) ? (int)__umulhi((unsigned)(x), (m)) : (int)(x))          /* m == 0: divisor 1 */
-    int item = wgc + nwgc * wave;
-    const int istep = nwgc * 8;
+    // XCD map: round k, XCD x = blocks [(8 k + x) * 8 nwgc, + 8 nwgc), wave w of worker s takes block w * nwgc + s of them
+    int item = (xmap ? xcd * (8 * nwgc) : 0) + wgc + nwgc * wave;
+    const int istep = (xmap ? 64 : 8) * nwgc;
     // the patch of (item, chunk) -> this wave's LDS buffer: 10 DMAs; out-of-range rows / columns deliver zeros
     int in_n = 0, in_y0 = 0, in_x0 = 0;
     auto locate = [&](int it) {
@@ -319,7 +328,10 @@ static int wino_res_launch_one(const WinoArgs& a, hipStream_t st) {
     const int per_cot = ceil_div(a.nblk, 8);               // more workgroups than 8-wave rounds of blocks would idle
     if (grid / ncot > per_cot) grid = per_cot * ncot;
     if (grid < ncot) grid = ncot;
-    hipLaunchKernelGGL((conv_wino_res_f32<WR_TN, MASK>), dim3(grid), dim3(WR_NT), shmem, st, a);
+    WinoArgs b = a;
+    static const int xmap_on = getenv("AESR_WINO_XCD") ? atoi(getenv("AESR_WINO_XCD")) : 1;
+    b.xcd_map = (xmap_on && grid % (8 * ncot) == 0) ? 1 : 0;
+    hipLaunchKernelGGL((conv_wino_res_f32<WR_TN, MASK>), dim3(grid), dim3(WR_NT), shmem, st, b);
     AESR_LAUNCH_CHECK("conv_wino_res_f32");
     return AESR_OK;
 }
