@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: ``ae_combined`` training slices/s on synthetic ACDC-shaped batches (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W [--config c2|c3]
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5]
 
 A step = one ae_combined training step (4 network passes, backward, Adam) over one batch of 12 synthetic triplets
 (36 slices of 160x160) that is already resident in HBM.  N > 1: launched by torch.distributed.run, one rank per GPU
@@ -9,6 +9,7 @@ over RCCL; the 12 triplets are sharded over the ranks (fixed global batch -> str
 Rank 0 prints ONE JSON line (see DESIGN.md section "Measurement").
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -20,21 +21,41 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-# algorithmic conv FLOPs per training step (SURVEY.md section 8a / BASELINE.md section 2), B=12, 160x160, scales 2
+# algorithmic conv FLOPs per training step (SURVEY.md section 8a / BASELINE.md section 2)
 STEP_GFLOP = {"c2": 330.8, "c3": 894.5, "c4": 2223.5, "c5": 1524.4, "c3_scales3": 959.6}
 # BASELINE configs[3], configs[4] on ONE rank (secondary numbers; the headline metric is quoted on c2): name -> (dataset, B, H, width, latent_width)
 BRAIN = {"c4": ("OASIS", 16, 220, 64, 16), "c5": ("dHCP", 8, 256, 256, 64)}
+WORKLOAD = {
+    "c2": "ACDC synthetic 12x(3x1x160x160) triplets, ae_combined latent=128 depth=32 scales=2, MSE synthesis loss (BASELINE configs[1])",
+    "c3": "ACDC synthetic 12x(3x1x160x160) triplets, ae_combined latent=128 depth=32 scales=2, LPIPS-VGG synthesis loss lambda=0.05, "
+          "synthetic backbone weights (BASELINE configs[2])",
+    "c4": "OASIS synthetic 16x(3x1x220x220) triplets (global batch), ae_combined latent=128 depth=32, LPIPS-VGG synthesis loss lambda=0.001, "
+          "synthetic backbone weights (BASELINE configs[3] on one rank)",
+    "c5": "dHCP synthetic 8x(3x1x256x256) triplets (global batch), ae_combined latent=128 depth=32, LPIPS-VGG synthesis loss lambda=0.001, "
+          "synthetic backbone weights (BASELINE configs[4] on one rank)",
+}
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+MFMA_KINDS = ("conv_wino_f32", "conv_wino_ring_f32", "conv_wino_res_f32", "conv_wgrad_wino_f32", "conv_igemm_f32", "conv_wgrad_f32")
 
 
 def stem_folded_gflop(B, H):
     """MFMA flops of the reference's op count that no longer run on the matrix cores: the 32->32 3x3 convolution behind the
     encoder stem is folded with the 1x1 stem into one bandwidth-bound 1->32 convolution (csrc/conv_thin.hip).  That layer ran
     forward on 3B images (x[2B] and the logging-only slice_between[B]) and its data and weight gradients on 2B images each:
-    7B image passes x (H+2)^2 x 32*32*9*2 flop = 40.63 GF at B=12, H=160 (330.8 -> 290.17 GF executed)."""
+    7B image passes x (H+2)^2 x 32*32*9*2 flop = 40.63 GF at B=12, H=160 (330.8 -> 290.17 GF on the matrix cores)."""
     return 7.0 * B * (H + 2) ** 2 * 32 * 32 * 9 * 2 / 1e9
 
 
-PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+def csrc_sha():
+    """Hash of the kernel sources: the PMC traffic files under profiles/ carry the hash they were measured at, and a stale one is
+    not quoted (``traffic: null``)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "superresolution_aniso_mri_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build_args(config, device, scales3=False):
@@ -54,16 +75,27 @@ def build_args(config, device, scales3=False):
     return args
 
 
-def cpu_baseline(B, H, steps=3):
-    """The oracle (PyTorch-CPU restatement of the same step, MSE synthesis loss) on this host's cores."""
-    from oracle import ae_oracle, step_oracle
+def config_shape(config, triplets=0):
+    B, H = (12, 160) if config not in BRAIN else (BRAIN[config][1], BRAIN[config][2])
+    return (int(triplets) if triplets else B), H
+
+
+def cpu_baseline(config, B, H, steps=3):
+    """The oracle (PyTorch-CPU restatement of the same step, with the configuration's own synthesis loss) on this host's cores."""
+    import numpy as np
+    from oracle import ae_oracle, lpips_oracle, step_oracle
     from superresolution_aniso_mri_amd.data_synth import synthetic_batch
     # a 1-GPU box gives this process a 16-CPU share of the host: more intra-op threads than that only oversubscribe
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(max(1, min(16, avail)))
     torch.manual_seed(892372)
     ae = ae_oracle.OracleAE(ae_oracle.acdc_args())
-    st = step_oracle.OracleStep(ae, lr=1e-5, ex_loss_weight1=0.05, image_mix_loss_func="mse")
+    kw, lossname = {}, "MSE synthesis loss"
+    if config != "c2":
+        lin = np.load(os.path.join(ROOT, "superresolution_aniso_mri_amd", "lpips", "weights", "v0.1", "vgg_lin.npz"))
+        kw = dict(vgg_sd=lpips_oracle.hash_vgg16_state(), lin_w=[torch.from_numpy(lin["lin%d" % k]).reshape(1, -1, 1, 1) for k in range(5)])
+        lossname, steps = "LPIPS-VGG synthesis loss (synthetic backbone)", 2
+    st = step_oracle.OracleStep(ae, lr=1e-5, ex_loss_weight1=0.05, image_mix_loss_func="mse" if config == "c2" else "perceptual", **kw)
     batch = synthetic_batch(B, H, H, seed=892372)
     st.train(batch["image"], batch["slice_between"])            # warm-up
     t0 = time.perf_counter()
@@ -71,69 +103,200 @@ def cpu_baseline(B, H, steps=3):
         st.train(batch["image"], batch["slice_between"])
     dt = (time.perf_counter() - t0) / steps
     return {"value": round(3 * B / dt, 2), "unit": "slices/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d steps (after 1 warm-up) of the same workload: B=%d triplets %dx%d, MSE synthesis loss, "
-                      "oracle/step_oracle.py on PyTorch-CPU fp32" % (steps, B, H, H), "s_per_step": round(dt, 3)}
+            "sample": "%d steps (after 1 warm-up) of the same workload: B=%d triplets %dx%d, %s, oracle/step_oracle.py on PyTorch-CPU fp32"
+                      % (steps, B, H, H, lossname), "s_per_step": round(dt, 3)}
 
 
-def make_line(opt, B, H, elapsed, launch, loss, roofline, engine):
-    """The JSON line of the contract for ``opt.steps`` steps that took ``elapsed`` seconds (max over ranks)."""
-    ms_per_step = 1e3 * elapsed / opt.steps
-    executed = STEP_GFLOP[opt.config] - (stem_folded_gflop(B, H) if engine.FUSE_STEM else 0.0)
-    line = {
-        "metric": "training slices/sec (ae_combined, %dx%d, latent=128)" % (H, H), "value": round(3 * B * opt.steps / elapsed, 1),
-        "unit": "slices/s", "n_gpus": opt.gpus, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("ACDC synthetic 12x(3x1x160x160) triplets, ae_combined latent=128 depth=32 scales=2, "
-                                + ("MSE synthesis loss (BASELINE configs[1])" if opt.config == "c2"
-                                   else "LPIPS-VGG synthesis loss lambda=0.05, synthetic backbone weights (BASELINE configs[2])"))
-                   if opt.config not in BRAIN else
-                   "%s synthetic %dx(3x1x%dx%d) triplets (global batch), ae_combined latent=128 depth=32, LPIPS-VGG synthesis loss lambda=0.001, "
-                   "synthetic backbone weights (BASELINE configs[%d])" % (BRAIN[opt.config][0], B, H, H, 3 if opt.config == "c4" else 4),
-                   "global_batch_triplets": B, "slices_per_step": 3 * B, "parallelism": "dp%d" % opt.gpus,
-                   "init": "reference Initializer, seed 892372, random weights", "launch": launch},
-        "step_algorithmic_gflop": STEP_GFLOP[opt.config],
-        "step_executed_mfma_gflop": round(executed, 2),
-        "step_tflops": round(executed / ms_per_step, 2),
-        "step_frac_of_f32_mfma_peak": round(executed / ms_per_step / PEAK_F32_MFMA_TFLOPS, 4),
-        "final_loss": round(float(loss), 6),
-    }
-    if roofline is not None:
-        line["roofline"] = roofline
-    return line
+def timed_steps(trainer, pool, steps, warmup, dp=None):
+    """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; max over ranks.  Seconds."""
+    def run(n, first=0):
+        for i in range(n):
+            trainer.train(pool[(first + i) % len(pool)], keep_predictions=False)
+    def sync():
+        if dp is not None and dp.active:
+            dp.synchronize()            # torch.cuda.synchronize() with a deadline: a dead peer ends the run (non-zero exit), no hang
+        else:
+            torch.cuda.synchronize()
+    run(warmup)
+    if dp is not None:
+        dp.barrier()
+    sync()
+    t0 = time.perf_counter()
+    run(steps, warmup)
+    sync()
+    if dp is not None:
+        dp.barrier()
+    dt = time.perf_counter() - t0
+    return dp.max_over_ranks(dt) if dp is not None else dt
 
 
-def secondary_measurements(device, steps=10, warmup=4):
-    """The other single-GPU configurations north_star asks for, measured the same way (inputs resident, captured-graph replay,
-    K steps between synchronizes) AFTER the headline measurement: BASELINE configs[2] (C3: + LPIPS), C3 with the README-literal
-    three pooling stages, and the 256x256 configuration (configs[4] on one rank).  Reported inside the one JSON line."""
-    from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+def make_trainer(config, device, B, H, scales3=False, graph=True, npool=4, dp=None):
+    from superresolution_aniso_mri_amd.data_synth import shard_batch, synthetic_batch
     from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
-    out = {}
-    for name, config, scales3 in (("c3", "c3", False), ("c3_scales3", "c3", True), ("c5", "c5", False)):
-        B, H = (12, 160) if config not in BRAIN else (BRAIN[config][1], BRAIN[config][2])
-        torch.manual_seed(892372)
-        tr = get_trainer_dynamic(build_args(config, device, scales3=scales3))
-        tr.enable_step_graph(eager_steps=2)
-        pool = []
-        for i in range(2):
-            b = synthetic_batch(B, H, H, seed=892372 + i, brain=config in BRAIN)
-            pool.append({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items()})
-        for i in range(warmup):
-            tr.train(pool[i % 2], keep_predictions=False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            tr.train(pool[i % 2], keep_predictions=False)
-        torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / steps
-        gf = STEP_GFLOP[name]
-        out[name] = {"workload": "%d triplets of %dx%d, LPIPS-VGG synthesis loss%s" % (B, H, H, ", scales 3 (latent_width 16)" if scales3 else ""),
-                     "ms_per_step": round(ms, 3), "slices_per_s": round(3 * B / ms * 1e3, 1), "steps": steps, "warmup": warmup,
-                     "step_algorithmic_gflop": gf, "step_algorithmic_tflops": round(gf / ms, 2),
-                     "frac_of_f32_mfma_peak": round(gf / ms / PEAK_F32_MFMA_TFLOPS, 4), "final_loss": round(float(tr.losses["loss_ae"][-1]), 6)}
-        del tr, pool
+    torch.manual_seed(892372)
+    trainer = get_trainer_dynamic(build_args(config, device, scales3=scales3))
+    if dp is not None and dp.active:
+        dp.attach(trainer)
+        dp.set_batch(B)
+    if graph:
+        trainer.enable_step_graph(eager_steps=2)        # data parallel: the form follows the data plane (parallel.DataParallelContext.graph_mode)
+    pool = []       # a small pool of distinct batches, sharded by triplet and resident in HBM before the timed region
+    for i in range(npool):
+        b = synthetic_batch(B, H, H, seed=892372 + i, brain=config in BRAIN)
+        if dp is not None and dp.active:
+            b = shard_batch(b, dp.rank, dp.world)
+        pool.append({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items()})
+    return trainer, pool
+
+
+def roofline_of(engine, device, nst, config, B, H, gpus, scales3=False):
+    """The same steps again, host-launched on a trainer of their own (event pairs need host-side launches; a trainer that has replayed
+    graphs keeps its pool and times the first eager launches wrongly), with one HIP-event pair around every MFMA convolution launch
+    (on the launching stream).  Dominant kernel
+    = the MFMA convolution kernel with the most time in the step.  Kinds are the library's kernels: conv_wino_f32 / conv_wino_ring_f32
+    / conv_wino_res_f32 (Winograd forward + data gradient: first streamed kernel, filter ring, resident filter), conv_wgrad_wino_f32
+    (Winograd weight gradient), conv_igemm_f32 / conv_wgrad_f32 (direct forms, where the Winograd ones do not apply)."""
+    trainer, pool = make_trainer(config, device, B, H, scales3=scales3, graph=False, npool=2)
+    for i in range(3):
+        trainer.train(pool[i % len(pool)], keep_predictions=False)
+    torch.cuda.synchronize()
+    engine.PROFILER = engine.KernelProfiler()
+    for i in range(nst):
+        trainer.train(pool[i % len(pool)], keep_predictions=False)
+    summ = engine.PROFILER.summary()
+    engine.PROFILER = None
+    del trainer, pool
+    kname = max(MFMA_KINDS, key=lambda n: summ.get(n, {"ms": 0.0})["ms"])
+    k = summ.get(kname, {"launches": 0, "flops": 0.0, "ms": 1e-9})
+    ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["launches"] else 0.0
+    wino = "wino" in kname
+    executed = ach / 2.25 if wino else ach
+    roofline = {"bound": "mfma", "kernel": kname, "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "algorithmic_achieved": round(ach, 2), "algorithmic_frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                "launches_per_step": k["launches"] // nst, "avg_launch_us": round(1e3 * k["ms"] / max(1, k["launches"]), 2),
+                "algorithmic_gflop_per_launch": round(k["flops"] / max(1, k["launches"]) / 1e9, 3),
+                "kernel_ms_per_step": round(k["ms"] / nst, 3), "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
+                "flop_basis": ("achieved / frac = flops EXECUTED on the matrix cores: the kernel is Winograd F(2x2,3x3) and runs 1/2.25 of the "
+                               "algorithmic flops (direct 3x3 convolution, 2*N*H*W*Cout*9*Cin per launch, SURVEY 8d), on which "
+                               "algorithmic_achieved / algorithmic_frac are quoted" if wino else "algorithmic = executed"),
+                "measured": "HIP events around every launch, %d instrumented steps after the timed region" % nst}
+    roofline["other_kernels"] = [
+        {"kernel": n, "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / (2.25 if "wino" in n else 1.0), 2),
+         "algorithmic_achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+         "ms_per_step": round(v["ms"] / nst, 3), "launches_per_step": v["launches"] // nst}
+        for n, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]) if n != kname and n in MFMA_KINDS and v["launches"]]
+    # HBM-side bytes per launch of the same kernel: PMC counters cannot be read from inside this process; they come from the
+    # committed rocprofv3 --pmc passes of this very command (scripts/profile_all.sh -> profiles/), N=1 and B=12 only, and only
+    # while the kernel sources are the ones the passes were measured on
+    tpath = os.path.join(ROOT, "profiles", "r03_%s_hbm_traffic.json" % config)
+    if gpus == 1 and B == 12 and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("csrc_sha") == csrc_sha():
+            ig = [v for name, v in tj["kernels"].items() if (kname + "<") in name or (kname + "(") in name]
+            nl = sum(v["launches_per_step"] for v in ig)
+            if nl > 0:
+                roofline["traffic"] = round(sum(v["MB_per_step"] for v in ig) / nl * 1e6)
+                roofline["traffic_unit"] = ("bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_%s_hbm_traffic.json, "
+                                            "kernel sources %s)" % (config, tj["csrc_sha"]))
+        else:
+            roofline["traffic_note"] = "profiles/r03_%s_hbm_traffic.json was measured on other kernel sources (%s, now %s): not quoted" % (
+                config, tj.get("csrc_sha"), csrc_sha())
+    return roofline
+
+
+def step_numbers(config, B, H, ms_per_step, fuse_stem, scales3=False):
+    """Step-level flop rates: the reference's op count (what the 70 % target of north_star is read against) and, beside it,
+    what the matrix cores execute (the op count minus the folded stem layer, in Winograd form 1/2.25 of it; the only MFMA layer that is
+    not Winograd, VGG conv1_1, is 0.3 % of the C3 step)."""
+    gf = STEP_GFLOP[config + "_scales3" if scales3 else config] * (B / float(config_shape(config)[0]))
+    executed = (gf - (stem_folded_gflop(B, H) if fuse_stem else 0.0)) / 2.25
+    return {"step_algorithmic_gflop": round(gf, 1), "step_algorithmic_tflops": round(gf / ms_per_step, 2),
+            "step_algorithmic_frac_of_f32_mfma_peak": round(gf / ms_per_step / PEAK_F32_MFMA_TFLOPS, 4),
+            "step_executed_mfma_gflop": round(executed, 2),
+            "step_executed_frac_of_f32_mfma_peak": round(executed / ms_per_step / PEAK_F32_MFMA_TFLOPS, 4)}
+
+
+def secondary_config(engine, config, device, scales3=False, steps=10, warmup=4, with_roofline=False, with_cpu=False):
+    B, H = config_shape(config)
+    trainer, pool = make_trainer(config, device, B, H, scales3=scales3, npool=2)
+    ms = 1e3 * timed_steps(trainer, pool, steps, warmup) / steps
+    out = {"workload": WORKLOAD[config] + (", scales 3 (latent_width 16)" if scales3 else ""), "ms_per_step": round(ms, 3),
+           "slices_per_s": round(3 * B / ms * 1e3, 1), "steps": steps, "warmup": warmup,
+           "final_loss": round(float(trainer.losses["loss_ae"][-1]), 6)}
+    out.update(step_numbers(config, B, H, ms, engine.FUSE_STEM, scales3))
+    del trainer, pool
+    torch.cuda.empty_cache()
+    if with_roofline:
+        out["roofline"] = roofline_of(engine, device, 3, config, B, H, 1, scales3)
         torch.cuda.empty_cache()
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(config, B, H)
     return out
+
+
+def small_shards(device):
+    """What strong scaling over 12 triplets runs on: the replayed step at 1 / 2 / 3 / 6 triplets on ONE GPU (c2 and c3), and the rate an
+    8-rank run is bounded by -- 36 slices per step of the slowest rank (2 triplets: 12 over 8 ranks = 2,2,2,2,1,1,1,1) plus the
+    enqueue cost of the step's 9 collectives measured on a one-rank communicator (no wire time: a lower bound on the step)."""
+    out = {}
+    for config in ("c2", "c3"):
+        row = {}
+        for t in (1, 2, 3, 6):
+            trainer, pool = make_trainer(config, device, t, 160, npool=2)
+            row["%d_triplets_ms" % t] = round(1e3 * timed_steps(trainer, pool, 20, 6) / 20, 3)
+            del trainer, pool
+        torch.cuda.empty_cache()
+        out[config] = row
+    coll_us = None
+    try:
+        from superresolution_aniso_mri_amd.parallel import one_rank_collective_cost_us
+        coll_us = one_rank_collective_cost_us(device)
+    except Exception as e:       # no RCCL on this box: the projection is quoted without the collectives
+        out["collectives_note"] = "one-rank RCCL communicator unavailable (%s)" % (str(e)[:120],)
+    for config in ("c2", "c3"):
+        step_ms = out[config]["2_triplets_ms"] + (9 * coll_us * 1e-3 if coll_us is not None else 0.0)
+        out[config]["projected_8_rank_slices_per_s"] = round(36.0 / step_ms * 1e3, 1)
+    out["collective_enqueue_us"] = None if coll_us is None else round(coll_us, 2)
+    out["projection"] = "36 slices / (2-triplet step + 9 collectives x the one-rank enqueue cost): an upper bound on the 8-rank rate"
+    return out
+
+
+def inference_bench(device):
+    """BASELINE configs[4] inference leg: generate_hr_volumes.create_super_volume on a synthetic dHCP-shaped volume cropped to the
+    evaluation patch (z = 30 slices of 224 x 224, 3 interpolations per pair), volume resident in HBM, output left in HBM."""
+    import numpy as np
+    from superresolution_aniso_mri_amd import generate_hr_volumes as ghv
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    Z, H, n = 30, 224, 3
+    torch.manual_seed(892372)
+    tr = get_trainer_dynamic(build_args("c5", device), eval_mode=True)
+    vol = torch.rand(Z, 1, H, H, device=device)
+    alphas = np.linspace(0, 1, n + 2, endpoint=True)[1:-1]
+    for _ in range(2):
+        ghv.create_super_volume(tr, vol, alphas, use_original=True, to_cpu=False)
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = ghv.create_super_volume(tr, vol, alphas, use_original=True, to_cpu=False)["upsampled_image"]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    synth = (Z - 1) * n
+    # algorithmic flops (direct convolutions of the reference's layers): every slice encoded once, every synthesised slice decoded once
+    h1, h2, h4 = H + 2, (H + 2) // 2, (H + 2) // 4
+    enc = 2.0 * (32 * h1 * h1 + 9 * (2 * 32 * 32 * h1 * h1 + (32 * 64 + 64 * 64) * h2 * h2 + (64 * 128 + 128 * 128) * h4 * h4))
+    dec = 2.0 * 9 * ((128 * 64 + 64 * 64) * h4 * h4 + (64 * 32 + 32 * 32) * (2 * h4) ** 2 + (32 * 32 + 32) * (4 * h4) ** 2)
+    gf = (Z * enc + synth * dec) / 1e9
+    del tr
+    torch.cuda.empty_cache()
+    return {"workload": "generate_hr_volumes.create_super_volume: synthetic volume %d x %d x %d (eval_patch_size 224), %d interpolations per "
+                        "slice pair, dHCP model (latent 128), random weights, input and output resident in HBM" % (Z, H, H, n),
+            "ms_per_volume": round(dt * 1e3, 3), "synthesised_slices_per_s": round(synth / dt, 1), "output_slices": int(out.shape[0]),
+            "algorithmic_gflop": round(gf, 2), "algorithmic_tflops": round(gf / dt / 1e3, 2),
+            "algorithmic_frac_of_f32_mfma_peak": round(gf / dt / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+            "reference_executes": "2n(z-1) encoder passes + n(z-1) decoder passes (generate_hr_volumes.py:72-101); here z encoder passes, "
+                                  "z decoder-stem passes and n(z-1) passes of the rest of the decoder"}
 
 
 def main():
@@ -149,18 +312,17 @@ def main():
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--triplets", type=int, default=12, help="global batch in triplets (12 = the BASELINE workload; other values are for experiments only)")
+    ap.add_argument("--triplets", type=int, default=0, help="global batch in triplets (default: the BASELINE workload; other values are for experiments only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured step")
     ap.add_argument("--dp-graph", choices=("on", "off"), default="on",
                     help="N > 1: 'on' (default) replays the step from the captured graph (RCCL data plane: ONE graph with the collectives "
                     "as nodes; gloo rehearsal: graph segments between eager collectives); 'off' launches every kernel from the host. "
                     "A failure in either form ends the run with a non-zero exit code: no other form is substituted")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary single-GPU measurements (c3, c3 with scales 3, c5)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary single-GPU measurements (c3, c3 with scales 3, c4, c5, "
+                    "small shards, inference)")
     opt = ap.parse_args()
 
     from superresolution_aniso_mri_amd import engine
-    from superresolution_aniso_mri_amd.data_synth import shard_batch, synthetic_batch
-    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
     from superresolution_aniso_mri_amd.parallel import DataParallelContext
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,109 +333,56 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
-    dp = DataParallelContext(device=device)
-    B, H = opt.triplets, 160
-    if opt.config in BRAIN:
-        B, H = BRAIN[opt.config][1], BRAIN[opt.config][2]
-    torch.manual_seed(892372)
-    trainer = get_trainer_dynamic(build_args(opt.config, device))
-    if dp.active:
-        dp.attach(trainer)
-        dp.set_batch(B)
-    use_graph = not opt.no_graph and (not dp.active or opt.dp_graph == "on")
-    if use_graph:
-        trainer.enable_step_graph(eager_steps=2)        # data parallel: the form follows the data plane (parallel.DataParallelContext.graph_mode)
-    # a small pool of distinct batches, sharded by triplet and resident in HBM before the timed region
-    pool = []
-    for i in range(4):
-        b = synthetic_batch(B, H, H, seed=892372 + i, brain=opt.config in BRAIN)
-        if dp.active:
-            b = shard_batch(b, dp.rank, dp.world)
-        pool.append({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items()})
-
-    def run(n, first=0):
-        for i in range(n):
-            trainer.train(pool[(first + i) % len(pool)], keep_predictions=False)
-
-    def measure():
-        """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; max over ranks."""
-        run(opt.warmup)
-        dp.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(opt.steps, opt.warmup)
-        torch.cuda.synchronize()
-        dp.barrier()
-        return dp.max_over_ranks(time.perf_counter() - t0)
-
-    elapsed = measure()
-    launch = "host launches"
-    if use_graph:
-        launch = ("captured HIP graph replay" if not dp.active else
-                  "one HIP graph per step, RCCL collectives (library-owned communicator) as graph nodes" if dp.graph_mode == "whole" else
-                  "HIP graph segments between eager host-staged (gloo) collectives")
-        if not getattr(trainer, "_graphs", None):
-            raise SystemExit("bench: the step graph was requested but never captured")
-    loss = trainer.losses["loss_ae"][-1]
-
-    roofline = None
-    if not opt.no_roofline:
-        # same steps again with one HIP-event pair around every MFMA convolution launch (on the launching stream)
-        trainer._graph_enabled = False          # event pairs need host-side launches
-        engine.PROFILER = engine.KernelProfiler()
-        run(min(opt.steps, 5), 0)
-        summ = engine.PROFILER.summary()
-        engine.PROFILER = None
-        # dominant kernel = the MFMA convolution kernel with the most time in the step.  Kinds are the library's kernels:
-        # conv_wino_f32 / conv_wino_ring_f32 / conv_wino_res_f32 (Winograd forward + data gradient: streamed, ring, resident filter), conv_wgrad_wino_f32
-        # (Winograd weight gradient), conv_igemm_f32 / conv_wgrad_f32 (direct forms, where the Winograd ones do not apply)
-        nst = max(1, min(opt.steps, 5))
-        kinds = ("conv_wino_f32", "conv_wino_ring_f32", "conv_wino_res_f32", "conv_wgrad_wino_f32", "conv_igemm_f32", "conv_wgrad_f32")
-        kname = max(kinds, key=lambda n: summ.get(n, {"ms": 0.0})["ms"])
-        k = summ.get(kname, {"launches": 0, "flops": 0.0, "ms": 1e-9})
-        ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["launches"] else 0.0
-        wino = "wino" in kname
-        roofline = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2),
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                    "traffic": None, "launches_per_step": k["launches"] // nst,
-                    "avg_launch_us": round(1e3 * k["ms"] / max(1, k["launches"]), 2),
-                    "algorithmic_gflop_per_launch": round(k["flops"] / max(1, k["launches"]) / 1e9, 3),
-                    "kernel_ms_per_step": round(k["ms"] / nst, 3),
-                    "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
-                    "flop_basis": ("algorithmic (direct 3x3 convolution: 2*N*H*W*Cout*9*Cin per launch); the kernel is Winograd F(2x2,3x3) "
-                                   "and executes 1/2.25 of these on the matrix cores, so the fraction of the MFMA peak can exceed 1; "
-                                   "executed_frac = frac / 2.25" if wino else "algorithmic = executed"),
-                    "measured": "HIP events around every launch, %d instrumented steps after the timed region" % nst}
-        if wino:
-            roofline["executed_frac"] = round(ach / 2.25 / PEAK_F32_MFMA_TFLOPS, 4)
-        roofline["other_kernels"] = [
-            {"kernel": n, "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(v["ms"] / nst, 3),
-             "launches_per_step": v["launches"] // nst}
-            for n, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]) if n != kname and n in kinds and v["launches"]]
-        # HBM-side bytes per launch of the same kernel: PMC counters cannot be read from inside this process; they come from the
-        # committed rocprofv3 --pmc passes of this very command (scripts/pmc_traffic.py -> profiles/), N=1 and B=12 only
-        tpath = os.path.join(ROOT, "profiles", "r02_%s_hbm_traffic.json" % opt.config)
-        if opt.gpus == 1 and B == 12 and opt.config in ("c2", "c3") and os.path.exists(tpath):
-            tk = json.load(open(tpath))["kernels"]
-            ig = [v for name, v in tk.items() if (kname + "<") in name or (kname + "(") in name]
-            nl = sum(v["launches_per_step"] for v in ig)
-            if nl > 0:
-                roofline["traffic"] = round(sum(v["MB_per_step"] for v in ig) / nl * 1e6)
-                roofline["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_%s_hbm_traffic.json)" % opt.config
-
-    if dp.rank != 0:
-        dp.shutdown()
-        return
-    line = make_line(opt, B, H, elapsed, launch, loss, roofline, engine)
-    if opt.gpus == 1 and not opt.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(B, H)
-    sys.stdout.flush()
-    if opt.gpus == 1 and opt.config == "c2" and B == 12 and not opt.no_secondary:
+    dp = DataParallelContext(device=device)        # N > 1: an RCCL init failure raises with the RCCL error string (non-zero exit, no fallback)
+    try:
+        B, H = config_shape(opt.config, opt.triplets)
+        use_graph = not opt.no_graph and (not dp.active or opt.dp_graph == "on")
+        trainer, pool = make_trainer(opt.config, device, B, H, graph=use_graph, dp=dp)
+        elapsed = timed_steps(trainer, pool, opt.steps, opt.warmup, dp)
+        launch = "host launches"
+        if use_graph:
+            launch = ("captured HIP graph replay" if not dp.active else
+                      "one HIP graph per step, RCCL collectives (library-owned communicator) as graph nodes" if dp.graph_mode == "whole" else
+                      "HIP graph segments between eager host-staged (gloo) collectives")
+            if not getattr(trainer, "_graphs", None):
+                raise SystemExit("bench: the step graph was requested but never captured")
+        loss = trainer.losses["loss_ae"][-1]
+        roofline = None
+        if not opt.no_roofline and not dp.active:
+            del trainer, pool
+            trainer = pool = None
+            torch.cuda.empty_cache()
+            roofline = roofline_of(engine, device, max(1, min(opt.steps, 5)), opt.config, B, H, opt.gpus)
+        if dp.rank != 0:
+            return
+        ms_per_step = 1e3 * elapsed / opt.steps
+        line = {
+            "metric": "training slices/sec (ae_combined, %dx%d, latent=128)" % (H, H), "value": round(3 * B * opt.steps / elapsed, 1),
+            "unit": "slices/s", "n_gpus": opt.gpus, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOAD[opt.config], "global_batch_triplets": B, "slices_per_step": 3 * B,
+                       "parallelism": "dp%d" % opt.gpus, "init": "reference Initializer, seed 892372, random weights", "launch": launch},
+            "final_loss": round(float(loss), 6),
+        }
+        line.update(step_numbers(opt.config, B, H, ms_per_step, engine.FUSE_STEM))
+        if roofline is not None:
+            line["roofline"] = roofline
         del trainer, pool
         torch.cuda.empty_cache()
-        line["secondary"] = secondary_measurements(device)
-    os.write(real_stdout, (json.dumps(line) + "\n").encode())
-    dp.shutdown()
+        if opt.gpus == 1 and not opt.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(opt.config, B, H)
+        if opt.gpus == 1 and opt.config == "c2" and B == 12 and not opt.no_secondary:
+            sec = {}
+            sec["c3"] = secondary_config(engine, "c3", device, with_roofline=not opt.no_roofline, with_cpu=not opt.no_cpu_baseline)
+            sec["c3_scales3"] = secondary_config(engine, "c3", device, scales3=True)
+            sec["c4"] = secondary_config(engine, "c4", device, steps=6, warmup=3)
+            sec["c5"] = secondary_config(engine, "c5", device, steps=6, warmup=3)
+            sec["small_shards"] = small_shards(device)
+            sec["inference"] = inference_bench(device)
+            line["secondary"] = sec
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    finally:
+        dp.shutdown()
 
 
 if __name__ == "__main__":

@@ -207,6 +207,12 @@ int aesr_lerp_bwd(const float* dzmix, const float* a_from, const float* a_to, fl
 /* The decoder input of the step in one pass (kwatsch/cardiac/trainer_ae.py:20-30: dec(z) and dec(z_mix) run as one batch here):
  * zcat[3B][per] = [z | a_from*z[:B] + a_to*z[B:]];  gradient dz[2B][per] = g[:2B] + (a_from, a_to) * g[2B:]. */
 int aesr_lerp_cat_fwd(const float* z, const float* a_from, const float* a_to, float* zcat, int B, size_t per, void* stream);
+/* Slice synthesis, all mixes of a volume in one launch (generate_hr_volumes.py:46-53,88; kwatsch/img_interpolation.py:57-89):
+ * out[k][i] = act(alphas[k] * z[i + 1] + (1 - alphas[k]) * z[i]) for the Z - 1 pairs of neighbouring slices and n <= 16 coefficients
+ * (host array).  z: [Z][per_slice] latents (act = AESR_ACT_NONE), or the pre-activations of the decoder's first convolution with that
+ * layer's activation -- the convolution is linear, so it runs once per slice instead of once per synthesised slice. */
+int aesr_lerp_multi(const float* z, float* out, int Z, size_t per_slice, const float* alphas_host, int n, int act, float slope,
+                    void* stream);
 int aesr_lerp_cat_bwd(const float* g, const float* a_from, const float* a_to, float* dz, int B, size_t per, void* stream);
 
 /* ---- losses (kwatsch/base_trainer.py:177; kwatsch/cardiac/trainer_ae.py:181) ------------------------------ */
@@ -244,9 +250,14 @@ int aesr_row_mean_bwd(const float* g, float* dx, int N, size_t M, void* stream);
 int aesr_act_bwd(const float* dout, const float* y, float* dpre, size_t n, int act, float slope, void* stream);
 
 /* ---- Adam (torch.optim.Adam as used by kwatsch/trainer_ae.py:29-30) on a flat buffer ---------------------- */
-/* state: 4 floats {step, 1-beta1^t, sqrt(1-beta2^t), unused}; the step is advanced on the device. */
-int aesr_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* state, size_t n, float lr,
-                   float beta1, float beta2, float eps, float weight_decay, void* stream);
+/* state: 8 floats {steps done t, 1-beta1^(t+1), sqrt(1-beta2^(t+1)), ticket counter (keep at zero), beta1^(t+1) and beta2^(t+1) as two
+ * doubles}, i.e. the bias corrections of the step about to run; fill it with aesr_adam_state_init (host, no launch) for a fresh optimizer
+ * (t = 0) or a resumed one.  The step and the powers are advanced on the device by the workgroup that finishes last: one launch per
+ * step, graph-replay safe.  The betas are doubles (their powers are, as in torch.optim.Adam's bias corrections; the element-wise
+ * moments use them rounded to fp32).  zero_grad != 0 leaves g at zero (a caller that keeps no gradients between steps saves its memset). */
+void aesr_adam_state_init(float* state_host8, double steps_done, double beta1, double beta2);
+int aesr_adam_step(float* p, float* g, float* exp_avg, float* exp_avg_sq, float* state, size_t n, float lr,
+                   double beta1, double beta2, float eps, float weight_decay, int zero_grad, void* stream);
 
 /* ---- on-device batch assembly + augmentation of the training triplets (train_cardiac_aesr.py:83-96, datasets/
  * shared_transforms.py:48-120,224-254,297-363,366-447, datasets/ACDC/data4d_simple.py:327-355) ------------------------------

@@ -6,7 +6,11 @@ wide (16 B/lane) coalesced reads -> doubled; WRITE_SIZE is exact for 16 B/lane s
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (csrc_sha: the kernel sources these passes were measured on; bench.py quotes the file only while they match)
 
 
 def load(path, counter):
@@ -33,7 +37,7 @@ for k in sorted(set(f) | set(w), key=lambda k: -(f.get(k, [0, 0])[1] * 2 + w.get
               "MB_per_step": round((2 * fb + wb) * 1024 / steps / 1e6, 1)}
 tot = sum(v["MB_per_step"] for v in out.values())
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB units, FETCH_SIZE doubled per the gfx950 correction; "
-               "memory-side requests of the L2 (Infinity-Cache hits are included)", "steps": steps,
+               "memory-side requests of the L2 (Infinity-Cache hits are included)", "steps": steps, "csrc_sha": bench.csrc_sha(),
        "total_MB_per_step": round(tot, 1), "kernels": out}
 json.dump(res, open(sys.argv[4], "w"), indent=1)
 print("total %.1f MB/step" % tot)

@@ -84,6 +84,7 @@ SIGNATURES = {
     "aesr_lerp_fwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
     "aesr_lerp_bwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
     "aesr_lerp_cat_fwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
+    "aesr_lerp_multi": (c_int, [P, P, c_int, c_size_t, FP, c_int, c_int, c_float, P]),
     "aesr_lerp_cat_bwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
     "aesr_mse_fwd": (c_int, [P, P, P, P, c_size_t, P]),
     "aesr_mse_bwd": (c_int, [P, P, P, P, c_size_t, P]),
@@ -100,7 +101,8 @@ SIGNATURES = {
     "aesr_triplet_assemble": (c_int, [P, ctypes.POINTER(TripletDesc), c_int, c_int, P, P, P]),
     "aesr_ssim_workspace_doubles": (c_size_t, [c_int, c_int, c_int]),
     "aesr_ssim_mse": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_double, c_double, c_double, P]),
-    "aesr_adam_step": (c_int, [P, P, P, P, P, c_size_t] + [c_float] * 5 + [P]),
+    "aesr_adam_state_init": (None, [FP, c_double, c_double, c_double]),
+    "aesr_adam_step": (c_int, [P, P, P, P, P, c_size_t, c_float, c_double, c_double, c_float, c_float, c_int, P]),
     "aesr_conv2d_wino_supported": (c_int, [c_int] * 5),
     "aesr_conv2d_wino_kernel": (c_int, [c_int] * 8),
     "aesr_conv2d_wino_ring_timeouts": (ctypes.c_uint, []),
@@ -130,6 +132,7 @@ ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 BN_NONE, BN_POOL, BN_UP = 0, 1, 2
 RS_POOL, RS_NEAREST, RS_BILINEAR = 1, 2, 3
 BN_NWG = 512
+REDUCE_MAX_JOBS = 16          # REDUCE_MAX_JOBS of csrc/aesr_kernels.h: layers per aesr_conv2d_wgrad_reduce_many launch
 MSE_NPART = 512
 MSE3_WS = 3 * 256 + 1            # doubles (AESR_MSE3_WS)
 LPIPS_NCH = 64

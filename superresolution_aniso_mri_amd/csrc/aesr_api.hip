@@ -29,6 +29,7 @@ static void cout_padding(int Cout, int* CoutP, int* NB) {
 
 struct ConvPlan { int TI, TH, TW, NB, MBW, CinP, CoutP, NT, ksplit; };
 static std::mutex g_plan_mu;
+
 static std::map<std::tuple<int, int, int, int, int, int>, ConvPlan> g_conv_plans;
 
 // Pick the workgroup shape (512 threads = one workgroup per CU, or 256 = two per CU) and the output tile (TI images x TH x
@@ -887,6 +888,16 @@ int aesr_lerp_cat_fwd(const float* z, const float* a_from, const float* a_to, fl
     return aesr_launch_lerp_cat_fwd(z, a_from, a_to, zcat, B, per, (hipStream_t)stream);
 }
 
+int aesr_lerp_multi(const float* z, float* out, int Z, size_t per_slice, const float* alphas_host, int n, int act, float slope,
+                    void* stream) {
+    AESR_CHECK_ARG(z && out && alphas_host && Z >= 2 && per_slice > 0 && per_slice % 4 == 0, "aesr_lerp_multi: bad arguments (two slices or more, per_slice %% 4 == 0)");
+    AESR_CHECK_ARG(n >= 1 && n <= 16, "aesr_lerp_multi: %d mixing coefficients per call (1..16)", n);
+    AESR_CHECK_ARG(act == ACT_NONE || act == ACT_RELU || (act == ACT_LRELU && slope >= 0.f && slope <= 1.f),
+                   "aesr_lerp_multi: activation %d (none, ReLU, or LeakyReLU with a slope in [0, 1])", act);
+    const float nslope = act == ACT_LRELU ? slope : (act == ACT_RELU ? 0.f : 1.f);
+    return aesr_launch_lerp_multi(z, out, Z, per_slice, alphas_host, n, nslope, (hipStream_t)stream);
+}
+
 int aesr_lerp_cat_bwd(const float* g, const float* a_from, const float* a_to, float* dz, int B, size_t per, void* stream) {
     AESR_CHECK_ARG(g && a_from && a_to && dz && g != dz && B > 0 && per % 4 == 0, "aesr_lerp_cat_bwd: bad arguments (per %% 4 == 0)");
     return aesr_launch_lerp_cat_bwd(g, a_from, a_to, dz, B, per, (hipStream_t)stream);
@@ -959,10 +970,26 @@ int aesr_act_bwd(const float* dout, const float* y, float* dpre, size_t n, int a
     return aesr_launch_act_bwd(dout, y, dpre, n, act, slope, (hipStream_t)stream);
 }
 
-int aesr_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* state, size_t n, float lr, float beta1,
-                   float beta2, float eps, float weight_decay, void* stream) {
+void aesr_adam_state_init(float* state_host8, double steps_done, double beta1, double beta2) {
+    // the same chain of double multiplications the kernel runs step after step (NOT pow): an optimizer resumed from a checkpoint
+    // continues bit for bit like the one that was never stopped
+    double b1p = beta1, b2p = beta2;
+    for (long k = 0; k < (long)steps_done; ++k) {
+        b1p *= beta1;
+        b2p *= beta2;
+    }
+    state_host8[0] = (float)steps_done;
+    state_host8[1] = (float)(1.0 - b1p);
+    state_host8[2] = (float)sqrt(1.0 - b2p);
+    state_host8[3] = 0.f;
+    memcpy(state_host8 + 4, &b1p, sizeof(double));
+    memcpy(state_host8 + 6, &b2p, sizeof(double));
+}
+
+int aesr_adam_step(float* p, float* g, float* exp_avg, float* exp_avg_sq, float* state, size_t n, float lr, double beta1,
+                   double beta2, float eps, float weight_decay, int zero_grad, void* stream) {
     AESR_CHECK_ARG(p && g && exp_avg && exp_avg_sq && state && n > 0, "aesr_adam_step: bad arguments");
-    return aesr_launch_adam(p, g, exp_avg, exp_avg_sq, state, n, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream);
+    return aesr_launch_adam(p, g, exp_avg, exp_avg_sq, state, n, lr, beta1, beta2, eps, weight_decay, zero_grad, (hipStream_t)stream);
 }
 
 int aesr_triplet_assemble(const float* volumes, const aesr_triplet_desc* desc_host, int B, int width, float* image,

@@ -167,6 +167,7 @@ int aesr_launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t st);
 int aesr_launch_lerp_fwd(const float* z, const float* af, const float* at, float* zmix, int B, size_t per, hipStream_t st);
 int aesr_launch_lerp_bwd(const float* dmix, const float* af, const float* at, float* dz, int B, size_t per, hipStream_t st);
 int aesr_launch_lerp_cat_fwd(const float* z, const float* af, const float* at, float* zcat, int B, size_t per, hipStream_t st);
+int aesr_launch_lerp_multi(const float* z, float* out, int Z, size_t per, const float* alphas, int n, float nslope, hipStream_t st);
 int aesr_launch_lerp_cat_bwd(const float* g, const float* af, const float* at, float* dz, int B, size_t per, hipStream_t st);
 int aesr_launch_mse_fwd(const float* a, const float* b, double* partial, int np, float* out, size_t n, hipStream_t st);
 int aesr_launch_mse3_fwd(const float* const* a, const float* const* b, const size_t* n, const float* lam, double* ws, float* out, hipStream_t st);
@@ -174,8 +175,8 @@ int aesr_launch_mse3_bwd(const float* a1, const float* b1, size_t n1, const floa
                          const float* g, float* d1, float* d2, hipStream_t st);
 int aesr_launch_mse_bwd(const float* a, const float* b, const float* g, float* da, size_t n, hipStream_t st);
 int aesr_launch_act_bwd(const float* dout, const float* y, float* dpre, size_t n, int act, float slope, hipStream_t st);
-int aesr_launch_adam(float* p, const float* g, float* m, float* v, float* state, size_t n, float lr, float beta1, float beta2,
-                     float eps, float wd, hipStream_t st);
+int aesr_launch_adam(float* p, float* g, float* m, float* v, float* state, size_t n, float lr, double beta1, double beta2,
+                     float eps, float wd, int zero_g, hipStream_t st);
 
 
 int aesr_launch_maxpool2_fwd(const float* x, float* out, int N, int H, int W, int C, hipStream_t st);

@@ -46,6 +46,27 @@ __global__ __launch_bounds__(256) void lerp_cat_fwd_kernel(const float* __restri
     }
 }
 
+// slice synthesis (generate_hr_volumes.py:46-53,88): for every alpha a_k and every pair of neighbouring slices (i, i + 1)
+//   out[k][i] = act(a_k * z[i + 1] + (1 - a_k) * z[i])
+// in ONE launch; z = latents (act none), or the PRE-ACTIVATIONS of the decoder's first convolution: that layer is linear, so its
+// output for a latent mix is the same mix of its outputs for the two slices (bias included: the weights add up to 1) -- the layer
+// runs once per slice instead of once per synthesised slice, and its LeakyReLU is applied here.
+struct LerpMultiArgs { float a[16]; int n; };
+__global__ __launch_bounds__(256) void lerp_multi_kernel(const float* __restrict__ z, float* __restrict__ out, int Zm1, size_t per4,
+                                                         LerpMultiArgs al, float nslope) {
+    const size_t total = (size_t)Zm1 * per4;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const f32x4 lo = ((const f32x4*)z)[idx], hi = ((const f32x4*)z)[idx + per4];
+        for (int k = 0; k < al.n; ++k) {
+            f32x4 v = hi * al.a[k] + lo * (1.f - al.a[k]);
+            const f32x4 vs = v * nslope;                      // none / LeakyReLU / ReLU as max(x, slope * x), 0 <= slope <= 1
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], vs[e]);
+            ((f32x4*)out)[(size_t)k * total + idx] = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void lerp_cat_bwd_kernel(const float* __restrict__ g, const float* __restrict__ af,
                                                            const float* __restrict__ at, float* __restrict__ dz, int B, size_t per4) {
     const size_t total = (size_t)B * per4;
@@ -127,14 +148,16 @@ __global__ __launch_bounds__(256) void mse3_fwd_kernel(Mse3Args p) {
     __syncthreads();
     unsigned* counter = (unsigned*)(p.ws + 3 * gridDim.x);
     if (threadIdx.x == 0) {
+        // write-through stores, drained, then the ticket: no agent release (an L2 write-back) per workgroup; only the last one acquires
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p.ws[3 * blockIdx.x + k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
-        __threadfence();
-        ticket = atomicAdd(counter, 1u);
+        for (int k = 0; k < 3; ++k)
+            __hip_atomic_store(p.ws + 3 * blockIdx.x + k, (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (ticket != gridDim.x - 1) return;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     double t[3] = {0.0, 0.0, 0.0};
     for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)
 #pragma unroll
@@ -184,25 +207,20 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 }
 
 // ---- adam ----------------------------------------------------------------------------------------------------
-// state[0] = step (float, exact below 2^24), state[1] = 1-beta1^t, state[2] = sqrt(1-beta2^t)
-__global__ void adam_prep_kernel(float* __restrict__ state, float beta1, float beta2) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const float t = state[0] + 1.f;
-        state[0] = t;
-        state[1] = (float)(1.0 - pow((double)beta1, (double)t));
-        state[2] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
-    }
-}
-
-__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                        float* __restrict__ m, float* __restrict__ v,
-                                                        const float* __restrict__ state, size_t n, float lr, float beta1,
-                                                        float beta2, float eps, float wd) {
+// state: 8 floats = {step t done so far, 1-beta1^(t+1), sqrt(1-beta2^(t+1)), ticket counter (bits), beta1^(t+1) and beta2^(t+1) as two
+// doubles}: the bias corrections of the step ABOUT to run are in the buffer (aesr_adam_state_init for a given t), every workgroup just
+// reads them, and the workgroup that finishes last advances the step and the running powers (doubles: 1e-11 after 10^5 steps) for the
+// next launch -- one launch, no pow() on any workgroup's critical path.  zero_g: the gradient buffer is left at zero.
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, float* __restrict__ state, size_t n, float lr,
+                                                        double beta1d, double beta2d, float eps, float wd, int zero_g) {
+    const float beta1 = (float)beta1d, beta2 = (float)beta2d;        // element-wise arithmetic in fp32 as torch's; the powers in double
     const float bc1 = state[1], bc2s = state[2];
     const float step_size = lr / bc1;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float gi = g[i];
         const float pi = p[i];
+        if (zero_g) g[i] = 0.f;
         if (wd != 0.f) gi = fmaf(wd, pi, gi);
         const float mi = m[i] + (gi - m[i]) * (1.f - beta1);          // torch: exp_avg.lerp_(grad, 1-beta1)
         const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;      // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
@@ -210,6 +228,21 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
         v[i] = vi;
         const float denom = sqrtf(vi) / bc2s + eps;
         p[i] = pi - step_size * (mi / denom);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // no data is handed over (the last workgroup only WRITES the state), so no fence: each workgroup read the state before its ticket
+        unsigned* counter = (unsigned*)(state + 3);
+        if (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            double* pw = (double*)(state + 4);
+            const double b1p = pw[0] * beta1d, b2p = pw[1] * beta2d;
+            pw[0] = b1p;
+            pw[1] = b2p;
+            state[0] += 1.f;
+            state[1] = (float)(1.0 - b1p);
+            state[2] = (float)sqrt(1.0 - b2p);
+            *counter = 0u;
+        }
     }
 }
 
@@ -275,6 +308,15 @@ int aesr_launch_lerp_cat_fwd(const float* z, const float* af, const float* at, f
     return AESR_OK;
 }
 
+int aesr_launch_lerp_multi(const float* z, float* out, int Z, size_t per, const float* alphas, int n, float nslope, hipStream_t st) {
+    LerpMultiArgs al;
+    al.n = n;
+    for (int k = 0; k < 16; ++k) al.a[k] = k < n ? alphas[k] : 0.f;
+    hipLaunchKernelGGL(lerp_multi_kernel, dim3(grid_for((size_t)(Z - 1) * per / 4, 4096)), dim3(256), 0, st, z, out, Z - 1, per / 4, al, nslope);
+    AESR_LAUNCH_CHECK("lerp_multi");
+    return AESR_OK;
+}
+
 int aesr_launch_lerp_cat_bwd(const float* g, const float* af, const float* at, float* dz, int B, size_t per, hipStream_t st) {
     hipLaunchKernelGGL(lerp_cat_bwd_kernel, dim3(grid_for((size_t)B * per / 4, 4096)), dim3(256), 0, st, g, af, at, dz, B, per / 4);
     AESR_LAUNCH_CHECK("lerp_cat_bwd");
@@ -319,11 +361,10 @@ int aesr_launch_act_bwd(const float* dout, const float* y, float* dpre, size_t n
     return AESR_OK;
 }
 
-int aesr_launch_adam(float* p, const float* g, float* m, float* v, float* state, size_t n, float lr, float beta1,
-                     float beta2, float eps, float wd, hipStream_t st) {
-    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, st, state, beta1, beta2);
-    AESR_LAUNCH_CHECK("adam_prep");
-    hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, st, p, g, m, v, state, n, lr, beta1, beta2, eps, wd);
+int aesr_launch_adam(float* p, float* g, float* m, float* v, float* state, size_t n, float lr, double beta1,
+                     double beta2, float eps, float wd, int zero_g, hipStream_t st) {
+    // <= 128 workgroups: the tickets of the step counter are atomics on ONE word (~12 ns each, serialized): 1 700 of them took 20 us
+    hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for(n, 128)), dim3(256), 0, st, p, g, m, v, state, n, lr, beta1, beta2, eps, wd, zero_g);
     AESR_LAUNCH_CHECK("adam_step");
     return AESR_OK;
 }

@@ -344,16 +344,25 @@ class SequentialRunner:
               "aesr_stemconv_fold")
         s.folded_epoch = epoch
 
-    def forward(self, x, nstart, train, save, fused=True):
+    def forward(self, x, nstart, train, save, fused=True, first=0, last=None, raw_last=False):
         """x: NHWC fp32 [N,H,W,C]; nstart: group boundaries (len G+1).  Returns (out, saved, steps): ``steps`` is the
-        compiled list that ran (the stem-folded one unless ``fused`` is False, e.g. when the input needs a gradient)."""
+        compiled list that ran (the stem-folded one unless ``fused`` is False, e.g. when the input needs a gradient).
+        ``first`` / ``last``: run only steps [first, last) of the UNFUSED list (inference: the decoder's first convolution apart from
+        the rest); ``raw_last``: the last step that runs is a convolution and leaves out its activation (pre-activations)."""
         _hip.require_gpu_tensor(x, "input")
         N, H, W, C = x.shape
         G = len(nstart) - 1
         saved = []
         cur = x
-        steps = self.steps_fused if (fused and self.steps_fused is not None) else self.steps
+        partial = first != 0 or last is not None
+        steps = self.steps_fused if (fused and self.steps_fused is not None and not partial) else self.steps
         self._ensure_packed(steps)
+        if partial:
+            if save:
+                raise RuntimeError("a partial pass keeps nothing for a backward pass")
+            steps = steps[first:last]
+            if raw_last and (not steps or steps[-1].kind != "conv"):
+                raise RuntimeError("raw_last needs a convolution as the last step of the range")
         for s in steps:
             if s.kind == "stemconv":
                 if C != 1:
@@ -367,6 +376,7 @@ class SequentialRunner:
                     saved.append((cur, out))
                 cur, H, W, C = out, Ho, Wo, s.cout
             elif s.kind == "conv":
+                act_k = _hip.ACT_NONE if (raw_last and s is steps[-1]) else s.act
                 if s.s2d:
                     if C != s.cin_full:
                         raise RuntimeError("channel mismatch: tensor has %d channels, conv expects %d" % (C, s.cin_full))
@@ -383,15 +393,15 @@ class SequentialRunner:
                 bias = s.mod.bias
                 if s.in_up2:
                     _pb(("wino", N, Ho, Wo, s.cin, s.cout, 0), 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
-                    check(lib.aesr_conv2d_wino_fwd_up2(ptr(cur), ptr(s.packed_w), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, s.act,
+                    check(lib.aesr_conv2d_wino_fwd_up2(ptr(cur), ptr(s.packed_w), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, act_k,
                                                        s.slope, stream()), "aesr_conv2d_wino_fwd_up2")
                     _pe()
                 elif s.cout == 1 and s.ks == 3 and s.pad == 1 and s.cin % 4 == 0:
-                    check(lib.aesr_conv2d_cout1_fwd(ptr(cur), ptr(s.mod.weight), ptr(bias), ptr(out), N, H, W, s.cin, s.act,
+                    check(lib.aesr_conv2d_cout1_fwd(ptr(cur), ptr(s.mod.weight), ptr(bias), ptr(out), N, H, W, s.cin, act_k,
                                                     s.slope, stream()), "aesr_conv2d_cout1_fwd")
                 elif s.wino_fwd:
                     _pb(("wino", N, Ho, Wo, s.cin, s.cout, 0), 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
-                    check(lib.aesr_conv2d_wino_fwd(ptr(cur), ptr(s.packed_w), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, s.act,
+                    check(lib.aesr_conv2d_wino_fwd(ptr(cur), ptr(s.packed_w), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, act_k,
                                                    s.slope, stream()), "aesr_conv2d_wino_fwd")
                     _pe()
                 elif s.mfma_fwd:
@@ -399,11 +409,11 @@ class SequentialRunner:
                     nws = lib.aesr_conv2d_workspace_floats(N, H, W, s.cin, s.cout, s.ks, s.pad)    # > 0: few, deep work items
                     ws = _empty((nws,), x) if nws else None
                     check(lib.aesr_conv2d_fwd_ws(ptr(cur), ptr(s.packed), ptr(bias), ptr(out), ptr(ws), N, H, W, s.cin, s.cout,
-                                                 s.ks, s.pad, s.act, s.slope, stream()), "aesr_conv2d_fwd_ws")
+                                                 s.ks, s.pad, act_k, s.slope, stream()), "aesr_conv2d_fwd_ws")
                     _pe()
                 elif s.cin <= 4:
                     check(lib.aesr_conv2d_smallcin_fwd(ptr(cur), ptr(s.mod.weight), ptr(bias), None, ptr(out), N, H, W,
-                                                       s.cin, s.cout, s.ks, s.pad, s.act, _hip.ACT_NONE, s.slope, 0, 0,
+                                                       s.cin, s.cout, s.ks, s.pad, act_k, _hip.ACT_NONE, s.slope, 0, 0,
                                                        None, None, stream()), "aesr_conv2d_smallcin_fwd")
                 else:
                     raise NotImplementedError("conv with Cin=%d (neither <=4 nor a multiple of 4)" % s.cin)
@@ -493,9 +503,10 @@ class SequentialRunner:
             g = g.contiguous()
         reduce_jobs = []          # (job, workspace, dw, db): the tensors stay referenced until the reduction has been enqueued
         g = self._backward_steps(steps, saved, g, ngrad, need_input_grad, grads, G, ns, reduce_jobs)
-        if reduce_jobs:
-            arr = (_hip.WgradReduceJob * len(reduce_jobs))(*[j[0] for j in reduce_jobs])
-            check(lib.aesr_conv2d_wgrad_reduce_many(arr, len(reduce_jobs), stream()), "aesr_conv2d_wgrad_reduce_many")
+        if _DEFERRED is not None:
+            _DEFERRED.extend(reduce_jobs)       # summed with the other passes' slabs by ONE launch (deferred_wgrad_reductions)
+        else:
+            flush_wgrad_reductions(reduce_jobs)
         return g, grads
 
     def _backward_steps(self, steps, saved, g, ngrad, need_input_grad, grads, G, ns, reduce_jobs):
@@ -643,6 +654,40 @@ class SequentialRunner:
         return g
 
 
+_DEFERRED = None      # list of pending weight-gradient reduction jobs while a deferred_wgrad_reductions() block is open
+
+
+def flush_wgrad_reductions(jobs):
+    """ONE aesr_conv2d_wgrad_reduce_many launch per 16 layers for the slab sets in ``jobs``."""
+    for k in range(0, len(jobs), _hip.REDUCE_MAX_JOBS):
+        part = jobs[k:k + _hip.REDUCE_MAX_JOBS]
+        arr = (_hip.WgradReduceJob * len(part))(*[j[0] for j in part])
+        check(lib.aesr_conv2d_wgrad_reduce_many(arr, len(part), stream()), "aesr_conv2d_wgrad_reduce_many")
+
+
+class deferred_wgrad_reductions(object):
+    """``with deferred_wgrad_reductions(): loss.backward()``: the weight-gradient slab sets of EVERY pass of the backward sweep
+    (decoder, then encoder) are summed by one launch when the block closes instead of one launch per pass.  Parameter gradients
+    are complete only after the block."""
+
+    def __enter__(self):
+        global _DEFERRED
+        self.outer = _DEFERRED
+        if os.environ.get("AESR_DEFER_REDUCE", "1") != "0":
+            _DEFERRED = []
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFERRED
+        jobs, _DEFERRED = (_DEFERRED or []), self.outer
+        if exc[0] is None:
+            if self.outer is not None:
+                self.outer.extend(jobs)
+            else:
+                flush_wgrad_reductions(jobs)
+        return False
+
+
 class _PassFn(torch.autograd.Function):
     """One pass of a compiled stack as a single autograd node: NHWC batch in, one logical-NCHW view of the NHWC output
     buffer per sub-batch out (so the caller never runs an autograd split / cat / layout copy on the activations)."""
@@ -650,6 +695,7 @@ class _PassFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, nstart, ngrad, train, splits, x, *params):
         need = any(ctx.needs_input_grad) and ngrad > 0       # grad mode is off inside forward(); this is the truth
+        ctx.set_materialize_grads(False)     # sub-batches without a gradient (the logging-only encoder pass) come back as None, not as zeros
         out, saved, steps = runner.forward(x.detach(), nstart, train, save=need, fused=not x.requires_grad)
         ctx.runner, ctx.nstart, ctx.ngrad, ctx.saved, ctx.steps = runner, nstart, ngrad, saved, steps
         ctx.x_needs_grad = x.requires_grad

@@ -3,8 +3,10 @@
 
 The reference re-encodes both neighbour stacks for EVERY alpha (2n encoder passes per slice pair) and
 copies every decoded stack to the host.  Here each slice is encoded ONCE (eval-mode BatchNorm makes results independent
-of batch composition), the latents stay resident in HBM, all (z-1)*n mixes are produced by the lerp kernel and decoded
-as ONE batch, the interleave and clamp happen on the device and there is a single device-to-host copy at the end.
+of batch composition), the latents stay resident in HBM, the decoder's first convolution runs once per SLICE (it is linear: its
+output for a latent mix is the mix of its outputs), all (z-1)*n mixes are formed on its pre-activations by ONE launch and the rest
+of the decoder runs on them as ONE batch, the interleave and clamp happen on the device and there is a single device-to-host copy
+at the end.
 Conventions kept: ``alpha*enc(later slice) + (1-alpha)*enc(earlier slice)``, alphas = linspace(0,1,n+2)[1:-1],
 output order [orig_0, interp_0(a_1..a_n), orig_1, ...], clamp to [0,1], new z-spacing = old/(n+1)."""
 import argparse
@@ -31,8 +33,9 @@ def latent_space_interp(alpha, trainer, img1, img2, device=None, with_labels=Fal
     return {"inter_image": inter.detach().cpu().contiguous(), "inter_label": None}
 
 
-def create_super_volume(trainer, images, alpha_range, use_original=False, labels=None):
-    """images [z,1,y,x] or [z,y,x] -> {'upsampled_image': [(z-1)(n+1)+1, y, x] (CPU, clamped), 'upsampled_labels': None}."""
+def create_super_volume(trainer, images, alpha_range, use_original=False, labels=None, to_cpu=True):
+    """images [z,1,y,x] or [z,y,x] -> {'upsampled_image': [(z-1)(n+1)+1, y, x] (CPU, clamped), 'upsampled_labels': None}.
+    ``to_cpu=False`` leaves the result in HBM (callers that go on working on the device; bench.py times it that way)."""
     if labels is not None:
         raise NotImplementedError("label channels (ACDCLBL multi-channel models) are outside this build")
     if images.dim() == 3:
@@ -47,14 +50,18 @@ def create_super_volume(trainer, images, alpha_range, use_original=False, labels
         out = torch.empty(((Z - 1) * (n + 1) + 1, H, W), device=vol.device, dtype=torch.float32)
         out[::n + 1] = recon[:, 0]
         if Z > 1 and n > 0:
-            zpair = torch.cat([lat[1:], lat[:-1]], dim=0)             # rows i / i+(Z-1): later slice / earlier slice
-            mixes = torch.cat([ops.lerp_mix(zpair, float(a), float(1 - a)) for a in alpha_range], dim=0)
-            dec = trainer.decode(mixes, use_sr_model=True)            # ONE decoder pass over all (Z-1)*n latents
+            model = trainer._use_sr_model(True)
+            model.eval()
+            dec = model.decode_mixes(lat, [float(a) for a in alpha_range]) if hasattr(model, "decode_mixes") else None
+            if dec is None:
+                zpair = torch.cat([lat[1:], lat[:-1]], dim=0)         # rows i / i+(Z-1): later slice / earlier slice
+                mixes = torch.cat([ops.lerp_mix(zpair, float(a), float(1 - a)) for a in alpha_range], dim=0)
+                dec = trainer.decode(mixes, use_sr_model=True)        # ONE decoder pass over all (Z-1)*n latents
             dec = dec.reshape(n, Z - 1, H, W)
             for k in range(n):
                 out[k + 1::n + 1] = dec[k]
         out.clamp_(0, 1.)
-    return {"upsampled_image": out.cpu(), "upsampled_labels": None}
+    return {"upsampled_image": out.cpu() if to_cpu else out, "upsampled_labels": None}
 
 
 # ---- I/O around the path (SimpleITK is optional; .npy volumes work everywhere) -----------------------------------------

@@ -5,7 +5,7 @@ from collections import defaultdict
 
 import torch
 
-from .. import ops
+from .. import engine, ops
 from .base_trainer import BaseTrainer, LossLog
 
 
@@ -60,11 +60,17 @@ class AEBaseTrainer(BaseTrainer):
     def _backward_and_step(self, loss, eval_mode):
         self.opt_ae.zero_grad()
         if not eval_mode:
+            one = self.__dict__.get("_one")
+            if one is None or one.device != loss.device:
+                one = self._one = torch.ones((), dtype=torch.float32, device=loss.device)      # seed of backward(): no ones_like fill per step
+            # the weight-gradient slabs of the decoder and the encoder pass are summed by ONE launch at the end of the sweep
+            with engine.deferred_wgrad_reductions():
+                if self.dp is not None and self.dp.active:
+                    (loss * self.dp.weight).backward(gradient=one)      # SUM over ranks of w_r * grad(loss_r) == grad of the global mean
+                else:
+                    loss.backward(gradient=one)
             if self.dp is not None and self.dp.active:
-                (loss * self.dp.weight).backward()      # SUM over ranks of w_r * grad(loss_r) == grad of the global mean
                 self.dp.allreduce_gradients(self.opt_ae)
-            else:
-                loss.backward()
             self.opt_ae.step()
         if self.opt_sched_ae is not None:
             self.opt_sched_ae.step()
@@ -110,6 +116,12 @@ class AEBaseTrainer(BaseTrainer):
         g = self._graphs.get(sig)
         if g is None:
             static = {k: dev_batch[k].clone() for k in keys}
+            if "image" in static and "slice_between" in static and static["image"].shape[1:] == static["slice_between"].shape[1:]:
+                # the two image sub-batches back to back in ONE buffer: the encoder pass reads [image | slice_between] as it lies (no
+                # concatenation node, networks/acai_vanilla._joined_view)
+                n1 = static["image"].shape[0]
+                both = torch.cat([static["image"], static["slice_between"]], dim=0).contiguous()
+                static["image"], static["slice_between"] = both[:n1], both[n1:]
             sink = {}
             dp_active = self.dp is not None and self.dp.active
             if dp_active and self._graph_dp == "segments":

@@ -80,6 +80,21 @@ def Decoder(scales, depth, latent, colors, n_res_block=None, use_upsample=True, 
     return nn.Sequential(*layers)
 
 
+def _joined_view(xs):
+    """The sub-batches as ONE [sum N, H, W, C] tensor WITHOUT a copy when they already lie back to back in one allocation (the
+    static input buffer of the captured step, kwatsch/trainer_ae.py), else None."""
+    first = xs[0]
+    if any(t.shape[1:] != first.shape[1:] or t.dtype != first.dtype or not t.is_contiguous() for t in xs):
+        return None
+    end = first.data_ptr() + first.numel() * first.element_size()
+    for t in xs[1:]:
+        if t.data_ptr() != end or t.untyped_storage().data_ptr() != first.untyped_storage().data_ptr():
+            return None
+        end += t.numel() * t.element_size()
+    n = sum(t.shape[0] for t in xs)
+    return first.new_empty(0).set_(first.untyped_storage(), first.storage_offset(), (n,) + tuple(first.shape[1:]))
+
+
 def num_scales(args):
     return int(round(math.log(args["width"] // args["latent_width"], 2)))
 
@@ -119,7 +134,9 @@ class HipAE(nn.Module):
         if any(g and not p for p, g in zip(needs_grad[:-1], needs_grad[1:])):
             raise ValueError("sub-batches that need gradients must come first")
         xs = [engine.to_nhwc(t) for t in tensors]
-        x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=0)
+        x = xs[0] if len(xs) == 1 else (_joined_view(xs) if not any(t.requires_grad for t in xs) else None)
+        if x is None:
+            x = torch.cat(xs, dim=0)
         return self._pass_batched(name, x, [t.shape[0] for t in xs], needs_grad)
 
     def _pass_batched(self, name, x_nhwc, splits, needs_grad, merge=False):
@@ -146,6 +163,36 @@ class HipAE(nn.Module):
 
     def decode_multi(self, latents, needs_grad=None):
         return self._pass("dec", latents, needs_grad)
+
+    def decode_mixes(self, z, alphas):
+        """Eval-mode slice synthesis for a whole volume: z [Z, C, h, w] latents of consecutive slices -> decoded mixes
+        [n * (Z - 1), colors, H, W], row k * (Z - 1) + i = dec(alphas[k] * z[i + 1] + (1 - alphas[k]) * z[i]).  The decoder's
+        first convolution is linear, so it runs ONCE PER SLICE on z; the mixes are formed on its pre-activations (one launch for all
+        of them, its LeakyReLU applied there) and only the rest of the decoder runs per synthesised slice.  Returns None when the
+        decoder does not start with conv + LeakyReLU/ReLU/nothing (caller falls back to lerp on the latents + a full decode)."""
+        from .. import _hip, ops
+        if self.training:
+            raise RuntimeError("decode_mixes is an inference path (model.eval())")
+        r = self._runner("dec")
+        s0 = r.steps[0]
+        if s0.kind != "conv" or s0.s2d or s0.act not in (_hip.ACT_NONE, _hip.ACT_LRELU, _hip.ACT_RELU) or len(r.steps) < 2 or \
+                (s0.act == _hip.ACT_LRELU and not 0.0 <= s0.slope <= 1.0):
+            return None
+        zn = engine.to_nhwc(z)
+        N = zn.shape[0]
+        with torch.no_grad():
+            pre, _, _ = r.forward(zn, (0, N), False, save=False, first=0, last=1, raw_last=True)
+            mixed = ops.lerp_multi(pre, alphas, s0.act, s0.slope)
+            # big volumes in pieces: no activation tensor of a pass may exceed the kernels' 32-bit offset range (as BaseTrainer._run_eval)
+            up = 1
+            for st in r.steps[1:]:
+                if st.kind == "bn" and st.mode == _hip.BN_UP or (st.kind == "resample" and st.mode != _hip.RS_POOL):
+                    up *= 2
+            n_max = max(1, (1 << 28) // (mixed.shape[1] * up * mixed.shape[2] * up * 64))
+            outs = [r.forward(mixed[i:i + n_max], (0, min(n_max, mixed.shape[0] - i)), False, save=False, first=1)[0]
+                    for i in range(0, mixed.shape[0], n_max)]
+            out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+        return engine.to_nchw_view(out)
 
     def encode(self, img):
         return self._pass("enc", [img])[0]

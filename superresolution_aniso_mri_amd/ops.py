@@ -2,6 +2,10 @@
 
 Follows kwatsch/cardiac/trainer_ae.py:173 / kwatsch/brain/trainer_ae.py:264-266 (lerp), kwatsch/base_trainer.py:177
 (``F.mse_loss`` mean) and kwatsch/trainer_ae.py:29-30 (``optim.Adam``).  No CPU fallback."""
+import os
+from ctypes import c_float
+
+import numpy as np
 import torch
 
 from . import _hip, engine
@@ -65,10 +69,11 @@ def _const_vec(n, value, device):
     """[n] fp32 tensor filled with ``value``, cached per (device, n, value): the scalar mixing coefficients (0.5 / 0.5) are the same
     every step, so no fill kernel runs per call.  While a stream is capturing, a fresh tensor is made instead (a tensor born in a
     graph's private pool must not outlive the graph through this cache)."""
-    if torch.cuda.is_current_stream_capturing():
-        return torch.full((n,), float(value), dtype=torch.float32, device=device)
     key = (str(device), int(n), float(value))
     t = _CONST_VECS.get(key)
+    if torch.cuda.is_current_stream_capturing():
+        # a vector cached by an earlier (eager) step lives outside the graph's pool: safe to bake into the graph, and no fill node
+        return t if t is not None else torch.full((n,), float(value), dtype=torch.float32, device=device)
     if t is None:
         if len(_CONST_VECS) > 64:
             _CONST_VECS.clear()
@@ -103,6 +108,20 @@ def lerp_mix(z, alpha_from, alpha_to):
     zn, af, at = _lerp_args(z, alpha_from, alpha_to)
     out = _LerpFn.apply(zn, af, at)
     return engine.to_nchw_view(out) if z.dim() == 4 else out
+
+
+def lerp_multi(z_nhwc, alphas, act=_hip.ACT_NONE, slope=0.0):
+    """All mixes of neighbouring slices in ONE launch: z_nhwc [Z, ...] -> [n * (Z - 1), ...], row k * (Z - 1) + i =
+    act(alphas[k] * z[i + 1] + (1 - alphas[k]) * z[i]) (no gradient: inference)."""
+    _hip.require_gpu_tensor(z_nhwc, "z")
+    Z, n = z_nhwc.shape[0], len(alphas)
+    per = z_nhwc[0].numel()
+    out = torch.empty((n * (Z - 1),) + tuple(z_nhwc.shape[1:]), device=z_nhwc.device, dtype=torch.float32)
+    for k0 in range(0, n, 16):
+        part = [float(a) for a in alphas[k0:k0 + 16]]
+        check(lib.aesr_lerp_multi(ptr(z_nhwc), ptr(out[k0 * (Z - 1):]), Z, per, _hip.float_array(part), len(part), int(act), float(slope),
+                                  stream()), "aesr_lerp_multi")
+    return out
 
 
 def lerp_cat(z, alpha_from, alpha_to):
@@ -148,9 +167,10 @@ _MSE3_WS = {}
 
 
 def _mse3_workspace(device):
-    """Partial sums + ticket counter of aesr_mse3_fwd: zeroed ONCE (the kernel leaves it consistent), one per device, allocated
-    outside any graph capture (the first, eager steps)."""
-    key = str(device)
+    """Partial sums + ticket counter of aesr_mse3_fwd: zeroed ONCE (the kernel leaves it consistent), one per (device, stream) --
+    two steps in flight on different streams must not share partial sums and tickets -- allocated outside any graph capture (the
+    first, eager steps)."""
+    key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
     if key not in _MSE3_WS:
         _MSE3_WS[key] = torch.zeros(_hip.MSE3_WS, device=device, dtype=torch.float64)
     return _MSE3_WS[key]
@@ -165,6 +185,7 @@ class _CombinedMseFn(torch.autograd.Function):
         n1, n2 = x.numel(), between.numel()
         if o3.numel() != n1 + n2:
             raise ValueError("combined_mse: %d outputs for %d + %d targets" % (o3.numel(), n1, n2))
+        ctx.set_materialize_grads(False)       # the three logged outputs carry no gradient: no zero tensors for them
         res = torch.empty(4, device=o3.device, dtype=torch.float32)
         flat = o3.reshape(-1)
         check(lib.aesr_mse3_fwd(ptr(flat), ptr(x), n1, ptr(flat[n1:]), ptr(between), n2, ptr(z_mix), ptr(z_ref),
@@ -177,6 +198,8 @@ class _CombinedMseFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, *_unused):
+        if g is None:
+            return None, None, None, None, None, None
         o3, x, between, lam = ctx.saved_tensors
         n1, n2 = x.numel(), between.numel()
         g = g.reshape(1).contiguous().float()
@@ -248,8 +271,11 @@ class HipAdam(torch.optim.Adam):
         self.flat_g = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_v = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.dev_state = torch.zeros(4, device=dev, dtype=torch.float32)
+        self.dev_state = torch.zeros(8, device=dev, dtype=torch.float32)
+        self._init_state(0.0)
         self._host_step = 0
+        self.lazy_zero = os.environ.get("AESR_LAZY_ZERO", "1") != "0"
+        self._pending_zero = False
         off = 0
         for p in self._plist:
             k = p.numel()
@@ -260,6 +286,15 @@ class HipAdam(torch.optim.Adam):
                              "exp_avg_sq": self.flat_v[off:off + k].view_as(p.data)}
             off += k
         self.numel = n
+
+    def _init_state(self, steps_done):
+        """Device state of aesr_adam_step for an optimizer that has taken ``steps_done`` steps (bias corrections of the next one)."""
+        b1, b2 = self.param_groups[0]["betas"]
+        host = (c_float * 8)()
+        lib.aesr_adam_state_init(host, float(steps_done), float(b1), float(b2))
+        # raw bytes: floats 4..7 carry two doubles, whose halves need not be meaningful floats
+        self.dev_state.view(torch.int32).copy_(torch.from_numpy(np.frombuffer(host, dtype=np.int32).copy()))
+        self._state_betas = (float(b1), float(b2))
 
     def _check_views(self):
         off = 0
@@ -276,21 +311,37 @@ class HipAdam(torch.optim.Adam):
             off += k
 
     def zero_grad(self, set_to_none=False):
+        """Gradients count as zero from here on.  ``lazy_zero`` (default): no memset node -- the engine OVERWRITES the gradient of
+        every parameter it differentiates (``_aesr_grad_fresh``), and ``step()`` zeroes the few it did not reach before Adam reads
+        them; until then the buffer of an unreached parameter still holds the previous step's values."""
         self._check_views()
-        self.flat_g.zero_()
+        if not self.lazy_zero:
+            self.flat_g.zero_()
         for p in self._plist:
             p._aesr_grad_fresh = True      # engine may overwrite p.grad directly instead of going through autograd's +=
+        self._pending_zero = self.lazy_zero
+
+    def _settle_unwritten(self):
+        """lazy_zero: parameters no backward pass wrote since zero_grad() get their zeros now."""
+        if self._pending_zero:
+            for p in self._plist:
+                if getattr(p, "_aesr_grad_fresh", False):
+                    p.grad.zero_()
+            self._pending_zero = False
 
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("closures are not supported")
         self._check_views()
+        self._settle_unwritten()
         g = self.param_groups[0]
         b1, b2 = g["betas"]
+        if (float(b1), float(b2)) != self._state_betas:            # betas changed between steps: the running powers start over
+            self._init_state(float(self.dev_state[0].item()))
         check(lib.aesr_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), ptr(self.dev_state),
                                  self.numel, float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
-                                 stream()), "aesr_adam_step")
+                                 0, stream()), "aesr_adam_step")
         self._host_step += 1
         if self.on_step is not None:
             self.on_step()
@@ -314,10 +365,5 @@ class HipAdam(torch.optim.Adam):
             st["exp_avg"] = self.flat_m[off:off + k].view_as(p.data)
             st["exp_avg_sq"] = self.flat_v[off:off + k].view_as(p.data)
             off += k
-        self.dev_state.zero_()
-        self.dev_state[0] = step
-        if step > 0:
-            b1, b2 = self.param_groups[0]["betas"]
-            self.dev_state[1] = 1.0 - b1 ** step
-            self.dev_state[2] = (1.0 - b2 ** step) ** 0.5
+        self._init_state(step)
         self._host_step = int(step)

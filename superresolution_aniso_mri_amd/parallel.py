@@ -17,9 +17,12 @@ import torch.distributed as dist
 
 
 class SegmentedStepGraph(object):
-    """The data-parallel step as a CHAIN of HIP graphs cut at every collective -- the form for a HOST-staged data plane (gloo:
-    CPU tests and several ranks rehearsed on one GPU), whose collectives cannot be graph nodes.  With the library-owned RCCL
-    communicator the collectives ARE graph nodes and the whole step is one graph (``dp_mode="whole"``); this class is not used.
+    """The data-parallel step as a CHAIN of HIP graphs cut at every collective, which stays an EAGER call between two replays: the
+    default form (``AESR_DP_GRAPH=segments``) for the RCCL data plane -- plain ncclAllReduce enqueues on the stream, RCCL's most
+    travelled path -- and the only one for a HOST-staged data plane (gloo: CPU tests and several ranks rehearsed on one GPU), whose
+    collectives cannot be graph nodes.  ``AESR_DP_GRAPH=whole`` captures the RCCL collectives as nodes of ONE step graph instead
+    (``dp_mode="whole"``: ~10 graph launches and 9 eager enqueues fewer per step; until a multi-GPU run has exercised captured
+    multi-rank collectives it is opt-in).
 
     During the capture step every ``cut(fn)`` ends the running capture, replays that segment (its results are needed now), runs
     the collective ``fn`` eagerly and begins the next segment.  Later steps replay segment i, then call collective i on the very
@@ -114,8 +117,12 @@ class DataParallelContext(object):
 
     @property
     def graph_mode(self):
-        """How a captured step handles the collectives: "whole" (RCCL calls are graph nodes) or "segments" (eager, between graphs)."""
-        return "whole" if self.data_backend == "rccl" else "segments"
+        """How a captured step handles the collectives: "segments" (eager calls between graph segments; default) or "whole" (RCCL
+        calls are nodes of one step graph; ``AESR_DP_GRAPH=whole``, RCCL data plane only)."""
+        want = os.environ.get("AESR_DP_GRAPH", "segments")
+        if want not in ("segments", "whole"):
+            raise ValueError("AESR_DP_GRAPH must be 'segments' or 'whole', got %r" % (want,))
+        return "whole" if (want == "whole" and self.data_backend == "rccl") else "segments"
 
     # ---- the library-owned RCCL communicator -------------------------------------------------------------------
     def ensure_comm(self):
@@ -133,7 +140,47 @@ class DataParallelContext(object):
         # collective over all ranks; the CURRENT device becomes this rank's device (callers set it before the first collective)
         check(lib.aesr_comm_init(box[0], self.world, self.rank, ctypes.byref(handle)), "aesr_comm_init")
         self.comm = handle
+        self._first_contact()
         return self.comm
+
+    def _first_contact(self):
+        """The communicator's first collective, checked: every rank contributes rank + 1 (fp32 and fp64), the sum must be
+        world (world + 1) / 2 on every rank and must arrive within the deadline -- a dead peer, a wrong device binding or a broken
+        fabric path shows up HERE with a message, not as a hang in step 1."""
+        n = self.world
+        a = torch.full((1024,), float(self.rank + 1), dtype=torch.float32, device=self.device)
+        b = torch.full((64,), float(self.rank + 1), dtype=torch.float64, device=self.device)
+        self._rccl(a, "sum")
+        self._rccl(b, "sum")
+        self.synchronize(float(os.environ.get("AESR_COMM_INIT_TIMEOUT", "120")), "the first all-reduce of the RCCL communicator")
+        want = n * (n + 1) / 2.0
+        if float(a.min()) != want or float(a.max()) != want or float(b.min()) != want or float(b.max()) != want:
+            raise RuntimeError("RCCL first contact: all-reduce over %d ranks returned [%g, %g] / [%g, %g], expected %g" % (
+                n, float(a.min()), float(a.max()), float(b.min()), float(b.max()), want))
+
+    def synchronize(self, timeout_s=None, what="the data-parallel step"):
+        """``torch.cuda.synchronize()`` with a deadline: the library's communicator has no watchdog thread (csrc/comm.hip), so a dead or
+        late peer would otherwise hang this rank forever.  On timeout the communicator is aborted (ncclCommAbort) and RuntimeError is
+        raised; callers exit non-zero."""
+        import time
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("AESR_STEP_TIMEOUT", "300"))
+        if self.comm is None or not torch.cuda.is_available():
+            torch.cuda.synchronize() if torch.cuda.is_available() else None
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        t0 = time.perf_counter()
+        while not ev.query():
+            if time.perf_counter() - t0 > timeout_s:
+                from ._hip import lib
+                try:
+                    lib.aesr_comm_abort(self.comm)
+                finally:
+                    self.comm = None
+                raise RuntimeError("rank %d: %s did not finish within %.0f s (a peer is dead or late); RCCL communicator aborted" % (
+                    self.rank, what, timeout_s))
+            time.sleep(0.0005 if time.perf_counter() - t0 < 0.05 else 0.01)
 
     def _rccl(self, t, op):
         from ._hip import COMM_F32, COMM_F64, COMM_MAX, COMM_SUM, check, lib, ptr, stream
@@ -154,7 +201,10 @@ class DataParallelContext(object):
         use gloo."""
         self.n_collectives += 1
         if t.is_cuda and self.data_backend == "rccl":
-            self._rccl(t, op)
+            if self.segments is not None and self.segments.capturing:
+                self.segments.cut(lambda: self._rccl(t, op))      # eager enqueue between two graph segments, replayed on this tensor
+            else:
+                self._rccl(t, op)                                 # eager step, or a node of the whole-step graph being captured
             return
         rop = dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM
 
@@ -199,6 +249,8 @@ class DataParallelContext(object):
             return
         flat = getattr(opt, "flat_g", None)
         if flat is not None:
+            if hasattr(opt, "_settle_unwritten"):
+                opt._settle_unwritten()          # lazy zero_grad: parameters no pass differentiated hold zeros before the sum
             self._all_reduce(flat)
             return
         grads = [p.grad for g in opt.param_groups for p in g["params"] if p.grad is not None]
@@ -269,9 +321,10 @@ class DataParallelContext(object):
         if self.comm is not None:
             from ._hip import lib
             try:
-                torch.cuda.synchronize()
-                lib.aesr_comm_destroy(self.comm)
-            except Exception:              # noqa: BLE001
+                self.synchronize(float(os.environ.get("AESR_SHUTDOWN_TIMEOUT", "60")), "the work still queued at shutdown")
+                if self.comm is not None:
+                    lib.aesr_comm_destroy(self.comm)
+            except Exception:              # noqa: BLE001  (synchronize() aborted the communicator: nothing left to destroy)
                 pass
             self.comm = None
         if dist.is_available() and dist.is_initialized():
@@ -286,3 +339,37 @@ class DataParallelContext(object):
         t = torch.tensor([float(v)], dtype=torch.float64)
         self._all_reduce(t, "max")
         return float(t)
+
+
+def one_rank_collective_cost_us(device, reps=50):
+    """Device time per collective of a data-parallel step's exchange pattern on a ONE-rank RCCL communicator: 8 SyncBN all-reduces
+    ([2][2][64] fp64) and the flat gradient all-reduce (443 777 fp32), as they are enqueued on the stream.  No wire time -- with one
+    rank RCCL copies in place -- so this is the enqueue / launch floor of the 9 collectives, the part of their cost that does not shrink
+    with the batch (bench.py: projected 8-rank rate)."""
+    import ctypes
+    from ._hip import COMM_F32, COMM_F64, COMM_ID_BYTES, COMM_SUM, check, lib, ptr, stream
+    uid = ctypes.create_string_buffer(COMM_ID_BYTES)
+    check(lib.aesr_comm_unique_id(uid), "aesr_comm_unique_id")
+    handle = ctypes.c_void_p()
+    torch.cuda.set_device(device)
+    check(lib.aesr_comm_init(uid.raw, 1, 0, ctypes.byref(handle)), "aesr_comm_init")
+    try:
+        small = [torch.zeros((2, 2, 64), dtype=torch.float64, device=device) for _ in range(8)]
+        flat = torch.zeros(443777, dtype=torch.float32, device=device)
+
+        def one_step():
+            for t in small:
+                check(lib.aesr_comm_allreduce(handle, ptr(t), t.numel(), COMM_F64, COMM_SUM, stream()), "aesr_comm_allreduce")
+            check(lib.aesr_comm_allreduce(handle, ptr(flat), flat.numel(), COMM_F32, COMM_SUM, stream()), "aesr_comm_allreduce")
+        for _ in range(5):
+            one_step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            one_step()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / (9 * reps)
+    finally:
+        lib.aesr_comm_destroy(handle)

@@ -125,7 +125,12 @@ def main(argv=None, brain=False):
                                                                                      trainer.mean_losses_test["loss_ae"][-1]))
                     trainer.reset_losses()
             trainer.end_epoch_processing(epoch=int(epoch), val_result_dict=val_result or {}, batch_item=batch_item)
+        trainer.save_models(os.path.join(args_dict["dir_models"], "{:0d}.models".format(int(epoch))), int(epoch))
     except KeyboardInterrupt:
         print("KeyboardInterrupt - Save model and exit")
-    trainer.save_models(os.path.join(args_dict["dir_models"], "{:0d}.models".format(int(epoch))), int(epoch))
+        trainer.save_models(os.path.join(args_dict["dir_models"], "{:0d}.models".format(int(epoch))), int(epoch))
+    finally:
+        # the library-owned communicator has no watchdog: leave it with a bounded wait (parallel.DataParallelContext.synchronize) so
+        # that a rank whose peer died exits instead of hanging in the teardown
+        dp.shutdown()
     return trainer

@@ -120,8 +120,10 @@ def test_grouped_passes_equal_sequential_passes():
 @pytest.mark.parametrize("cname,args", [("VanillaACAI", SMALL), ("LargerAE", SMALL), ("VanillaACAIStrided", SMALL),
                                         ("VanillaACAI", dict(SMALL, width=64, latent_width=16, depth=32, latent=32))])
 def test_stem_folded_pass_equals_unfolded_pass(cname, args):
-    """The encoder pass with the stem folded into the first 3x3 convolution (default) == the layer-by-layer pass
-    (outputs 1e-5, every parameter gradient 1e-4, BatchNorm running statistics 1e-5)."""
+    """The encoder pass with the stem folded into the first 3x3 convolution (default) == the layer-by-layer pass: outputs and BatchNorm
+    running statistics to 1e-5; parameter gradients are judged against an fp64 evaluation of the oracle -- the folded pass may be no
+    further from it than the layer-by-layer pass (x2 + 1e-4), because the two fp32 paths differ from EACH OTHER by more than either
+    differs in quality (gradients here are sums over every pixel of nearly cancelling products)."""
     torch.manual_seed(11)
     model = _model(cname, args)
     for p in model.parameters():           # non-zero biases so the per-tap border bias matters
@@ -151,12 +153,21 @@ def test_stem_folded_pass_equals_unfolded_pass(cname, args):
     (z1, zb1, g1, r1), (z0, zb0, g0, r0) = res
     assert rel_l2(z1, z0) < 1e-5 and rel_l2(zb1, zb0) < 1e-5
     assert set(g1) == set(g0) and any(k.startswith("enc.0.") for k in g1)
+    # the same gradient in fp64 (the oracle's restatement of the reference modules, parameters and inputs cast up)
+    from oracle import ae_oracle
+    o64 = ae_oracle.OracleAE(dict(args), ae_class=cname, init=False).load_state_dict({k: v.detach().cpu() for k, v in state0.items()})
+    o64.params = type(o64.params)((k, v.detach().double().requires_grad_(True)) for k, v in o64.params.items())
+    o64.buffers = type(o64.buffers)((k, v.double() if v.is_floating_point() else v) for k, v in o64.buffers.items())
+    z64 = o64.encode(x.cpu().double(), train=True)
+    (z64 ** 2).mean().backward()
+    assert rel_l2(z1, z64.detach()) < 1e-5
+    worst = 0.0
     for k in g0:
-        # parameter gradients are sums over every pixel of products that nearly cancel (values 1e-8 .. 1e-5 under this loss), so the
-        # 1e-7 difference between the two ways of computing the first activation is amplified: 7e-4 measured on the depth-32
-        # stack.  The fold itself is pinned by the outputs and the BatchNorm statistics here and by
-        # test_gpu_kernels.py::test_stem_folded_into_first_conv against torch
-        assert rel_l2(g1[k], g0[k]) < 3e-3, k
+        ref = o64.params[k].grad
+        e1, e0 = rel_l2(g1[k], ref), rel_l2(g0[k], ref)
+        worst = max(worst, e1)
+        assert e1 <= 2.0 * e0 + 1e-4, (k, e1, e0)
+    assert worst < 2e-3            # and an absolute ceiling on the folded pass itself (7e-4 measured on the depth-32 stack)
     for k in r0:
         assert rel_l2(r1[k], r0[k]) < 1e-5, k
 

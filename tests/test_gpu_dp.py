@@ -102,11 +102,12 @@ def test_segmented_step_graph_equals_host_launched_data_parallel(tmp_path):
             assert int(seg["sd"][k]) == int(v)
 
 
-def _rccl_worker(rank, port, out):
+def _rccl_worker(rank, port, out, graph_form):
     """A data-parallel group of ONE on the library-owned RCCL communicator (RCCL refuses two ranks on one device, so a one-GPU box
-    exercises the call pattern with nranks = 1): raw collectives, then the trainer step host-launched and as ONE captured graph
-    with the RCCL calls as graph nodes."""
-    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AESR_FORCE_DP="1")
+    exercises the call pattern with nranks = 1): raw collectives, then the trainer step host-launched and captured -- as graph
+    segments between eager RCCL enqueues (the default form) or as ONE graph with the RCCL calls as nodes (AESR_DP_GRAPH=whole)."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AESR_FORCE_DP="1",
+                      AESR_DP_GRAPH=graph_form)
     os.environ.pop("AESR_DIST_BACKEND", None)
     import ctypes
     import warnings
@@ -117,7 +118,7 @@ def _rccl_worker(rank, port, out):
     from superresolution_aniso_mri_amd.parallel import DataParallelContext
     torch.cuda.set_device(0)
     dp = DataParallelContext(device="cuda:0")
-    assert dp.active and dp.data_backend == "rccl" and dp.graph_mode == "whole"
+    assert dp.active and dp.data_backend == "rccl" and dp.graph_mode == graph_form
     ver = ctypes.c_int(0)
     _hip.check(_hip.lib.aesr_comm_rccl_version(ctypes.byref(ver)), "aesr_comm_rccl_version")
     res = {"rccl_version": ver.value}
@@ -140,7 +141,7 @@ def _rccl_worker(rank, port, out):
     tr = get_trainer_dynamic(_args("mse"))
     dp.attach(tr)
     dp.set_batch(3)
-    tr.enable_step_graph(eager_steps=2)                  # dp_mode picked from the data plane: "whole"
+    tr.enable_step_graph(eager_steps=2)                  # dp_mode picked from the data plane / AESR_DP_GRAPH
     n0 = dp.n_collectives
     for step in range(5):                                # 2 host-launched, 1 capture, 2 replays
         tr.train(synthetic_batch(3, 32, 32, seed=40 + step, brain=True), keep_predictions=False)
@@ -153,16 +154,17 @@ def _rccl_worker(rank, port, out):
     dp.shutdown()
 
 
-def test_rccl_communicator_and_whole_step_graph(tmp_path):
+@pytest.mark.parametrize("graph_form", ["segments", "whole"])
+def test_rccl_communicator_and_step_graph_forms(tmp_path, graph_form):
     import warnings
     from superresolution_aniso_mri_amd.data_synth import synthetic_batch
     from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
     out = str(tmp_path / "rccl.pt")
-    mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(_free_port(), out, graph_form), nprocs=1, join=True)
     res = torch.load(out)
     assert res["rccl_version"] >= 21800 and res["raw_ok"]
     assert res["bad_dtype"][0] != 0 and "dtype" in res["bad_dtype"][1]
-    assert res["graphs"] == 1 and res["graph_dp"] == "whole"
+    assert res["graphs"] == 1 and res["graph_dp"] == graph_form
     # per step: 4 BatchNorm layers x (forward + backward) SyncBN exchanges + ONE flat gradient all-reduce
     assert res["collectives_per_step"] == 9
     with warnings.catch_warnings():
@@ -179,4 +181,71 @@ def test_rccl_communicator_and_whole_step_graph(tmp_path):
             continue
         diff = (a - b).abs()
         assert float(diff.max()) <= 5 * 2 * 1e-3 + 1e-6, k
+        assert float((diff > 1e-4 + 1e-3 * b.abs()).double().mean()) <= 0.03, k
+
+
+# ---- first contact with a real multi-GPU node: TWO ranks on DISTINCT devices over RCCL -----------------------------------------------
+def _rccl2_worker(rank, port, B, out, graph_form, steps):
+    os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      AESR_DP_GRAPH=graph_form or "segments", AESR_COMM_INIT_TIMEOUT="90", AESR_STEP_TIMEOUT="120")
+    os.environ.pop("AESR_DIST_BACKEND", None)
+    os.environ.pop("AESR_FORCE_DP", None)
+    import warnings
+    warnings.simplefilter("ignore")
+    from superresolution_aniso_mri_amd.data_synth import shard_batch, synthetic_batch
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    from superresolution_aniso_mri_amd.parallel import DataParallelContext
+    torch.cuda.set_device(rank)
+    dev = "cuda:%d" % rank
+    dp = DataParallelContext(device=dev)
+    try:
+        assert dp.data_backend == "rccl"
+        torch.manual_seed(100 + rank)                       # ranks start from different weights; attach() broadcasts rank 0's
+        tr = get_trainer_dynamic(dict(_args("mse"), device=dev))
+        dp.attach(tr)                                       # first collective: the checked first contact of parallel._first_contact
+        dp.set_batch(B)
+        if graph_form:
+            tr.enable_step_graph(eager_steps=1)
+        for step in range(steps):
+            tr.train(shard_batch(synthetic_batch(B, 32, 32, seed=40 + step, brain=True), rank, 2), keep_predictions=False)
+        dp.synchronize()
+        losses = [dp.reduce_scalar(v) for v in tr.losses["loss_ae"].floats()]
+        if rank == 0:
+            torch.save({"sd": {k: v.cpu() for k, v in tr.model.state_dict().items()}, "loss": losses,
+                        "graph_dp": getattr(tr, "_graph_dp", None), "ncoll": dp.n_collectives}, out)
+        dp.barrier()
+    finally:
+        dp.shutdown()
+
+
+@pytest.mark.parametrize("graph_form", [None, "segments", "whole"])
+@pytest.mark.parametrize("B", [4, 3])
+def test_two_gpus_rccl_equal_single_process(tmp_path, graph_form, B):
+    """Needs two GPUs (skipped on the one-GPU build box; the driver's 8-GPU node runs it): two ranks on distinct devices through
+    aesr_comm_init, 5 steps host-launched / as graph segments between eager RCCL collectives / as one graph with the collectives as
+    nodes, even (2 + 2) and uneven (1 + 2 triplets) shards; every form must reproduce the single-process run."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import warnings
+    from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    out = str(tmp_path / "rccl2.pt")
+    steps = 5
+    mp.spawn(_rccl2_worker, args=(_free_port(), B, out, graph_form, steps), nprocs=2, join=True)
+    res = torch.load(out)
+    assert res["graph_dp"] == graph_form or graph_form is None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(100)
+        ref = get_trainer_dynamic(_args("mse"))
+    for step in range(steps):
+        ref.train(synthetic_batch(B, 32, 32, seed=40 + step, brain=True), keep_predictions=False)
+    np.testing.assert_allclose(res["loss"], ref.losses["loss_ae"].floats(), rtol=2e-5)
+    for k, v in ref.model.state_dict().items():
+        a, b = res["sd"][k].double(), v.cpu().double()
+        if "num_batches" in k:
+            assert int(a) == int(b)
+            continue
+        diff = (a - b).abs()
+        assert float(diff.max()) <= steps * 2 * 1e-3 + 1e-6, k
         assert float((diff > 1e-4 + 1e-3 * b.abs()).double().mean()) <= 0.03, k

@@ -60,6 +60,37 @@ def test_super_volume_properties_at_dhcp_size():
     np.testing.assert_allclose(lim[2::3][:Z - 1].numpy(), rec[0:-1:n + 1].numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_fused_lerp_decode_at_eval_patch_size(monkeypatch):
+    """BASELINE configs[4] inference leg: a dHCP-shaped volume cropped to the 224 x 224 evaluation patch (README.md:97), 3 interpolations.
+    The fused path (decoder's first convolution once per slice, all mixes formed on its pre-activations by aesr_lerp_multi, the rest of
+    the decoder on them) must equal lerp on the latents + a full decoder pass, and the kernel its definition."""
+    from superresolution_aniso_mri_amd import _hip, ops
+    from superresolution_aniso_mri_amd.generate_hr_volumes import create_super_volume
+    from superresolution_aniso_mri_amd.networks.acai_vanilla import HipAE
+    torch.manual_seed(7)
+    tr = _trainer(dict(width=256, latent_width=64, depth=32, latent=128))
+    Z, n = 7, 3
+    vol = torch.rand(Z, 1, 224, 224)
+    alphas = np.linspace(0, 1, n + 2)[1:-1]
+    fused = create_super_volume(tr, vol, alphas, use_original=True)["upsampled_image"]
+    assert fused.shape == ((Z - 1) * (n + 1) + 1, 224, 224)
+    called = []
+    orig = HipAE.decode_mixes
+    monkeypatch.setattr(HipAE, "decode_mixes", lambda self, z, a: called.append(1) or None)          # -> lerp on latents + full decode
+    plain = create_super_volume(tr, vol, alphas, use_original=True)["upsampled_image"]
+    monkeypatch.setattr(HipAE, "decode_mixes", orig)
+    assert called
+    np.testing.assert_allclose(fused.numpy(), plain.numpy(), rtol=1e-5, atol=2e-6)
+    # the kernel: out[k][i] = act(a_k z[i+1] + (1 - a_k) z[i])
+    z = torch.randn(5, 6, 10, 8, device="cuda")
+    a = [0.25, 0.5, 0.9]
+    got = ops.lerp_multi(z, a, _hip.ACT_LRELU, 0.01)
+    ref = torch.cat([torch.nn.functional.leaky_relu(ak * z[1:] + (1 - ak) * z[:-1], 0.01) for ak in a])
+    assert torch.allclose(got, ref, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(ops.lerp_multi(z, a), torch.cat([ak * z[1:] + (1 - ak) * z[:-1] for ak in a]), rtol=1e-6, atol=1e-7)
+    assert _hip.lib.aesr_lerp_multi(_hip.ptr(z), _hip.ptr(got), 1, 480, _hip.float_array(a), 3, 0, 0.0, _hip.stream()) != 0      # one slice: no pair
+
+
 def test_patch_tiled_interpolation_matches_whole_image_on_tiles():
     from superresolution_aniso_mri_amd.kwatsch.img_interpolation import latent_space_interp, latent_space_interp_diff_patch_size
     torch.manual_seed(4)

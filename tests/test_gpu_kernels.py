@@ -1,6 +1,8 @@
 """-m gpu: every HIP kernel of libaesr_hip.so, called through the C ABI, against a PyTorch-CPU fp32 reference
 of the same op on the same seeded inputs.  Tolerances are fp32 summation-order tolerances (the MFMA path is an
 exact-fp32 fma chain): rel-L2 <= 1e-5 for forward ops, <= 1e-4 for long reductions (wgrad)."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -331,7 +333,7 @@ def test_resample2_fwd_bwd(hip, mode, shape, masked):
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
-@pytest.mark.parametrize("shape", [(6, 33, 31, 32), (4, 40, 40, 64), (3, 9, 9, 8)])
+@pytest.mark.parametrize("shape", [(6, 33, 31, 32), (4, 40, 40, 64), (3, 9, 9, 8), (9, 80, 80, 32)])
 def test_bn_groups_fwd_bwd(hip, mode, shape):
     """Two statistic groups (4+2 images etc.) == two independent nn.BatchNorm2d calls in sequence."""
     N, H, W, C = shape
@@ -383,6 +385,21 @@ def test_bn_groups_fwd_bwd(hip, mode, shape):
     mask = torch.where(y.detach()[:n0] > 0, 1.0, 0.01)
     assert rel_l2(nchw(dpre), y.grad[:n0] * mask) < 2e-5
     assert rel_l2(dgam, bn.weight.grad) < 2e-5 and rel_l2(dbet, bn.bias.grad) < 2e-5
+    # the single-process composites (what the engine calls) give the same numbers
+    rm2, rv2, nbt2 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros((), dtype=torch.int64, device="cuda")
+    st2 = [torch.full((G, C), float("nan"), device="cuda") for _ in range(4)]
+    hip.check(L.aesr_bn_stats_finalize(hip.ptr(yd), hip.ptr(partial), counts, hip.ptr(gam), hip.ptr(bet), hip.ptr(rm2), hip.ptr(rv2),
+                                       hip.ptr(nbt2), *[hip.ptr(t) for t in st2], H * W, C, G, ns, 0.1, 1e-5, 1, hip.stream()), "stats_finalize")
+    coef2 = torch.full((1, 2, C), float("nan"), device="cuda")
+    dgam2, dbet2 = torch.full((C,), float("nan"), device="cuda"), torch.full((C,), float("nan"), device="cuda")
+    dpre2 = torch.full((n0, H, W, C), float("nan"), device="cuda")
+    hip.check(L.aesr_bn_bwd(hip.ptr(god), hip.ptr(yd), hip.ptr(st[0]), hip.ptr(st[1]), hip.ptr(st[2]), hip.ptr(partial), counts,
+                            hip.ptr(coef2), hip.ptr(dgam2), hip.ptr(dbet2), hip.ptr(dpre2), n0, H, W, C, mode, 1, 0.01, 1, ns1,
+                            hip.stream()), "bn_bwd")
+    torch.cuda.synchronize()
+    assert int(nbt2) == 2
+    for got, want in zip(st2 + [rm2, rv2, coef2, dgam2, dbet2, dpre2], st + [rm, rv, coef, dgam, dbet, dpre]):
+        assert rel_l2(got, want) < 2e-6
 
 
 def test_lerp_mse_act_adam(hip):
@@ -433,13 +450,20 @@ def test_lerp_mse_act_adam(hip):
     p = torch.randn(5000, generator=g)
     pt = p.clone().requires_grad_(True)
     opt = torch.optim.Adam([pt], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
-    pd, m, v, state = p.cuda(), torch.zeros(5000, device="cuda"), torch.zeros(5000, device="cuda"), torch.zeros(4, device="cuda")
-    for _ in range(3):
+    pd, m, v = p.cuda(), torch.zeros(5000, device="cuda"), torch.zeros(5000, device="cuda")
+    host = (ctypes.c_float * 8)()
+    L.aesr_adam_state_init(host, 0.0, 0.9, 0.999)
+    state = torch.from_numpy(np.frombuffer(host, dtype=np.int32).copy()).cuda().view(torch.float32)
+    for k in range(3):
         gr = torch.randn(5000, generator=g)
         pt.grad = gr.clone()
         opt.step()
-        hip.check(L.aesr_adam_step(hip.ptr(pd), hip.ptr(D(gr)), hip.ptr(m), hip.ptr(v), hip.ptr(state), 5000, 1e-3, 0.9, 0.999, 1e-8,
-                                   0.01, hip.stream()), "adam")
+        gd = D(gr)
+        hip.check(L.aesr_adam_step(hip.ptr(pd), hip.ptr(gd), hip.ptr(m), hip.ptr(v), hip.ptr(state), 5000, 1e-3, 0.9, 0.999, 1e-8,
+                                   0.01, k % 2, hip.stream()), "adam")
+        # zero_grad: the gradient buffer is left at zero (odd k) or untouched (even k); the step counter advances once per launch
+        assert float(gd.abs().max()) == 0.0 if k % 2 else torch.equal(gd.cpu(), gr)
+        assert float(state[0]) == k + 1 and state.view(torch.int32)[3].item() == 0
     assert rel_l2(pd, pt.detach()) < 1e-6 and float(state[0]) == 3.0
 
 

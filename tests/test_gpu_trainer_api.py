@@ -127,3 +127,140 @@ def test_masked_mse_synthesis_loss(tmp_path):
     batch["loss_mask"] = mask
     tr.train(batch)
     assert np.isfinite(tr.losses["loss_ae"][-1])
+
+
+@pytest.mark.parametrize("name,B,size,width,latent_width,dataset", [("c4_oasis", 16, 220, 64, 16, "OASIS"), ("c5_dhcp", 8, 256, 256, 64, "dHCP")])
+def test_baseline_config_shapes_with_lpips_vs_oracle(tmp_path, name, B, size, width, latent_width, dataset):
+    """BASELINE configs[3] / configs[4] as BASELINE.json states them -- WITH the LPIPS-VGG synthesis loss (lambda 0.001, per-sample
+    mixing coefficients of the brain trainer), full size, one rank: first step against the CPU oracle (losses, predictions, first-step
+    gradients, parameters after Adam)."""
+    from oracle import ae_oracle, lpips_oracle, step_oracle
+    from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = dict(width=width, latent_width=latent_width, depth=32, latent=128, colors=1, use_batchnorm=True, use_sigmoid=True)
+    torch.manual_seed(5)
+    with pytest.warns(UserWarning):
+        tr = get_trainer_dynamic(_args(tmp_path, dataset=dataset, ex_loss_weight1=0.001, lr=1e-5, image_mix_loss_func="perceptual", **cfg))
+    assert type(tr).__name__ == "AETrainerExtension1Brain" and tr.percept_criterion is not None
+    oracle = ae_oracle.OracleAE(cfg, init=False).load_state_dict({k: v.detach().cpu() for k, v in tr.model.state_dict().items()})
+    lin = np.load(os.path.join(root, "superresolution_aniso_mri_amd", "lpips", "weights", "v0.1", "vgg_lin.npz"))
+    ost = step_oracle.OracleStep(oracle, lr=1e-5, ex_loss_weight1=0.001, image_mix_loss_func="perceptual", vgg_sd=lpips_oracle.hash_vgg16_state(),
+                                 lin_w=[torch.from_numpy(lin["lin%d" % k]).reshape(1, -1, 1, 1) for k in range(5)])
+    batch = synthetic_batch(B, size, size, seed=11, brain=True)
+    tr.train(batch)
+    ref = ost.train(batch["image"], batch["slice_between"], batch["alpha_from"], batch["alpha_to"])
+    for key, want in (("loss_ae", ref["loss_ae"]), ("loss_ae_dist_extra", ref["loss_ae_dist_extra"]), ("loss_latent_1", ref["loss_latent_1"])):
+        assert abs(tr.losses[key][-1] - want) <= 5e-5 * abs(want), key
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    assert rel(tr.train_predictions["reconstruction"], ref["out"]) < 1e-5 and rel(tr.train_predictions["slice_inbetween_mix"], ref["s_mix"]) < 1e-5
+    num = den = 0.0
+    for k, p in tr.model.named_parameters():
+        g, r = p.grad.detach().double().cpu(), oracle.params[k].grad.double()
+        num += float((g - r).pow(2).sum())
+        den += float(r.pow(2).sum())
+    assert (num / den) ** 0.5 < 2.5e-4
+    for (k, a), (_, b) in zip(tr.model.state_dict().items(), oracle.state_dict().items()):
+        if a.dtype.is_floating_point:
+            assert float((a.cpu() - b).abs().max()) <= 2.5e-5 + 1e-5 * float(b.abs().max()), k
+
+
+def test_vgg_weights_file_is_loaded(tmp_path):
+    """--vgg_weights FILE (lpips/dist_model.py:24-25 of this build; replaces torchvision.models.vgg16(pretrained=True) of the reference's
+    lpips/pretrained_networks.py:100): a torchvision-keyed ``features.N.weight / .bias`` state_dict on disk is what the HIP LPIPS
+    computes with -- distances and gradient equal the oracle's with the SAME weights, and differ from the synthetic backbone's."""
+    from oracle import lpips_oracle
+    from superresolution_aniso_mri_amd.lpips.perceptual import PerceptualLoss
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = torch.Generator().manual_seed(21)
+    sd = {}
+    for idx, (cin, cout) in zip(lpips_oracle.vgg16_feature_indices(), [(3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256),
+                                                                      (256, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 512)]):
+        sd["features.%d.weight" % idx] = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+        sd["features.%d.bias" % idx] = torch.randn(cout, generator=g) * 0.05
+    f = str(tmp_path / "vgg16_features.pth")
+    torch.save(sd, f)
+    crit = PerceptualLoss(model="net-lin", net="vgg", use_gpu=True, gpu_ids=[0], vgg_weights=f, device="cuda")
+    with pytest.warns(UserWarning):
+        synth = PerceptualLoss(model="net-lin", net="vgg", use_gpu=True, gpu_ids=[0], vgg_weights="synthetic-hash", device="cuda")
+    a = torch.rand(3, 1, 48, 40, generator=g)
+    b = torch.rand(3, 1, 48, 40, generator=g)
+    bd = b.cuda().requires_grad_(True)
+    d = crit(a.cuda(), bd, normalize=True)
+    d.mean().backward()
+    lin = np.load(os.path.join(root, "superresolution_aniso_mri_amd", "lpips", "weights", "v0.1", "vgg_lin.npz"))
+    lin_w = [torch.from_numpy(lin["lin%d" % k]).reshape(1, -1, 1, 1) for k in range(5)]
+    br = b.clone().requires_grad_(True)
+    ref = lpips_oracle.perceptual_loss(a, br, sd, lin_w, normalize=True)
+    ref.mean().backward()
+    np.testing.assert_allclose(d.detach().cpu().numpy().ravel(), ref.detach().numpy().ravel(), rtol=2e-5)
+    assert float((bd.grad.cpu().double() - br.grad.double()).norm() / br.grad.double().norm()) < 2e-4
+    d_syn = synth(a.cuda(), b.cuda(), normalize=True)
+    assert float((d_syn.cpu() - d.detach().cpu()).abs().max()) > 1e-3 * float(d.detach().abs().max())
+
+
+def test_model_sr_and_load_caisr_round_trip(tmp_path):
+    """The second ("SR") model of the eval wrappers (kwatsch/base_trainer.py:213-214,298-300 here; reference :325-336,358-367) through the
+    loader's own route (kwatsch/get_trainer.py:42-55: ``model_nbr_sr`` -> models/<nbr>.models -> ``model_sr`` + ``load_caisr``):
+    ``use_sr_model=True`` routes encode / decode through it, and generate_hr_volumes synthesises with it."""
+    from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+    from superresolution_aniso_mri_amd.generate_hr_volumes import create_super_volume
+    from superresolution_aniso_mri_amd.kwatsch.common import saveExperimentSettings
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    src = tmp_path / "exper"
+    os.makedirs(src / "models")
+    a = _args(src)
+    saveExperimentSettings(a, str(src / "settings.yaml"))
+    torch.manual_seed(0)
+    main = get_trainer_dynamic(dict(a))
+    main.train(synthetic_batch(3, 32, 32, seed=0))
+    main.save_models(str(src / "models" / "3.models"), 3)
+    torch.manual_seed(1)                                  # the SR checkpoint: a different, further trained model
+    donor = get_trainer_dynamic(dict(a))
+    for it in range(3):
+        donor.train(synthetic_batch(3, 32, 32, seed=10 + it))
+    donor.save_models(str(src / "models" / "5.models"), 5)
+    tr, args2 = get_trainer_dynamic(src_path=str(src), model_nbr=3, model_nbr_sr=5, eval_mode=True)
+    assert tr.model_sr is not None and tr.model_sr is not tr.model and args2["latent"] == a["latent"]
+    for (k, v), (_, w) in zip(tr.model_sr.state_dict().items(), donor.model.state_dict().items()):
+        assert torch.equal(v.cpu(), w.cpu()), k
+    for (k, v), (_, w) in zip(tr.model.state_dict().items(), main.model.state_dict().items()):
+        assert torch.equal(v.cpu(), w.cpu()), k
+    x = torch.rand(4, 1, 32, 32)
+    z_sr, z_main, z_donor = tr.encode(x, use_sr_model=True), tr.encode(x), donor.encode(x)
+    assert torch.allclose(z_sr, z_donor, rtol=1e-6, atol=1e-7) and not torch.allclose(z_sr, z_main, rtol=1e-3, atol=1e-4)
+    assert torch.allclose(tr.decode(z_sr, use_sr_model=True), donor.decode(z_donor), rtol=1e-6, atol=1e-7)
+    hr_sr = create_super_volume(tr, x, [0.5], use_original=False)["upsampled_image"]          # synthesis goes through the SR model
+    hr_donor = create_super_volume(donor, x, [0.5], use_original=False)["upsampled_image"]
+    np.testing.assert_allclose(hr_sr.numpy(), hr_donor.numpy(), rtol=1e-6, atol=1e-7)
+    # no SR checkpoint asked for: use_sr_model falls back to the main model (reference _use_sr_model)
+    tr0, _ = get_trainer_dynamic(src_path=str(src), model_nbr=3, eval_mode=True)
+    assert tr0.model_sr is None and torch.equal(tr0.encode(x, use_sr_model=True), tr0.encode(x))
+
+
+def test_cosine_annealing_lr_steps_vs_oracle(tmp_path):
+    """--use_lr_scheduler (kwatsch/base_trainer.py:58-62 here, reference :18-22: CosineAnnealingLR(opt, lr_iter_max, eta_min=0), stepped
+    once per training step): three steps against the oracle with the same scheduler; the step graph stays off (per-step learning rates)."""
+    from oracle import ae_oracle, step_oracle
+    from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    cfg = dict(width=32, latent_width=8, depth=8, latent=16, colors=1, use_batchnorm=True, use_sigmoid=True)
+    torch.manual_seed(3)
+    tr = get_trainer_dynamic(_args(tmp_path, lr=1e-3, use_lr_scheduler=True, lr_iter_max=4))
+    tr.enable_step_graph(eager_steps=0)
+    oracle = ae_oracle.OracleAE(cfg, init=False).load_state_dict({k: v.detach().cpu() for k, v in tr.model.state_dict().items()})
+    ost = step_oracle.OracleStep(oracle, lr=1e-3, ex_loss_weight1=0.05, image_mix_loss_func="mse")
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(ost.opt, 4, eta_min=0, last_epoch=-1)
+    lrs = []
+    for it in range(3):
+        b = synthetic_batch(3, 32, 32, seed=50 + it)
+        tr.train(b, keep_predictions=False)
+        ref = ost.train(b["image"], b["slice_between"])
+        sched.step()
+        lrs.append(tr.opt_ae.param_groups[0]["lr"])
+        assert abs(tr.losses["loss_ae"][-1] - ref["loss_ae"]) <= 5e-5 * abs(ref["loss_ae"]), it
+        assert abs(lrs[-1] - ost.opt.param_groups[0]["lr"]) < 1e-12
+    assert lrs[0] > lrs[1] > lrs[2] > 0 and not getattr(tr, "_graphs", None)
+    for (k, a), (_, b_) in zip(tr.model.state_dict().items(), oracle.state_dict().items()):
+        if a.dtype.is_floating_point:
+            assert float((a.cpu() - b_).abs().max()) <= 3 * 2 * 1e-3 + 1e-6, k
