@@ -36,6 +36,12 @@ VGG = [
 ]
 
 
+if os.environ.get("AESR_BENCH_N"):          # small-shard experiments: the same layers at another image count
+    _n = int(os.environ["AESR_BENCH_N"])
+    AE = [(a, _n, c, d, e, f) for a, _, c, d, e, f in AE]
+    VGG = [(a, max(1, _n * 2 // 3), c, d, e, f) for a, _, c, d, e, f in VGG]
+
+
 def timeit(fn, iters=10):
     fn()
     torch.cuda.synchronize()

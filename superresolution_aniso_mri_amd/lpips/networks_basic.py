@@ -104,6 +104,11 @@ class _LpipsFn(torch.autograd.Function):
         return None, None, None, g0, None
 
 
+# ScalingLayer + channel broadcast + conv1_1 folded into one single-channel convolution (PNetLin._conv1_1_folded); AESR_LPIPS_FOLD=0 keeps
+# the 4-channel expansion + implicit GEMM
+FOLD_CONV1_1 = os.environ.get("AESR_LPIPS_FOLD", "1") != "0"
+
+
 class PNetLin(nn.Module):
     def __init__(self, pnet_type="vgg", pnet_rand=False, pnet_tune=False, use_dropout=True, spatial=False, version="0.1",
                  lpips=True, vgg_state_dict=None):
@@ -160,6 +165,35 @@ class PNetLin(nn.Module):
         self._packed = pk
         return pk
 
+    def _conv1_1_folded(self, pk, mul, add):
+        """ScalingLayer + the 1 -> 3 channel broadcast + conv1_1 (lpips/networks_basic.py:99-100, lpips/pretrained_networks.py:107 of the
+        reference) as ONE single-channel 3x3 convolution: the three input planes are affine copies a_c x + b_c of the same slice, so
+        conv1_1 of them is a 1 -> 64 convolution with weff[t][co] = sum_c W[co,c,t] a_c plus a per-tap bias beff[t][co] = sum_c W[co,c,t] b_c
+        that counts only for taps inside the image (the zero padding applies to the 3-channel tensor) -- the stem-fold form of
+        csrc/conv_thin.hip, bandwidth-bound.  Returns (folded [2 x 9 x 64] for aesr_stemconv_fwd, flipped filter [1,64,3,3] for the data
+        gradient as a 64 -> 1 convolution); cached per (mul, add)."""
+        cache = pk.setdefault("c11", {})
+        if add is None:                       # backward: the filter only depends on ``mul``; any entry of the forward pass serves
+            for (m, _), v in cache.items():
+                if m == float(mul):
+                    return v
+            add = 0.0
+        key = (float(mul), float(add))
+        if key in cache:
+            return cache[key]
+        ca, cb = self._affine(mul, add)
+        w0 = self.net.convs()[0].weight.detach().double()                     # [64, 3, 3, 3]
+        a = torch.tensor(ca, dtype=torch.float64, device=w0.device)
+        b = torch.tensor(cb, dtype=torch.float64, device=w0.device)
+        weff = torch.einsum("ocyx,c->yxo", w0, a).reshape(9, -1)               # [t = 3 ky + kx][co]
+        beff = torch.einsum("ocyx,c->yxo", w0, b).reshape(9, -1)
+        folded = torch.cat([weff.reshape(-1), beff.reshape(-1)]).float().contiguous()
+        wflip = weff.flip(0).t().reshape(1, -1, 3, 3).float().contiguous()      # [0, co, ky, kx] = weff[(2 - ky, 2 - kx)][co]
+        if len(cache) > 8:
+            cache.clear()
+        cache[key] = (folded, wflip)
+        return folded, wflip
+
     def _affine(self, mul, add):
         hc = self.__dict__.get("_scaling_host")
         if hc is None:          # one device read, cached: no host sync per call (and legal under HIP-graph capture)
@@ -174,15 +208,20 @@ class PNetLin(nn.Module):
         B, H, W, _ = x0.shape
         x = torch.cat([x0, x1], dim=0)
         N = 2 * B
-        ca, cb = self._affine(mul, add)
         acts, pool_in, taps = [], {}, []
         c0 = convs[0]
-        x4 = torch.empty((N, H, W, 4), device=x.device)
-        check(lib.aesr_scale_expand_fwd(ptr(x), ptr(x4), N * H * W, _hip.float_array(ca), _hip.float_array(cb), stream()),
-              "aesr_scale_expand_fwd")
         cur = torch.empty((N, H, W, 64), device=x.device)
-        check(lib.aesr_conv2d_fwd(ptr(x4), ptr(pk["fwd"][0]), ptr(c0.bias), ptr(cur), N, H, W, 4, 64, 3, 1, _hip.ACT_RELU, 0.0,
-                                  stream()), "aesr_conv2d_fwd(vgg conv1_1)")
+        if FOLD_CONV1_1:
+            folded, _ = self._conv1_1_folded(pk, mul, add)
+            check(lib.aesr_stemconv_fwd(ptr(x), ptr(folded), ptr(c0.bias), ptr(cur), N, H, W, 64, 0, _hip.ACT_RELU, 0.0, stream()),
+                  "aesr_stemconv_fwd(vgg conv1_1)")
+        else:
+            ca, cb = self._affine(mul, add)
+            x4 = torch.empty((N, H, W, 4), device=x.device)
+            check(lib.aesr_scale_expand_fwd(ptr(x), ptr(x4), N * H * W, _hip.float_array(ca), _hip.float_array(cb), stream()),
+                  "aesr_scale_expand_fwd")
+            check(lib.aesr_conv2d_fwd(ptr(x4), ptr(pk["fwd"][0]), ptr(c0.bias), ptr(cur), N, H, W, 4, 64, 3, 1, _hip.ACT_RELU, 0.0,
+                                      stream()), "aesr_conv2d_fwd(vgg conv1_1)")
         acts.append(cur)
         nconv, h, w, cin = 1, H, W, 64
         partials, hws = [], []
@@ -249,6 +288,13 @@ class PNetLin(nn.Module):
                     check(lib.aesr_maxpool2_bwd(ptr(g), ptr(a), ptr(gtap), ptr(dpre), B, h, w, c, 1, stream()), "aesr_maxpool2_bwd")
                     g = dpre
             # now g = d/d(pre-activation of conv n); push it through conv n to its input
+            if n == 1 and FOLD_CONV1_1:
+                # data gradient of the folded layer with respect to the 1-channel slice: a 64 -> 1 convolution with the flipped filter
+                _, wflip = self._conv1_1_folded(pk, mul, None)
+                dx = torch.empty((B, H, W, 1), device=dev)
+                check(lib.aesr_conv2d_cout1_fwd(ptr(g), ptr(wflip), None, ptr(dx), B, H, W, 64, _hip.ACT_NONE, 0.0, stream()),
+                      "aesr_conv2d_cout1_fwd(vgg conv1_1 dgrad)")
+                return dx
             if n == 1:
                 ca, _ = self._affine(mul, 0.0)
                 d4 = torch.empty((B, H, W, 4), device=dev)
