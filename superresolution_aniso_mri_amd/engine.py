@@ -510,6 +510,17 @@ class SequentialRunner:
         return g, grads
 
     def _backward_steps(self, steps, saved, g, ngrad, need_input_grad, grads, G, ns, reduce_jobs):
+        mode = _side_mode()
+        use_side = _DEFERRED is not None and g.is_cuda and mode != "0"
+
+        def beside(dsts, *tensors):
+            """Context for a weight-gradient launch: the side stream when nothing reads its results before the reductions are
+            flushed -- slabs always; a parameter gradient only when it is ``p.grad`` itself (a temporary goes back to autograd,
+            which accumulates it on the main stream right after this pass)."""
+            if use_side and all(grads[p] is None for p in dsts if p is not None):
+                return _on_side_stream(*tensors)
+            return _same_stream()
+
         for k in range(len(steps) - 1, -1, -1):
             s = steps[k]
             if s.kind == "stemconv":
@@ -521,9 +532,10 @@ class SequentialRunner:
                 dw1 = self._grad_dst(s.mod.weight, grads)
                 db1 = self._grad_dst(s.mod.bias, grads) if s.mod.bias is not None else None
                 ws = _empty((lib.aesr_stemconv_workspace_floats(s.cout),), g)
-                check(lib.aesr_stemconv_wgrad(ptr(xin), ptr(g), ptr(s.stem.weight), ptr(s.stem.bias), ptr(s.mod.weight),
-                                              ptr(dws), ptr(dbs), ptr(dw1), ptr(db1), ptr(ws), ngrad, H, W, s.cs, s.cout,
-                                              s.stem_pad, stream()), "aesr_stemconv_wgrad")
+                with beside((s.stem.weight, s.stem.bias, s.mod.weight, s.mod.bias), xin, g, ws):
+                    check(lib.aesr_stemconv_wgrad(ptr(xin), ptr(g), ptr(s.stem.weight), ptr(s.stem.bias), ptr(s.mod.weight),
+                                                  ptr(dws), ptr(dbs), ptr(dw1), ptr(db1), ptr(ws), ngrad, H, W, s.cs, s.cout,
+                                                  s.stem_pad, stream()), "aesr_stemconv_wgrad")
                 g = None
                 break
             if s.kind == "conv":
@@ -544,25 +556,30 @@ class SequentialRunner:
                 if s.cin % 4 == 0 and s.cout % 4 == 0:
                     nws = lib.aesr_conv2d_wgrad_workspace_floats(N, H, W, s.cin, s.cout, s.ks, s.pad)
                     ws = _empty((nws,), g)
-                    _pb(("wgrad", s.cin, s.cout, s.ks, s.pad), 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
                     if s.s2d:        # its result is re-laid out right below: reduce at once
+                        _pb(("wgrad", s.cin, s.cout, s.ks, s.pad), 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
                         check(lib.aesr_conv2d_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout, s.ks,
                                                     s.pad, stream()), "aesr_conv2d_wgrad")
+                        _pe()
                     else:
                         # partial slabs now; the slabs of all layers of this pass are summed by ONE launch at the end of the pass
-                        check(lib.aesr_conv2d_wgrad_partial(ptr(xin), ptr(g), ptr(ws), N, H, W, s.cin, s.cout, s.ks, s.pad,
-                                                            int(s.in_up2), stream()), "aesr_conv2d_wgrad_partial")
+                        with beside((), xin, g, ws):
+                            _pb(("wgrad", s.cin, s.cout, s.ks, s.pad), 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
+                            check(lib.aesr_conv2d_wgrad_partial(ptr(xin), ptr(g), ptr(ws), N, H, W, s.cin, s.cout, s.ks, s.pad,
+                                                                int(s.in_up2), stream()), "aesr_conv2d_wgrad_partial")
+                            _pe()
                         reduce_jobs.append((_hip.WgradReduceJob(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
                                                                 N, H, W, s.cin, s.cout, s.ks, s.pad), ws, dw, db))
-                    _pe()
                 elif s.cin <= 4 and s.ks == 1 and db is not None:
                     ws = _empty((lib.aesr_small_wgrad_workspace_floats(s.cout * (s.cin + 1)),), g)
-                    check(lib.aesr_conv2d_smallcin_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout,
-                                                         s.pad, stream()), "aesr_conv2d_smallcin_wgrad")
+                    with beside((s.mod.weight, s.mod.bias), xin, g, ws):
+                        check(lib.aesr_conv2d_smallcin_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout,
+                                                             s.pad, stream()), "aesr_conv2d_smallcin_wgrad")
                 elif s.cout == 1 and s.ks == 3 and s.pad == 1 and db is not None:
                     ws = _empty((lib.aesr_conv2d_cout1_workspace_floats(s.cin),), g)
-                    check(lib.aesr_conv2d_cout1_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, stream()),
-                          "aesr_conv2d_cout1_wgrad")
+                    with beside((s.mod.weight, s.mod.bias), xin, g, ws):
+                        check(lib.aesr_conv2d_cout1_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, stream()),
+                              "aesr_conv2d_cout1_wgrad")
                 else:
                     raise NotImplementedError("no wgrad kernel for conv %d->%d k%d" % (s.cin, s.cout, s.ks))
                 if s.s2d:       # [Cout, (ky,kx,c)] -> [Cout, c, ky, kx]
@@ -646,6 +663,7 @@ class SequentialRunner:
                     sums = torch.empty((G, 2, C), device=dev, dtype=torch.float64)
                     check(lib.aesr_bn_bwd_reduce(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(partial), ptr(sums), N,
                                                  H, W, C, s.run_mode, G, nsa, stream()), "aesr_bn_bwd_reduce")
+                    join_side_stream()          # a collective may end a graph segment: no fork left open across it
                     self.sync_bn(sums)
                     check(lib.aesr_bn_bwd_apply(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(sums),
                                                 _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dpre),
@@ -656,9 +674,65 @@ class SequentialRunner:
 
 _DEFERRED = None      # list of pending weight-gradient reduction jobs while a deferred_wgrad_reductions() block is open
 
+# ---- weight gradients on a second stream --------------------------------------------------------------------------------
+# Inside a deferred_wgrad_reductions() block nothing reads a weight gradient before the block closes, so the weight-gradient
+# kernels of a layer need not sit between its data gradient and the next layer's: they are enqueued on a side stream that forks
+# after the layer's output gradient exists and joins where the slabs are summed (in a captured step: a fork/join in the graph).
+# A small shard leaves most of the 256 CUs idle under every kernel (profiles/r03_small_shards.txt: 2 triplets = 384 wave items
+# for 2 048 wave slots), so the ~25 % of the step spent in weight gradients then runs BESIDE the data-gradient chain; at full
+# batches both kinds fill the chip and the overlap is worth little (AESR_WGRAD_STREAM=0 switches it off, =1 forces it).
+_SIDE = {}            # device index -> torch.cuda.Stream
+_SIDE_HOLD = []       # tensors the side stream still reads: kept out of the allocator until the join
+_SIDE_OPEN = [False]
+
+
+def _side_mode():
+    return os.environ.get("AESR_WGRAD_STREAM", "auto")
+
+
+class _on_side_stream(object):
+    """``with _on_side_stream(g, xin, ...):`` -- launches inside go to the side stream, ordered after everything enqueued so far on
+    the current stream; the listed tensors stay referenced until join_side_stream()."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+
+    def __enter__(self):
+        cur = torch.cuda.current_stream()
+        side = _SIDE.get(cur.device.index)
+        if side is None:
+            side = _SIDE[cur.device.index] = torch.cuda.Stream(device=cur.device)
+        side.wait_stream(cur)
+        _SIDE_HOLD.extend(t for t in self.tensors if t is not None)
+        _SIDE_OPEN[0] = True
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+def join_side_stream():
+    """The current stream waits for the side stream's weight-gradient kernels (no-op when none are pending)."""
+    if _SIDE_OPEN[0]:
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(_SIDE[cur.device.index])
+        _SIDE_OPEN[0] = False
+        del _SIDE_HOLD[:]
+
+
+class _same_stream(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
 
 def flush_wgrad_reductions(jobs):
     """ONE aesr_conv2d_wgrad_reduce_many launch per 16 layers for the slab sets in ``jobs``."""
+    join_side_stream()
     for k in range(0, len(jobs), _hip.REDUCE_MAX_JOBS):
         part = jobs[k:k + _hip.REDUCE_MAX_JOBS]
         arr = (_hip.WgradReduceJob * len(part))(*[j[0] for j in part])

@@ -22,6 +22,7 @@ from .synthetic_vgg import VGG16_CFG, conv_indices, synthetic_vgg16_state
 SHIFT = (-.030, -.088, -.188)
 SCALE = (.458, .448, .450)
 TAP_AFTER_CONV = (2, 4, 7, 10, 13)
+_TRACE = None       # diagnostics (scripts/diag_vggfile_grad.py): a list collects (conv number, gradient of its pre-activation) per backward
 _SLICE_BOUNDS = (4, 9, 16, 23, 30)      # features[x] belongs to slice k if x < bound[k] (pretrained_networks.py:107-116)
 
 
@@ -261,6 +262,8 @@ class PNetLin(nn.Module):
         parr = (ctypes.c_void_p * len(partials))(*[p.data_ptr() for p in partials])
         check(lib.aesr_lpips_finalize(parr, _hip.int_array(hws), len(partials), ptr(d), B, stream()), "aesr_lpips_finalize")
         saved = (acts, taps, (B, H, W)) if save else None
+        if _TRACE is not None:
+            _TRACE.append(("acts", list(acts)))
         return d.reshape(B, 1, 1, 1), saved
 
     def _backward_hip(self, gd, saved, mul):
@@ -288,6 +291,8 @@ class PNetLin(nn.Module):
                     check(lib.aesr_maxpool2_bwd(ptr(g), ptr(a), ptr(gtap), ptr(dpre), B, h, w, c, 1, stream()), "aesr_maxpool2_bwd")
                     g = dpre
             # now g = d/d(pre-activation of conv n); push it through conv n to its input
+            if _TRACE is not None:
+                _TRACE.append((n, g.clone()))
             if n == 1 and FOLD_CONV1_1:
                 # data gradient of the folded layer with respect to the 1-channel slice: a 64 -> 1 convolution with the flipped filter
                 _, wflip = self._conv1_1_folded(pk, mul, None)

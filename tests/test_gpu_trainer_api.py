@@ -194,14 +194,19 @@ def test_vgg_weights_file_is_loaded(tmp_path):
     ref = lpips_oracle.perceptual_loss(a, br, sd, lin_w, normalize=True)
     ref.mean().backward()
     np.testing.assert_allclose(d.detach().cpu().numpy().ravel(), ref.detach().numpy().ravel(), rtol=2e-5)
-    # the gradient against the oracle evaluated in fp64: random (He) backbone weights put many ReLU inputs within rounding of zero, where
-    # the derivative jumps 0 <-> 1, so an fp32 evaluation -- the oracle's own included -- sits a few 1e-3 from the exact gradient;
-    # the HIP path must be no further from it than the CPU fp32 oracle (x3 + 2e-4)
+    # The gradient, judged against the oracle evaluated in fp64.  With these weights ONE max-pool window of relu2_2 (image 1, rows 20-21,
+    # columns 8-9, channel 35) holds two candidates closer than fp32 rounding, and the folded conv1_1 rounds them the other way round than
+    # fp64 does: the window's gradient goes to the other pixel, which moves a 14 x 16-pixel patch of the input gradient (140 of 5 760
+    # elements, 3.0e-3 of the gradient's norm); every stage before that window agrees to 1e-5 and every element outside the patch to
+    # 4e-6 (scripts/diag_vggfile_grad.py, profiles/r03_lpips_maxpool_flip.txt).  So: the bulk must agree to rounding, a flipped
+    # window or two may show in the norm.
     b64 = b.double().clone().requires_grad_(True)
     lpips_oracle.perceptual_loss(a.double(), b64, {k: v.double() for k, v in sd.items()}, [w.double() for w in lin_w], normalize=True).mean().backward()
-    rel64 = lambda g: float((g.double().cpu() - b64.grad).norm() / b64.grad.norm())
-    e_hip, e_cpu = rel64(bd.grad), rel64(br.grad)
-    assert e_hip <= 3.0 * e_cpu + 2e-4, (e_hip, e_cpu)
+    err = (bd.grad.double().cpu() - b64.grad).abs()
+    gmax = float(b64.grad.abs().max())
+    assert float(err.flatten().quantile(0.9)) < 2e-5 * gmax
+    assert float(err.norm() / b64.grad.norm()) < 1e-2
+    assert float((br.grad.double() - b64.grad).norm() / b64.grad.norm()) < 1e-4           # the fp32 CPU oracle itself: 1.8e-6
     d_syn = synth(a.cuda(), b.cuda(), normalize=True)
     assert float((d_syn.cpu() - d.detach().cpu()).abs().max()) > 1e-3 * float(d.detach().abs().max())
 
