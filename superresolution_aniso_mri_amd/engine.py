@@ -510,16 +510,18 @@ class SequentialRunner:
         return g, grads
 
     def _backward_steps(self, steps, saved, g, ngrad, need_input_grad, grads, G, ns, reduce_jobs):
-        mode = _side_mode()
-        use_side = _DEFERRED is not None and g.is_cuda and mode != "0"
+        use_side = _DEFERRED is not None and g.is_cuda and _side_wanted(g.shape[0] * g.shape[1] * g.shape[2])
+        if use_side:
+            issue_pending_wgrads(True)        # the previous pass's weight gradients: beside this pass's chain
 
-        def beside(dsts, *tensors):
-            """Context for a weight-gradient launch: the side stream when nothing reads its results before the reductions are
-            flushed -- slabs always; a parameter gradient only when it is ``p.grad`` itself (a temporary goes back to autograd,
-            which accumulates it on the main stream right after this pass)."""
+        def beside(dsts, tensors, launch):
+            """Run a weight-gradient launch now, or -- when nothing reads its results before the reductions are flushed: slabs always,
+            a parameter gradient only if it is ``p.grad`` itself (a temporary goes back to autograd, which accumulates it on the main
+            stream right after this pass) -- queue it for the side stream (see _PENDING)."""
             if use_side and all(grads[p] is None for p in dsts if p is not None):
-                return _on_side_stream(*tensors)
-            return _same_stream()
+                _PENDING.append((launch, tensors))
+            else:
+                launch()
 
         for k in range(len(steps) - 1, -1, -1):
             s = steps[k]
@@ -532,10 +534,12 @@ class SequentialRunner:
                 dw1 = self._grad_dst(s.mod.weight, grads)
                 db1 = self._grad_dst(s.mod.bias, grads) if s.mod.bias is not None else None
                 ws = _empty((lib.aesr_stemconv_workspace_floats(s.cout),), g)
-                with beside((s.stem.weight, s.stem.bias, s.mod.weight, s.mod.bias), xin, g, ws):
+
+                def launch(s=s, xin=xin, g=g, ws=ws, dws=dws, dbs=dbs, dw1=dw1, db1=db1, H=H, W=W):
                     check(lib.aesr_stemconv_wgrad(ptr(xin), ptr(g), ptr(s.stem.weight), ptr(s.stem.bias), ptr(s.mod.weight),
                                                   ptr(dws), ptr(dbs), ptr(dw1), ptr(db1), ptr(ws), ngrad, H, W, s.cs, s.cout,
                                                   s.stem_pad, stream()), "aesr_stemconv_wgrad")
+                beside((s.stem.weight, s.stem.bias, s.mod.weight, s.mod.bias), (xin, g, ws), launch)
                 g = None
                 break
             if s.kind == "conv":
@@ -563,23 +567,28 @@ class SequentialRunner:
                         _pe()
                     else:
                         # partial slabs now; the slabs of all layers of this pass are summed by ONE launch at the end of the pass
-                        with beside((), xin, g, ws):
+                        def launch(s=s, xin=xin, g=g, ws=ws, N=N, H=H, W=W, Ho=Ho, Wo=Wo):
                             _pb(("wgrad", s.cin, s.cout, s.ks, s.pad), 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
                             check(lib.aesr_conv2d_wgrad_partial(ptr(xin), ptr(g), ptr(ws), N, H, W, s.cin, s.cout, s.ks, s.pad,
                                                                 int(s.in_up2), stream()), "aesr_conv2d_wgrad_partial")
                             _pe()
+                        beside((), (xin, g, ws), launch)
                         reduce_jobs.append((_hip.WgradReduceJob(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
                                                                 N, H, W, s.cin, s.cout, s.ks, s.pad), ws, dw, db))
                 elif s.cin <= 4 and s.ks == 1 and db is not None:
                     ws = _empty((lib.aesr_small_wgrad_workspace_floats(s.cout * (s.cin + 1)),), g)
-                    with beside((s.mod.weight, s.mod.bias), xin, g, ws):
+
+                    def launch(s=s, xin=xin, g=g, ws=ws, dw=dw, db=db, N=N, H=H, W=W):
                         check(lib.aesr_conv2d_smallcin_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout,
                                                              s.pad, stream()), "aesr_conv2d_smallcin_wgrad")
+                    beside((s.mod.weight, s.mod.bias), (xin, g, ws), launch)
                 elif s.cout == 1 and s.ks == 3 and s.pad == 1 and db is not None:
                     ws = _empty((lib.aesr_conv2d_cout1_workspace_floats(s.cin),), g)
-                    with beside((s.mod.weight, s.mod.bias), xin, g, ws):
+
+                    def launch(s=s, xin=xin, g=g, ws=ws, dw=dw, db=db, N=N, H=H, W=W):
                         check(lib.aesr_conv2d_cout1_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, stream()),
                               "aesr_conv2d_cout1_wgrad")
+                    beside((s.mod.weight, s.mod.bias), (xin, g, ws), launch)
                 else:
                     raise NotImplementedError("no wgrad kernel for conv %d->%d k%d" % (s.cin, s.cout, s.ks))
                 if s.s2d:       # [Cout, (ky,kx,c)] -> [Cout, c, ky, kx]
@@ -663,7 +672,6 @@ class SequentialRunner:
                     sums = torch.empty((G, 2, C), device=dev, dtype=torch.float64)
                     check(lib.aesr_bn_bwd_reduce(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(partial), ptr(sums), N,
                                                  H, W, C, s.run_mode, G, nsa, stream()), "aesr_bn_bwd_reduce")
-                    join_side_stream()          # a collective may end a graph segment: no fork left open across it
                     self.sync_bn(sums)
                     check(lib.aesr_bn_bwd_apply(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(sums),
                                                 _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dpre),
@@ -676,58 +684,62 @@ _DEFERRED = None      # list of pending weight-gradient reduction jobs while a d
 
 # ---- weight gradients on a second stream --------------------------------------------------------------------------------
 # Inside a deferred_wgrad_reductions() block nothing reads a weight gradient before the block closes, so the weight-gradient
-# kernels of a layer need not sit between its data gradient and the next layer's: they are enqueued on a side stream that forks
-# after the layer's output gradient exists and joins where the slabs are summed (in a captured step: a fork/join in the graph).
-# A small shard leaves most of the 256 CUs idle under every kernel (profiles/r03_small_shards.txt: 2 triplets = 384 wave items
-# for 2 048 wave slots), so the ~25 % of the step spent in weight gradients then runs BESIDE the data-gradient chain; at full
-# batches both kinds fill the chip and the overlap is worth little (AESR_WGRAD_STREAM=0 switches it off, =1 forces it).
+# kernels need not sit between a layer's data gradient and the next layer's.  A small shard leaves most of the 256 CUs idle under
+# every kernel (2 triplets: 384 wave items for 2 048 wave slots), so they can run BESIDE the data-gradient chain.  A fork per
+# layer does not pay: in a replayed HIP graph every fork/join costs ~10 us of cross-stream signalling (12 forks: +0.13 ms per step
+# at every shard size, profiles/r03_wgrad_stream.txt).  Hence ONE fork per step: the launches of a pass are queued (_PENDING) and
+# issued on the side stream when the NEXT pass of the backward sweep starts (the decoder's weight gradients run beside the
+# encoder's data-gradient chain); what is still queued when the block closes (the encoder's) runs on the main stream, then the join.
+# MEASURED (same file): the one-fork form costs nothing but gains nothing either -- 0.883 -> 0.898 ms at 2 triplets, 2.305 -> 2.278 ms
+# at 12 -- the replayed graph does not run the two branches side by side on this runtime.  So it is OFF unless AESR_WGRAD_STREAM=1
+# (kept because an eager, host-launched step does overlap, and tests/test_gpu_step.py holds it to bit-equality).
 _SIDE = {}            # device index -> torch.cuda.Stream
 _SIDE_HOLD = []       # tensors the side stream still reads: kept out of the allocator until the join
 _SIDE_OPEN = [False]
+_PENDING = []         # (launch closure, tensors it reads) queued by SequentialRunner._backward_steps
 
 
-def _side_mode():
-    return os.environ.get("AESR_WGRAD_STREAM", "auto")
+def _side_wanted(n_pixels):
+    mode = os.environ.get("AESR_WGRAD_STREAM", "auto")
+    if mode in ("0", "1"):
+        return mode == "1"
+    return n_pixels <= SIDE_STREAM_MAX_PIXELS
 
 
-class _on_side_stream(object):
-    """``with _on_side_stream(g, xin, ...):`` -- launches inside go to the side stream, ordered after everything enqueued so far on
-    the current stream; the listed tensors stay referenced until join_side_stream()."""
+SIDE_STREAM_MAX_PIXELS = 0       # gradient pixels (images x H x W of the pass output) up to which the side stream is used by default: none
 
-    def __init__(self, *tensors):
-        self.tensors = tensors
 
-    def __enter__(self):
-        cur = torch.cuda.current_stream()
-        side = _SIDE.get(cur.device.index)
-        if side is None:
-            side = _SIDE[cur.device.index] = torch.cuda.Stream(device=cur.device)
-        side.wait_stream(cur)
-        _SIDE_HOLD.extend(t for t in self.tensors if t is not None)
-        _SIDE_OPEN[0] = True
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        return self.ctx.__exit__(*exc)
+def issue_pending_wgrads(beside):
+    """Issue the queued weight-gradient launches: on the side stream (ordered after everything enqueued so far on the current
+    stream) when ``beside``, else on the current stream."""
+    if not _PENDING:
+        return
+    jobs = list(_PENDING)
+    del _PENDING[:]
+    if not beside:
+        for launch, _ in jobs:
+            launch()
+        return
+    cur = torch.cuda.current_stream()
+    side = _SIDE.get(cur.device.index)
+    if side is None:
+        side = _SIDE[cur.device.index] = torch.cuda.Stream(device=cur.device)
+    side.wait_stream(cur)
+    _SIDE_OPEN[0] = True
+    with torch.cuda.stream(side):
+        for launch, tensors in jobs:
+            _SIDE_HOLD.extend(t for t in tensors if t is not None)
+            launch()
 
 
 def join_side_stream():
-    """The current stream waits for the side stream's weight-gradient kernels (no-op when none are pending)."""
+    """Queued launches run now (main stream); the current stream then waits for the side stream (no-op when nothing is pending)."""
+    issue_pending_wgrads(False)
     if _SIDE_OPEN[0]:
         cur = torch.cuda.current_stream()
         cur.wait_stream(_SIDE[cur.device.index])
         _SIDE_OPEN[0] = False
         del _SIDE_HOLD[:]
-
-
-class _same_stream(object):
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        return False
 
 
 def flush_wgrad_reductions(jobs):
