@@ -692,7 +692,7 @@ _DEFERRED = None      # list of pending weight-gradient reduction jobs while a d
 # encoder's data-gradient chain); what is still queued when the block closes (the encoder's) runs on the main stream, then the join.
 # MEASURED (same file): the one-fork form costs nothing but gains nothing either -- 0.883 -> 0.898 ms at 2 triplets, 2.305 -> 2.278 ms
 # at 12 -- the replayed graph does not run the two branches side by side on this runtime.  So it is OFF unless AESR_WGRAD_STREAM=1
-# (kept because an eager, host-launched step does overlap, and tests/test_gpu_step.py holds it to bit-equality).
+# (a measured knob for other runtimes / driver versions; tests/test_gpu_step.py holds it to bit-equality).
 _SIDE = {}            # device index -> torch.cuda.Stream
 _SIDE_HOLD = []       # tensors the side stream still reads: kept out of the allocator until the join
 _SIDE_OPEN = [False]
