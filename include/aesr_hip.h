@@ -306,6 +306,18 @@ int aesr_conv2d_wino_fwd(const float* in, const float* upacked, const float* bia
                          int Cout, int act, float slope, void* stream);
 int aesr_conv2d_wino_dgrad(const float* dy, const float* upacked_t, const float* x_saved, float* dx, int N, int H, int W, int Cin,
                            int Cout, int mask_act, float slope, void* stream);
+/* The same two with a caller-owned workspace for the CHANNEL SPLIT of small layers with many K-side channels (a small shard of a
+ * data-parallel step; the deep VGG layers of lpips/pretrained_networks.py:107-116 at any batch): a layer with fewer work items than
+ * the chip has SIMDs streams its K side serially per item (512 channels = 32 chunks of ~3 us), so conv_wino_ring_f32 splits the
+ * chunks over up to 16 items per (block group, cout tile), each writing raw partial sums into its own output-shaped slab of the
+ * workspace, and wino_split_reduce_kernel adds the slabs in fixed order (+ bias, activation, derivative mask).
+ * aesr_conv2d_wino_workspace_floats: the floats the library wants for a layer (0: no split; transpose = 1 for the data gradient).
+ * A NULL or smaller workspace is legal: the layer then runs unsplit, exactly as through the functions above. */
+size_t aesr_conv2d_wino_workspace_floats(int N, int H, int W, int Cin, int Cout, int transpose);
+int aesr_conv2d_wino_fwd_ws(const float* in, const float* upacked, const float* bias, float* out, float* workspace, size_t workspace_floats,
+                            int N, int H, int W, int Cin, int Cout, int act, float slope, void* stream);
+int aesr_conv2d_wino_dgrad_ws(const float* dy, const float* upacked_t, const float* x_saved, float* dx, float* workspace, size_t workspace_floats,
+                              int N, int H, int W, int Cin, int Cout, int mask_act, float slope, void* stream);
 
 /* nearest-neighbour Upsample(x2) in front of a 3x3 convolution (Decoder: networks/acai_vanilla.py:92-96) folded into the Winograd
  * kernels: H, W are the convolution's (= the upsampled, even) size; `in_half` / `x_half` / `dx_half` are [N,H/2,W/2,C] tensors.  The

@@ -110,6 +110,9 @@ SIGNATURES = {
     "aesr_conv2d_wino_pack_many": (c_int, [ctypes.POINTER(PackJob), c_int, P]),
     "aesr_conv2d_wino_fwd": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),
     "aesr_conv2d_wino_dgrad": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),
+    "aesr_conv2d_wino_workspace_floats": (c_size_t, [c_int] * 6),
+    "aesr_conv2d_wino_fwd_ws": (c_int, [P, P, P, P, P, c_size_t] + [c_int] * 6 + [c_float, P]),
+    "aesr_conv2d_wino_dgrad_ws": (c_int, [P, P, P, P, P, c_size_t] + [c_int] * 6 + [c_float, P]),
     "aesr_conv2d_wino_fwd_up2": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),
     "aesr_conv2d_wino_dgrad_sum2": (c_int, [P, P, P] + [c_int] * 5 + [P]),
     "aesr_conv2d_wgrad_up2_supported": (c_int, [c_int, c_int]),

@@ -424,7 +424,21 @@ int aesr_conv2d_wino_kernel(int N, int H, int W, int Cin, int Cout, int KS, int 
     a.CinP = p.CinP; a.CoutP = p.CoutP;
     a.plan_cost = p.cost;
     if (aesr_wino_res_ok(a)) return 2;
+    a.ws = (float*)(size_t)16;          // as called with the workspace aesr_conv2d_wino_workspace_floats asks for
+    a.ws_floats = ~(size_t)0;
     return aesr_wino_ring_takes(a) ? 3 : 1;
+}
+
+size_t aesr_conv2d_wino_workspace_floats(int N, int H, int W, int Cin, int Cout, int transpose) {
+    if (!aesr_conv2d_wino_supported(Cin, Cout, 3, 1, transpose) || N < 1 || H < 1 || W < 1) return 0;
+    const int kin = transpose ? Cout : Cin, nout = transpose ? Cin : Cout;
+    const WinoPlan p = plan_wino(N, H, W, kin, nout);
+    WinoArgs a = {};
+    a.N = N; a.H = H; a.W = W; a.Cin = kin; a.Cout = nout;
+    a.CinP = p.CinP; a.CoutP = p.CoutP;
+    a.plan_cost = p.cost;
+    if (aesr_wino_res_ok(a)) return 0;
+    return aesr_wino_ring_workspace_floats(a);
 }
 
 unsigned int aesr_conv2d_wino_ring_timeouts(void) {
@@ -463,7 +477,8 @@ int aesr_conv2d_wino_pack_many(const aesr_pack_job* jobs_host, int njobs, void* 
 }
 
 static int run_wino(const float* in, const float* upk, const float* bias, const float* ysave, float* out, int N, int H, int W,
-                    int Cin, int Cout, int act, int mask_act, float slope, hipStream_t st, int in_up2 = 0, int out_sum2 = 0) {
+                    int Cin, int Cout, int act, int mask_act, float slope, hipStream_t st, int in_up2 = 0, int out_sum2 = 0,
+                    float* ws = nullptr, size_t ws_floats = 0) {
     const WinoPlan p = plan_wino(N, H, W, Cin, Cout);
     WinoArgs a = {};
     a.in = in; a.upk = upk; a.bias = bias; a.ysave = ysave; a.out = out;
@@ -471,6 +486,8 @@ static int run_wino(const float* in, const float* upk, const float* bias, const 
     a.TI = p.TI; a.THt = p.THt; a.TWt = p.TWt; a.regs_y = a.regs_x = a.nitems = 0;
     a.plan_cost = p.cost;
     a.act = act; a.mask_act = mask_act; a.slope = slope; a.dbgbuf = nullptr; a.flags = 0; a.in_up2 = in_up2; a.out_sum2 = out_sum2;
+    a.ws = ws_floats ? ws : nullptr; a.ws_floats = ws ? ws_floats : 0;
+    a.ksplit = 1;
     return aesr_launch_conv_wino(a, st);
 }
 
@@ -487,6 +504,20 @@ int aesr_conv2d_wino_dgrad(const float* dy, const float* upacked_t, const float*
     AESR_CHECK_ARG(aesr_conv2d_wino_supported(Cin, Cout, 3, 1, 1), "aesr_conv2d_wino_dgrad: needs Cout %% 16 == 0 and Cin %% 32 == 0 (got %d -> %d)", Cin, Cout);
     // dx = conv(dy [N,H,W,Cout], flipped / transposed filter), padding 1 -> [N,H,W,Cin]
     return run_wino(dy, upacked_t, nullptr, x_saved, dx, N, H, W, Cout, Cin, ACT_NONE, mask_act, slope, (hipStream_t)stream);
+}
+
+int aesr_conv2d_wino_fwd_ws(const float* in, const float* upacked, const float* bias, float* out, float* workspace, size_t workspace_floats,
+                            int N, int H, int W, int Cin, int Cout, int act, float slope, void* stream) {
+    AESR_CHECK_ARG(in && upacked && out && N > 0 && H > 0 && W > 0, "aesr_conv2d_wino_fwd_ws: null pointer or empty shape");
+    AESR_CHECK_ARG(aesr_conv2d_wino_supported(Cin, Cout, 3, 1, 0), "aesr_conv2d_wino_fwd_ws: needs Cin %% 16 == 0 and Cout %% 32 == 0 (got %d -> %d)", Cin, Cout);
+    return run_wino(in, upacked, bias, nullptr, out, N, H, W, Cin, Cout, act, ACT_NONE, slope, (hipStream_t)stream, 0, 0, workspace, workspace_floats);
+}
+
+int aesr_conv2d_wino_dgrad_ws(const float* dy, const float* upacked_t, const float* x_saved, float* dx, float* workspace, size_t workspace_floats,
+                              int N, int H, int W, int Cin, int Cout, int mask_act, float slope, void* stream) {
+    AESR_CHECK_ARG(dy && upacked_t && dx && N > 0 && H > 0 && W > 0, "aesr_conv2d_wino_dgrad_ws: null pointer or empty shape");
+    AESR_CHECK_ARG(aesr_conv2d_wino_supported(Cin, Cout, 3, 1, 1), "aesr_conv2d_wino_dgrad_ws: needs Cout %% 16 == 0 and Cin %% 32 == 0 (got %d -> %d)", Cin, Cout);
+    return run_wino(dy, upacked_t, nullptr, x_saved, dx, N, H, W, Cout, Cin, ACT_NONE, mask_act, slope, (hipStream_t)stream, 0, 0, workspace, workspace_floats);
 }
 
 /* nearest Upsample(x2) in front of the convolution folded into the kernels (H, W = the convolution's = upsampled size, even) */

@@ -39,6 +39,12 @@ struct WinoArgs {
     int xcd_map;                 // resident-filter kernel: XCD-aware workgroup -> block map (set by its launcher)
     double plan_cost;            // cost estimate (cycles) of the first streamed kernel's plan for this layer: the ring kernel runs where its own is lower
     int nfull, tail_k;           // item list: groups of 8 blocks, then the last partial round in groups of tail_k <= 4 blocks
+    // ring kernel, channel split (small layers with many K-side channels): ksplit workgroup items per (block group, cout tile), each
+    // streaming kchunks 16-channel chunks into its own output-shaped slab of the workspace, split_bytes apart; summed by the split-reduce kernel
+    int ksplit, kchunks, split_bytes;
+    unsigned m_ksplit;           // ceil(2^32 / ksplit) (0: ksplit == 1)
+    float* ws;                   // caller's workspace for the slabs (nullptr: no channel split)
+    size_t ws_floats;
 };
 int aesr_launch_conv_wino(const WinoArgs& a, hipStream_t st);
 bool aesr_wino_res_ok(const WinoArgs& a);                        // few input channels: the filter stays resident, waves run on their own
@@ -46,6 +52,7 @@ int aesr_launch_conv_wino_res(const WinoArgs& a, hipStream_t st);
 int aesr_wino_ring_mode();                                       // AESR_WINO_RING: 0 never, 1 (default) where its cost estimate is lower, 2 always
 bool aesr_wino_ring_takes(const WinoArgs& a);                    // many K-side channels: filter chunks through an LDS ring, independent waves
 int aesr_launch_conv_wino_ring(const WinoArgs& a, hipStream_t st);
+size_t aesr_wino_ring_workspace_floats(const WinoArgs& a);      // floats of workspace the ring kernel's channel split wants for this layer (0: none)
 unsigned aesr_wino_ring_timeouts();                              // protocol watchdog of the ring kernel (0 unless a spin gave up)
 size_t aesr_wino_lds_bytes(int patch_pixels);
 

@@ -66,6 +66,9 @@ __device__ __forceinline__ int rg_lane() {
 __device__ __forceinline__ f32x4 rg_ld(__amdgpu_buffer_rsrc_t rs, int byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
 }
+// (the slab offset of a channel split is added to the per-lane offset, not passed as the instruction's scalar offset: with an SGPR
+// soffset -- even one holding 0 -- the tiles 12..15 of all-tail layers came out wrong in their odd channels on the box, cause not
+// found; scripts/diag_ring_tail.py reproduces it)
 __device__ __forceinline__ void rg_st(__amdgpu_buffer_rsrc_t rs, int byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), rs, byte_off, 0, 0);
 }
@@ -91,7 +94,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_ring_f32(WinoArgs a) {
     const int inimg = inH * inW * a.Cin * 4, inrow = inW * a.Cin * 4;                        // bytes of an input image / row
     const int ibytes = __builtin_amdgcn_readfirstlane(a.N * inimg);
     const int wbytes = __builtin_amdgcn_readfirstlane(16 * a.CinP * a.CoutP * 4);
-    const int obytes = __builtin_amdgcn_readfirstlane(a.N * outH * outW * a.Cout * 4), ybytes = __builtin_amdgcn_readfirstlane(a.N * a.H * a.W * a.Cout * 4);
+    // with a channel split (a.ksplit > 1) a.out is the workspace of partial outputs: one output-shaped slab per split
+    const int obytes = __builtin_amdgcn_readfirstlane(a.ksplit * a.split_bytes), ybytes = __builtin_amdgcn_readfirstlane(a.N * a.H * a.W * a.Cout * 4);
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, ibytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.upk, 0, wbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, obytes, 0x00020000);
@@ -137,11 +141,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino_ring_f32(WinoArgs a) {
 
 #define RG_DIV(x, m) ((m) ? (int)__umulhi((unsigned)(x), (m)) : (int)(x))          /* m == 0: divisor 1 */
     // item -> (block group, cout tile); this wave's block of the group -> (image group, block row, block column)
-    int in_n0 = 0, in_ty0 = 0, in_tx0 = 0, in_co0 = 0;
+    // channel split: item = ((block group, split), cout tile); split s streams chunks [s kchunks, (s + 1) kchunks) of the K side into its
+    // own output-shaped slab (no bias, no activation: the split-reduce kernel finishes the layer)
+    int in_n0 = 0, in_ty0 = 0, in_tx0 = 0, in_co0 = 0, in_c0 = 0, in_c1 = nchunks, in_so = 0;
     bool in_active = false;
     auto locate = [&](int it) {
-        const int bg = RG_DIV(it, a.m_ncot);
-        in_co0 = (it - bg * ncot) * 32;
+        const int bgs = RG_DIV(it, a.m_ncot);
+        in_co0 = (it - bgs * ncot) * 32;
+        const int bg = RG_DIV(bgs, a.m_ksplit);
+        const int sp = bgs - bg * a.ksplit;
+        in_c0 = sp * a.kchunks;
+        in_c1 = min(in_c0 + a.kchunks, nchunks);
+        in_so = sp * a.split_bytes;
         // full groups of 8 blocks first (whole rounds over the grid); the blocks of the last, partial round are dealt a.tail_k <= 4 per
         // group -- one wave per SIMD on EVERY CU instead of eight waves on a few -- and waves tail_k.. only stream the filter
         const int tj = bg - a.nfull;
@@ -208,18 +219,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino_ring_f32(WinoArgs a) {
         for (int k = 0; k < (a.flags & 15); ++k) __builtin_amdgcn_s_sleep(16);
     const int istep = G;
     locate(item);
-    fetch_u(in_co0, 0, 0);
-    if (in_active) fetch_patch(0);
+    fetch_u(in_co0, in_c0, 0);
+    if (in_active) fetch_patch(in_c0);
     signal(0, true);
 
     f32x4 acc[16][2];
     bool after_stores = false;                  // exactly 8 stores (and nothing else) were issued behind the current patch's DMAs
-    int cc = 0, slot = 0;
+    int cc = in_c0, slot = 0;
     unsigned target = (unsigned)NW;             // arrivals that complete the chunk in `slot`
     while (true) {
         const bool active = in_active;
-        const int cur_n0 = in_n0, cur_ty0 = in_ty0, cur_tx0 = in_tx0, cur_co0 = in_co0;
-        const bool last = cc + 1 == nchunks;
+        const int cur_n0 = in_n0, cur_ty0 = in_ty0, cur_tx0 = in_tx0, cur_co0 = in_co0, cur_c0 = in_c0, cur_so = in_so;
+        const bool last = cc + 1 == in_c1;
         const int nslot = slot == RG_SLOTS - 1 ? 0 : slot + 1;
         bool has_next = true;
         // request the next patch (next chunk, or chunk 0 of the next item) and this wave's part of the next U chunk; slot (q + 1) % 3
@@ -230,8 +241,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_ring_f32(WinoArgs a) {
                 has_next = item < a.nitems;
                 if (has_next) {
                     locate(item);
-                    fetch_u(in_co0, 0, nslot);
-                    if (in_active) fetch_patch(0);
+                    fetch_u(in_co0, in_c0, nslot);
+                    if (in_active) fetch_patch(in_c0);
                 }
             } else {
                 fetch_u(cur_co0, cc + 1, nslot);
@@ -305,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_ring_f32(WinoArgs a) {
             using XE = std::integral_constant<int, 16>;
             // ONE branch per chunk (first chunk of an item or not), the signal inside both arms: a second branch between the two runs
             // of positions made the register allocator rotate ~200 registers through moves at the join
-            if (cc == 0) {
+            if (cc == cur_c0) {
                 positions(std::true_type{}, X0{}, XS{});
                 signal(nslot, has_next);
                 positions(std::true_type{}, XS{}, XE{});
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_ring_f32(WinoArgs a) {
             ++cc;
             continue;
         }
-        cc = 0;
+        cc = in_c0;              // of the item located by fetch_next (unused after the last item)
         // ---- item finished: output transform Y = A^T M A, activation, (data gradient) derivative mask, store ----------
         if (active) {
             const int g = rg_lane() >> 4;
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_ring_f32(WinoArgs a) {
                     // adjoint of the nearest Upsample(x2) in front of this layer's forward: the 2x2 tile collapses to one pixel
                     const f32x4 s = aesr_sub4((P[0][0] + P[1][0]) + 2.f * (P[0][1] + P[1][1]), P[0][3] + P[1][3]);
                     const int obs = (okn && y0 < a.H && x0 < a.W) ? ((n * outH + (y0 >> 1)) * outW + (x0 >> 1)) * a.Cout * 4 : RG_OOB;
-                    rg_st(rs_out, obs + cob, s);
+                    rg_st(rs_out, obs + cob + cur_so, s);
                     continue;
                 }
 #pragma unroll
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_ring_f32(WinoArgs a) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] *= (ys[p][q][e] > 0.f ? 1.f : mslope);
                         }
-                        rg_st(rs_out, ob[p][q] + cob, o);
+                        rg_st(rs_out, ob[p][q] + cob + cur_so, o);
                     }
                 }
             }
@@ -426,8 +437,8 @@ static int ring_conflicts(int TI, int THt, int TWt, int P16, int IP16, int sa, i
 // the kernel's compile-time patch widths (pixel slots): the smallest that holds 2 TWt + 2 pixels
 static int ring_pwt(int TWt) { const int pw = 2 * TWt + 2; return pw <= 8 ? 8 : pw <= 10 ? 10 : pw <= 12 ? 12 : 16; }
 
-struct RingPlan { int TI, THt, TWt, PWT, imgP, sa, sm, sb, patch_fl, nfull, tail_k, ntail, conf; double cost; };
-static std::map<std::tuple<int, int, int, int, int>, RingPlan> g_ring_plans;
+struct RingPlan { int TI, THt, TWt, PWT, imgP, sa, sm, sb, patch_fl, nfull, tail_k, ntail, conf, ksplit; double cost; };
+static std::map<std::tuple<int, int, int, int, int, int, int>, RingPlan> g_ring_plans;
 static std::mutex g_ring_mu;
 
 static size_t ring_lds_bytes(int patch_fl, int CoutP) { return ((size_t)RG_SLOTS * RG_WFL + (size_t)8 * patch_fl + CoutP + 16) * sizeof(float); }
@@ -467,15 +478,23 @@ static void ring_items(RingPlan& p, long B, int ncot, int G) {
     }
 }
 
-static RingPlan plan_ring(const WinoArgs& a) {
+constexpr int RG_KSPLIT_MAX = 16;
+
+// smax: the largest channel split the caller's workspace allows (1: none)
+static RingPlan plan_ring(const WinoArgs& a, int smax) {
     std::lock_guard<std::mutex> lk(g_ring_mu);
-    const auto key = std::make_tuple(a.N, a.H, a.W, a.CinP, a.CoutP);
+    if (smax > RG_KSPLIT_MAX) smax = RG_KSPLIT_MAX;
+    if (smax < 1) smax = 1;
+    int fks = 0;
+    if (const char* e = getenv("AESR_RING_KSPLIT")) fks = atoi(e);                  // experiments / tests: force the channel split (where the workspace allows)
+    const auto key = std::make_tuple(a.N, a.H, a.W, a.CinP, a.CoutP, smax, fks);
     auto it = g_ring_plans.find(key);
     if (it != g_ring_plans.end()) return it->second;
     const int Ht = ceil_div(a.H, 2), Wt = ceil_div(a.W, 2), ncot = a.CoutP / 32, nch = a.CinP / 16;
     RingPlan best;
     best.cost = 1e300;
-    best.TI = 1; best.THt = 1; best.TWt = 1;
+    best.TI = 1; best.THt = 1; best.TWt = 1; best.ksplit = 1;
+    const double out_bytes = (double)a.N * a.H * a.W * a.Cout * 4.0;
     auto consider = [&](int TI, int THt, int TWt) {
         RingPlan p;
         p.TI = TI; p.THt = THt; p.TWt = TWt;
@@ -485,15 +504,26 @@ static RingPlan plan_ring(const WinoArgs& a) {
         ring_layout(p);
         if (ring_lds_bytes(p.patch_fl, a.CoutP) > (size_t)RG_LDS_MAX) return;
         const long B = (long)ceil_div(a.N, TI) * ceil_div(Ht, THt) * ceil_div(Wt, TWt);
-        ring_items(p, B, ncot, 256);
-        // chunks the busiest SIMD runs: two waves per full round, one (tail_k <= 4) or two in the tail round; a wave's chunk = 128 MFMAs
-        // + the transforms, LDS reads and DMA issue nothing overlaps when the wave is alone on its SIMD, about half of it when paired
-        const double items = (double)p.nfull * ncot, tail_items = (double)p.ntail * ncot;
-        const double rounds = items <= 4 * 256 ? (double)ceil_div((int)items, 256) : items / 256.0;
-        const double ovh = 700.0 + 45.0 * (nrows + 4) + p.conf;
-        const double tail = tail_items > 0 ? (double)ceil_div((int)tail_items, 256) * (p.tail_k <= 4 ? 4096.0 + ovh : 2.0 * 4096.0 + 1.2 * ovh) : 0.0;
-        p.cost = nch * (rounds * (2.0 * 4096.0 + 1.2 * ovh) + tail) + 3000.0 * (rounds + (tail > 0)) + 3000.0;
-        if (p.cost < best.cost) best = p;
+        int sforce = 0;                       // forced split: the largest valid one <= min(fks, smax)
+        for (int S = 1; fks > 0 && S <= smax && S <= fks; S *= 2)
+            if (S == 1 || (ceil_div(nch, S) >= 2 && ceil_div(nch, ceil_div(nch, S)) == S)) sforce = S;
+        for (int S = 1; S <= smax; S *= 2) {
+            const int kch = ceil_div(nch, S);
+            if (S > 1 && (kch < 2 || ceil_div(nch, kch) != S)) continue;        // at least two chunks per split, no empty split
+            if (sforce > 0 && S != sforce) continue;
+            ring_items(p, B, ncot * S, 256);
+            // chunks the busiest SIMD runs: two waves per full round, one (tail_k <= 4) or two in the tail round; a wave's chunk = 128 MFMAs
+            // + the transforms, LDS reads and DMA issue nothing overlaps when the wave is alone on its SIMD, about half of it when paired
+            const double items = (double)p.nfull * ncot * S, tail_items = (double)p.ntail * ncot * S;
+            const double rounds = items <= 4 * 256 ? (double)ceil_div((int)items, 256) : items / 256.0;
+            const double ovh = 700.0 + 45.0 * (nrows + 4) + p.conf;
+            const double tail = tail_items > 0 ? (double)ceil_div((int)tail_items, 256) * (p.tail_k <= 4 ? 4096.0 + ovh : 2.0 * 4096.0 + 1.2 * ovh) : 0.0;
+            p.cost = kch * (rounds * (2.0 * 4096.0 + 1.2 * ovh) + tail) + 3000.0 * (rounds + (tail > 0)) + 3000.0;
+            // the split-reduce launch: a kernel boundary + ramp (~3 us) and (S + 1) output-sized streams at ~2 KB per cycle
+            if (S > 1) p.cost += 7000.0 + (S + 1) * out_bytes / 2048.0;
+            p.ksplit = S;
+            if (p.cost < best.cost) best = p;
+        }
     };
     int fti = 0, fth = 0, ftw = 0;
     if (const char* e = getenv("AESR_RING_SHAPE")) (void)sscanf(e, "%d,%d,%d", &fti, &fth, &ftw);      // experiments: "TI,THt,TWt"
@@ -508,8 +538,8 @@ static RingPlan plan_ring(const WinoArgs& a) {
     }
     if (getenv("AESR_PLAN_DEBUG"))
         fprintf(stderr, "[aesr plan] ring N=%d %dx%d Cin=%d Cout=%d -> TI=%d THt=%d TWt=%d PWT=%d imgP=%d swizzle (%d,%d,%d) conflicts %d patch %d B; "
-                "%d full groups + %d tail groups of %d; cost %.0f\n", a.N, a.H, a.W, a.CinP, a.CoutP, best.TI, best.THt, best.TWt, best.PWT, best.imgP,
-                best.sa, best.sm, best.sb, best.conf, best.patch_fl * 4, best.nfull, best.ntail, best.tail_k, best.cost);
+                "channel split %d (of <= %d); %d full groups + %d tail groups of %d; cost %.0f\n", a.N, a.H, a.W, a.CinP, a.CoutP, best.TI, best.THt, best.TWt,
+                best.PWT, best.imgP, best.sa, best.sm, best.sb, best.conf, best.patch_fl * 4, best.ksplit, smax, best.nfull, best.ntail, best.tail_k, best.cost);
     g_ring_plans[key] = best;
     return best;
 }
@@ -523,11 +553,28 @@ int aesr_wino_ring_mode() {
 // the layer tables of profiles/r03_wino_layers.txt: 0.50-0.59 us per 1000 cycles for either); the ring kernel wins where 8 x 8-output
 // blocks tile the image well, the first kernel's big shared patches where they do not (81 x 81: 87 % against 94 % of the tile slots
 // used) and on layers too small for a round of ring items (VGG conv5)
+// The channel split the workspace in ``a`` allows: the unconstrained plan's if its slabs fit, else none
+static int ring_smax(const WinoArgs& a) {
+    if (!a.ws || a.out_sum2) return 1;
+    const size_t out_floats = (size_t)a.N * a.H * a.W * a.Cout;
+    const RingPlan p = plan_ring(a, RG_KSPLIT_MAX);
+    return (size_t)p.ksplit * out_floats <= a.ws_floats ? RG_KSPLIT_MAX : 1;
+}
+
 bool aesr_wino_ring_takes(const WinoArgs& a) {
     const int mode = aesr_wino_ring_mode();
     if (mode <= 0 || a.CinP != a.Cin) return false;
     if (mode >= 2 || a.plan_cost <= 0.0) return true;
-    return plan_ring(a).cost < a.plan_cost;
+    return plan_ring(a, ring_smax(a)).cost < a.plan_cost;
+}
+
+size_t aesr_wino_ring_workspace_floats(const WinoArgs& a) {
+    WinoArgs b = a;
+    b.ws = (float*)(size_t)16;            // "a workspace of any size": the plan's wish
+    b.ws_floats = ~(size_t)0;
+    if (!aesr_wino_ring_takes(b)) return 0;
+    const RingPlan p = plan_ring(b, RG_KSPLIT_MAX);
+    return p.ksplit > 1 ? (size_t)p.ksplit * a.N * a.H * a.W * a.Cout : 0;
 }
 
 unsigned aesr_wino_ring_timeouts() {
@@ -555,9 +602,35 @@ static int ring_launch_one(const WinoArgs& a, int grid, size_t shmem, hipStream_
 }
 
 // called by aesr_launch_conv_wino (which has validated the arguments) for the layers the resident-filter kernel does not take
+// out = act(sum of the S slabs + bias) (x the derivative mask of the data gradient): finishes a channel-split layer
+__global__ __launch_bounds__(256) void wino_split_reduce_kernel(const float* __restrict__ part, int S, size_t n4, size_t stride4,
+                                                                const float* __restrict__ bias, int Cout4, const float* __restrict__ ysave,
+                                                                float* __restrict__ out, int act, float slope, int mask_act) {
+    const f32x4* p4 = (const f32x4*)part;
+    const float nslope = act == ACT_LRELU ? slope : (act == ACT_RELU ? 0.f : 1.f);
+    const float mslope = mask_act == ACT_LRELU ? slope : (mask_act == ACT_RELU ? 0.f : 1.f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 v = p4[i];
+        for (int s_ = 1; s_ < S; ++s_) v += p4[s_ * stride4 + i];          // fixed order: deterministic
+        if (bias) v += ((const f32x4*)bias)[i % Cout4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * nslope);
+        if (act == ACT_SIGMOID) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + expf(-v[e]));
+        }
+        if (ysave) {
+            const f32x4 y = ((const f32x4*)ysave)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= (y[e] > 0.f ? 1.f : mslope);
+        }
+        ((f32x4*)out)[i] = v;
+    }
+}
+
 int aesr_launch_conv_wino_ring(const WinoArgs& a_in, hipStream_t st) {
     WinoArgs a = a_in;
-    const RingPlan p = plan_ring(a);
+    const RingPlan p = plan_ring(a, ring_smax(a));
     a.TI = p.TI; a.THt = p.THt; a.TWt = p.TWt; a.nw = 8;
     a.rowP = p.PWT * 16 + 4; a.imgP = p.imgP; a.sw_a = p.sa; a.sw_m = p.sm; a.sw_b = p.sb; a.patch_fl = p.patch_fl;
     const int Ht = ceil_div(a.H, 2), Wt = ceil_div(a.W, 2), ncot = a.CoutP / 32;
@@ -566,10 +639,25 @@ int aesr_launch_conv_wino_ring(const WinoArgs& a_in, hipStream_t st) {
     a.bpi = a.regs_y * a.regs_x;
     a.nblk = ceil_div(a.N, a.TI) * a.bpi;
     a.nfull = p.nfull; a.tail_k = p.tail_k;
-    a.nitems = (p.nfull + p.ntail) * ncot;
+    a.ksplit = p.ksplit;
+    a.kchunks = ceil_div(a.CinP / 16, p.ksplit);
+    const size_t out_floats = (size_t)a.N * (a.out_sum2 ? a.H / 2 : a.H) * (a.out_sum2 ? a.W / 2 : a.W) * a.Cout;
+    if (out_floats * 4 * (size_t)a.ksplit >= (size_t)RG_OOB) {
+        aesr_set_error("conv_wino_ring: %zu output bytes x %d channel splits exceed the kernel's 32-bit offsets", out_floats * 4, a.ksplit);
+        return AESR_ERR_UNSUPPORTED;
+    }
+    a.split_bytes = (int)(out_floats * 4);
+    a.nitems = (p.nfull + p.ntail) * ncot * a.ksplit;
     auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((((unsigned long long)1 << 32) + d - 1) / d); };
-    a.m_ncot = magic(ncot); a.m_bpi = magic(a.bpi); a.m_regs_x = magic(a.regs_x);
-    if (((unsigned long long)a.nitems + 4096) * (unsigned)(ncot + 1) >= ((unsigned long long)1 << 31) ||
+    a.m_ncot = magic(ncot); a.m_bpi = magic(a.bpi); a.m_regs_x = magic(a.regs_x); a.m_ksplit = magic(a.ksplit);
+    const float* fin_bias = a.bias;
+    const float* fin_mask = a.ysave;
+    const int fin_act = a.act;
+    float* const fin_out = a.out;
+    if (a.ksplit > 1) {                 // the kernel writes raw partial sums into the slabs; bias, activation and mask in the reduce
+        a.out = a.ws; a.bias = nullptr; a.ysave = nullptr; a.act = ACT_NONE;
+    }
+    if (((unsigned long long)a.nitems + 4096) * (unsigned)(ncot * a.ksplit + 1) >= ((unsigned long long)1 << 31) ||
         ((unsigned long long)a.nblk + 4096) * (unsigned)(a.bpi + a.regs_x) >= ((unsigned long long)1 << 31)) {
         aesr_set_error("conv_wino_ring: %d items exceed the exact range of the item decomposition", a.nitems);
         return AESR_ERR_UNSUPPORTED;
@@ -582,9 +670,15 @@ int aesr_launch_conv_wino_ring(const WinoArgs& a_in, hipStream_t st) {
     int grid = 256;                                     // persistent: one workgroup per CU
     if (const char* e = getenv("AESR_WINO_GRID")) grid = atoi(e);
     if (grid > a.nitems) grid = a.nitems;
-#define RG_CASE(pw) if (p.PWT == pw) return a.ysave ? ring_launch_one<pw, true>(a, grid, shmem, st) : ring_launch_one<pw, false>(a, grid, shmem, st);
+    int rc = AESR_ERR_UNSUPPORTED;
+#define RG_CASE(pw) if (p.PWT == pw) rc = a.ysave ? ring_launch_one<pw, true>(a, grid, shmem, st) : ring_launch_one<pw, false>(a, grid, shmem, st);
     RG_CASE(8) RG_CASE(10) RG_CASE(12) RG_CASE(16)
 #undef RG_CASE
-    aesr_set_error("conv_wino_ring: no instantiation for a patch of %d pixel slots", p.PWT);
-    return AESR_ERR_UNSUPPORTED;
+    if (rc == AESR_ERR_UNSUPPORTED) aesr_set_error("conv_wino_ring: no instantiation for a patch of %d pixel slots", p.PWT);
+    if (rc != AESR_OK || a.ksplit == 1) return rc;
+    const size_t n4 = out_floats / 4;
+    hipLaunchKernelGGL(wino_split_reduce_kernel, dim3((unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048)), dim3(256), 0, st, a.ws, a.ksplit, n4, n4, fin_bias, a.Cout / 4, fin_mask,
+                       fin_out, fin_act, a.slope, a.mask_act);
+    AESR_LAUNCH_CHECK("wino_split_reduce");
+    return AESR_OK;
 }

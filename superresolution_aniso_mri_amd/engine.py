@@ -71,6 +71,13 @@ def wino_kind(n, h, w, cin, cout, transpose):
     return {2: "conv_wino_res_f32", 3: "conv_wino_ring_f32"}.get(k, "conv_wino_f32")
 
 
+def wino_workspace(like, n, h, w, cin, cout, transpose):
+    """(workspace tensor or None, its floats) for aesr_conv2d_wino_fwd_ws / _dgrad_ws: the slabs of the ring kernel's channel split,
+    which the library asks for on small layers with many K-side channels (0 floats elsewhere)."""
+    nws = lib.aesr_conv2d_wino_workspace_floats(n, h, w, cin, cout, transpose)
+    return (torch.empty((nws,), device=like.device, dtype=torch.float32), nws) if nws else (None, 0)
+
+
 def wgrad_kind(cin, cout, ks, pad):
     """... of the weight-gradient kernel (conv_wgrad_wino.hip for 3x3 / padding 1 with both channel counts multiples of 32)."""
     return "conv_wgrad_wino_f32" if (ks == 3 and pad == 1 and lib.aesr_conv2d_wgrad_up2_supported(int(cin), int(cout))) else "conv_wgrad_f32"
@@ -401,8 +408,9 @@ class SequentialRunner:
                                                     s.slope, stream()), "aesr_conv2d_cout1_fwd")
                 elif s.wino_fwd:
                     _pb(("wino", N, Ho, Wo, s.cin, s.cout, 0), 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
-                    check(lib.aesr_conv2d_wino_fwd(ptr(cur), ptr(s.packed_w), ptr(bias), ptr(out), N, H, W, s.cin, s.cout, act_k,
-                                                   s.slope, stream()), "aesr_conv2d_wino_fwd")
+                    ws, nws = wino_workspace(cur, N, H, W, s.cin, s.cout, 0)
+                    check(lib.aesr_conv2d_wino_fwd_ws(ptr(cur), ptr(s.packed_w), ptr(bias), ptr(out), ptr(ws), nws, N, H, W, s.cin, s.cout,
+                                                      act_k, s.slope, stream()), "aesr_conv2d_wino_fwd_ws")
                     _pe()
                 elif s.mfma_fwd:
                     _pb("conv_igemm_f32", 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
@@ -615,8 +623,9 @@ class SequentialRunner:
                                                          s.pad, 0, None, stream()), "aesr_conv2d_smallcin_dgrad")
                 elif s.wino_dgrad:
                     _pb(("wino", N, H, W, s.cin, s.cout, 1), 2.0 * N * H * W * s.cin * 9 * s.cout)
-                    check(lib.aesr_conv2d_wino_dgrad(ptr(g), ptr(s.packed_wt), ptr(mask), ptr(dx), N, H, W, s.cin, s.cout, mask_act,
-                                                     mslope, stream()), "aesr_conv2d_wino_dgrad")
+                    ws, nws = wino_workspace(g, N, H, W, s.cin, s.cout, 1)
+                    check(lib.aesr_conv2d_wino_dgrad_ws(ptr(g), ptr(s.packed_wt), ptr(mask), ptr(dx), ptr(ws), nws, N, H, W, s.cin, s.cout,
+                                                        mask_act, mslope, stream()), "aesr_conv2d_wino_dgrad_ws")
                     _pe()
                 elif s.cout % 4 == 0:
                     _pb("conv_igemm_f32", 2.0 * N * H * W * s.cin * s.ks * s.ks * s.cout)

@@ -239,8 +239,9 @@ class PNetLin(nn.Module):
             out = torch.empty((N, h, w, v), device=x.device)
             if pk["fwd_wino"][nconv]:
                 engine._pb(("wino", N, h, w, cin, v, 0), 2.0 * N * h * w * v * 9 * cin)
-                check(lib.aesr_conv2d_wino_fwd(ptr(cur), ptr(pk["fwd"][nconv]), ptr(c.bias), ptr(out), N, h, w, cin, v, _hip.ACT_RELU,
-                                               0.0, stream()), "aesr_conv2d_wino_fwd(vgg)")
+                ws, nws = engine.wino_workspace(cur, N, h, w, cin, v, 0)
+                check(lib.aesr_conv2d_wino_fwd_ws(ptr(cur), ptr(pk["fwd"][nconv]), ptr(c.bias), ptr(out), ptr(ws), nws, N, h, w, cin, v,
+                                                  _hip.ACT_RELU, 0.0, stream()), "aesr_conv2d_wino_fwd_ws(vgg)")
                 engine._pe()
             else:
                 nws = lib.aesr_conv2d_workspace_floats(N, h, w, cin, v, 3, 1)      # > 0: the small deep layers (conv4/5) get K-split
@@ -315,9 +316,10 @@ class PNetLin(nn.Module):
             dxs = torch.empty((B, h, w, cv.in_channels), device=dev)
             if pk["bwd_wino"][n - 1]:
                 engine._pb(("wino", B, h, w, cv.in_channels, cv.out_channels, 1), 2.0 * B * h * w * cv.in_channels * 9 * cv.out_channels)
-                check(lib.aesr_conv2d_wino_dgrad(ptr(g), ptr(pk["bwd"][n - 1]), ptr(mask), ptr(dxs), B, h, w, cv.in_channels,
-                                                 cv.out_channels, _hip.ACT_RELU if mask is not None else 0, 0.0, stream()),
-                      "aesr_conv2d_wino_dgrad(vgg)")
+                wsd, nwsd = engine.wino_workspace(g, B, h, w, cv.in_channels, cv.out_channels, 1)
+                check(lib.aesr_conv2d_wino_dgrad_ws(ptr(g), ptr(pk["bwd"][n - 1]), ptr(mask), ptr(dxs), ptr(wsd), nwsd, B, h, w,
+                                                    cv.in_channels, cv.out_channels, _hip.ACT_RELU if mask is not None else 0, 0.0, stream()),
+                      "aesr_conv2d_wino_dgrad_ws(vgg)")
                 engine._pe()
             else:
                 nws = lib.aesr_conv2d_dgrad_workspace_floats(B, h, w, cv.in_channels, cv.out_channels, 3, 1)

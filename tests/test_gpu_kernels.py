@@ -571,6 +571,72 @@ def test_conv_wino_dgrad(hip, case, mask_act, streamed_kernel):
     assert rel_l2(nchw(dx), ref) < 1e-5
 
 
+KSPLIT_CASES = [
+    # N, H, W, Cin, Cout, forced split
+    (2, 10, 10, 512, 64, 8),      # VGG conv5 of a small shard: 32 chunks in 8 splits of 4
+    (3, 20, 12, 256, 96, 4),
+    (1, 7, 9, 96, 32, 4),         # 6 chunks: 4 splits would leave one empty -> the launcher settles for 2
+    (4, 40, 40, 128, 64, 2),
+    (1, 5, 3, 64, 32, 2),
+]
+
+
+@pytest.mark.parametrize("case", KSPLIT_CASES)
+def test_conv_wino_channel_split(hip, case, monkeypatch):
+    """conv_wino_ring_f32 with its K side split over several work items + wino_split_reduce_kernel (aesr_conv2d_wino_fwd_ws / _dgrad_ws):
+    forward with bias and LeakyReLU, data gradient with the ReLU mask, against fp64 (1e-5) and against the unsplit launch of the same
+    kernel (2e-6: another summation order over the channels); a workspace that is too small means an unsplit launch, not an error."""
+    N, H, W, Cin, Cout, S = case
+    L = hip.lib
+    monkeypatch.setenv("AESR_WINO_RING", "2")
+    monkeypatch.setenv("AESR_RING_KSPLIT", str(S))
+    g = torch.Generator().manual_seed(11 + hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    nws = L.aesr_conv2d_wino_workspace_floats(N, H, W, Cin, Cout, 0)
+    assert nws >= 2 * N * H * W * Cout and nws % (N * H * W * Cout) == 0 and nws // (N * H * W * Cout) <= S
+    ws = torch.full((nws,), float("nan"), device="cuda")
+    xd, up = D(nhwc(x)), D(_pack_wino(hip, w.cuda(), 0))
+    out, out1, out2 = (torch.full((N, H, W, Cout), float("nan"), device="cuda") for _ in range(3))
+    hip.check(L.aesr_conv2d_wino_fwd_ws(hip.ptr(xd), hip.ptr(up), hip.ptr(b.cuda()), hip.ptr(out), hip.ptr(ws), nws, N, H, W, Cin, Cout, 1, 0.01,
+                                        hip.stream()), "wino_fwd_ws")
+    hip.check(L.aesr_conv2d_wino_fwd_ws(hip.ptr(xd), hip.ptr(up), hip.ptr(b.cuda()), hip.ptr(out1), None, 0, N, H, W, Cin, Cout, 1, 0.01,
+                                        hip.stream()), "wino_fwd_ws(no workspace)")
+    hip.check(L.aesr_conv2d_wino_fwd_ws(hip.ptr(xd), hip.ptr(up), hip.ptr(b.cuda()), hip.ptr(out2), hip.ptr(ws), N * H * W * Cout, N, H, W, Cin, Cout,
+                                        1, 0.01, hip.stream()), "wino_fwd_ws(small workspace)")
+    torch.cuda.synchronize()
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.01)
+    assert rel_l2(nchw(out), ref) < 1e-5 and rel_l2(nchw(out1), ref) < 1e-5
+    assert rel_l2(out, out1) < 2e-6 and not torch.equal(out, out1)          # really another summation order
+    assert torch.equal(out1, out2)
+    # data gradient (roles of the channel counts swapped), ReLU mask
+    dy = torch.randn(N, Cin, H, W, generator=g)
+    wt = torch.randn(Cin, Cout, 3, 3, generator=g) / np.sqrt(Cin * 9)      # a layer Cout -> Cin: K side of its data gradient = Cin channels
+    xs = torch.randn(N, Cout, H, W, generator=g)
+    nwd = L.aesr_conv2d_wino_workspace_floats(N, H, W, Cout, Cin, 1)
+    assert nwd >= 2 * N * H * W * Cout
+    wsd = torch.full((nwd,), float("nan"), device="cuda")
+    dx = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    hip.check(L.aesr_conv2d_wino_dgrad_ws(hip.ptr(D(nhwc(dy))), hip.ptr(D(_pack_wino(hip, wt.cuda(), 1))), hip.ptr(D(nhwc(xs))), hip.ptr(dx), hip.ptr(wsd),
+                                          nwd, N, H, W, Cout, Cin, 2, 0.0, hip.stream()), "wino_dgrad_ws")
+    torch.cuda.synchronize()
+    refd = torch.nn.grad.conv2d_input((N, Cout, H, W), wt.double(), dy.double(), padding=1) * (xs > 0).double()
+    assert rel_l2(nchw(dx), refd) < 1e-5
+    assert L.aesr_conv2d_wino_ring_timeouts() == 0
+
+
+def test_conv_wino_channel_split_is_planned_for_small_deep_layers(hip):
+    """Without any forcing: the launcher asks for slabs on the deep VGG layers of a small shard (few blocks x 512 channels) and on none of
+    the layers of a full batch that fills the chip."""
+    L = hip.lib
+    assert L.aesr_conv2d_wino_workspace_floats(4, 10, 10, 512, 512, 0) > 0
+    assert L.aesr_conv2d_wino_workspace_floats(2, 20, 20, 512, 512, 1) > 0
+    assert L.aesr_conv2d_wino_workspace_floats(24, 160, 160, 64, 64, 0) == 0
+    assert L.aesr_conv2d_wino_workspace_floats(36, 40, 40, 128, 128, 0) == 0
+    assert L.aesr_conv2d_wino_workspace_floats(36, 160, 160, 32, 32, 0) == 0       # resident-filter kernel
+
+
 def test_conv_wino_ring_kernel_selection_and_watchdog(hip, monkeypatch):
     """Layers with many K-side channels run on the ring kernel (kernel id 3); its arrival-counter watchdog never fired in this process;
     forced block shapes (every compile-time patch width of the kernel) give the same results as the planned ones."""
