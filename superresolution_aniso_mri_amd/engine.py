@@ -518,19 +518,6 @@ class SequentialRunner:
         return g, grads
 
     def _backward_steps(self, steps, saved, g, ngrad, need_input_grad, grads, G, ns, reduce_jobs):
-        use_side = _DEFERRED is not None and g.is_cuda and _side_wanted(g.shape[0] * g.shape[1] * g.shape[2])
-        if use_side:
-            issue_pending_wgrads(True)        # the previous pass's weight gradients: beside this pass's chain
-
-        def beside(dsts, tensors, launch):
-            """Run a weight-gradient launch now, or -- when nothing reads its results before the reductions are flushed: slabs always,
-            a parameter gradient only if it is ``p.grad`` itself (a temporary goes back to autograd, which accumulates it on the main
-            stream right after this pass) -- queue it for the side stream (see _PENDING)."""
-            if use_side and all(grads[p] is None for p in dsts if p is not None):
-                _PENDING.append((launch, tensors))
-            else:
-                launch()
-
         for k in range(len(steps) - 1, -1, -1):
             s = steps[k]
             if s.kind == "stemconv":
@@ -542,12 +529,9 @@ class SequentialRunner:
                 dw1 = self._grad_dst(s.mod.weight, grads)
                 db1 = self._grad_dst(s.mod.bias, grads) if s.mod.bias is not None else None
                 ws = _empty((lib.aesr_stemconv_workspace_floats(s.cout),), g)
-
-                def launch(s=s, xin=xin, g=g, ws=ws, dws=dws, dbs=dbs, dw1=dw1, db1=db1, H=H, W=W):
-                    check(lib.aesr_stemconv_wgrad(ptr(xin), ptr(g), ptr(s.stem.weight), ptr(s.stem.bias), ptr(s.mod.weight),
-                                                  ptr(dws), ptr(dbs), ptr(dw1), ptr(db1), ptr(ws), ngrad, H, W, s.cs, s.cout,
-                                                  s.stem_pad, stream()), "aesr_stemconv_wgrad")
-                beside((s.stem.weight, s.stem.bias, s.mod.weight, s.mod.bias), (xin, g, ws), launch)
+                check(lib.aesr_stemconv_wgrad(ptr(xin), ptr(g), ptr(s.stem.weight), ptr(s.stem.bias), ptr(s.mod.weight),
+                                              ptr(dws), ptr(dbs), ptr(dw1), ptr(db1), ptr(ws), ngrad, H, W, s.cs, s.cout,
+                                              s.stem_pad, stream()), "aesr_stemconv_wgrad")
                 g = None
                 break
             if s.kind == "conv":
@@ -575,28 +559,20 @@ class SequentialRunner:
                         _pe()
                     else:
                         # partial slabs now; the slabs of all layers of this pass are summed by ONE launch at the end of the pass
-                        def launch(s=s, xin=xin, g=g, ws=ws, N=N, H=H, W=W, Ho=Ho, Wo=Wo):
-                            _pb(("wgrad", s.cin, s.cout, s.ks, s.pad), 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
-                            check(lib.aesr_conv2d_wgrad_partial(ptr(xin), ptr(g), ptr(ws), N, H, W, s.cin, s.cout, s.ks, s.pad,
-                                                                int(s.in_up2), stream()), "aesr_conv2d_wgrad_partial")
-                            _pe()
-                        beside((), (xin, g, ws), launch)
+                        _pb(("wgrad", s.cin, s.cout, s.ks, s.pad), 2.0 * N * Ho * Wo * s.cout * s.ks * s.ks * s.cin)
+                        check(lib.aesr_conv2d_wgrad_partial(ptr(xin), ptr(g), ptr(ws), N, H, W, s.cin, s.cout, s.ks, s.pad,
+                                                            int(s.in_up2), stream()), "aesr_conv2d_wgrad_partial")
+                        _pe()
                         reduce_jobs.append((_hip.WgradReduceJob(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
                                                                 N, H, W, s.cin, s.cout, s.ks, s.pad), ws, dw, db))
                 elif s.cin <= 4 and s.ks == 1 and db is not None:
                     ws = _empty((lib.aesr_small_wgrad_workspace_floats(s.cout * (s.cin + 1)),), g)
-
-                    def launch(s=s, xin=xin, g=g, ws=ws, dw=dw, db=db, N=N, H=H, W=W):
-                        check(lib.aesr_conv2d_smallcin_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout,
-                                                             s.pad, stream()), "aesr_conv2d_smallcin_wgrad")
-                    beside((s.mod.weight, s.mod.bias), (xin, g, ws), launch)
+                    check(lib.aesr_conv2d_smallcin_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout,
+                                                         s.pad, stream()), "aesr_conv2d_smallcin_wgrad")
                 elif s.cout == 1 and s.ks == 3 and s.pad == 1 and db is not None:
                     ws = _empty((lib.aesr_conv2d_cout1_workspace_floats(s.cin),), g)
-
-                    def launch(s=s, xin=xin, g=g, ws=ws, dw=dw, db=db, N=N, H=H, W=W):
-                        check(lib.aesr_conv2d_cout1_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, stream()),
-                              "aesr_conv2d_cout1_wgrad")
-                    beside((s.mod.weight, s.mod.bias), (xin, g, ws), launch)
+                    check(lib.aesr_conv2d_cout1_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, stream()),
+                          "aesr_conv2d_cout1_wgrad")
                 else:
                     raise NotImplementedError("no wgrad kernel for conv %d->%d k%d" % (s.cin, s.cout, s.ks))
                 if s.s2d:       # [Cout, (ky,kx,c)] -> [Cout, c, ky, kx]
@@ -691,69 +667,8 @@ class SequentialRunner:
 
 _DEFERRED = None      # list of pending weight-gradient reduction jobs while a deferred_wgrad_reductions() block is open
 
-# ---- weight gradients on a second stream --------------------------------------------------------------------------------
-# Inside a deferred_wgrad_reductions() block nothing reads a weight gradient before the block closes, so the weight-gradient
-# kernels need not sit between a layer's data gradient and the next layer's.  A small shard leaves most of the 256 CUs idle under
-# every kernel (2 triplets: 384 wave items for 2 048 wave slots), so they can run BESIDE the data-gradient chain.  A fork per
-# layer does not pay: in a replayed HIP graph every fork/join costs ~10 us of cross-stream signalling (12 forks: +0.13 ms per step
-# at every shard size, profiles/r03_wgrad_stream.txt).  Hence ONE fork per step: the launches of a pass are queued (_PENDING) and
-# issued on the side stream when the NEXT pass of the backward sweep starts (the decoder's weight gradients run beside the
-# encoder's data-gradient chain); what is still queued when the block closes (the encoder's) runs on the main stream, then the join.
-# MEASURED (same file): the one-fork form costs nothing but gains nothing either -- 0.883 -> 0.898 ms at 2 triplets, 2.305 -> 2.278 ms
-# at 12 -- the replayed graph does not run the two branches side by side on this runtime.  So it is OFF unless AESR_WGRAD_STREAM=1
-# (a measured knob for other runtimes / driver versions; tests/test_gpu_step.py holds it to bit-equality).
-_SIDE = {}            # device index -> torch.cuda.Stream
-_SIDE_HOLD = []       # tensors the side stream still reads: kept out of the allocator until the join
-_SIDE_OPEN = [False]
-_PENDING = []         # (launch closure, tensors it reads) queued by SequentialRunner._backward_steps
-
-
-def _side_wanted(n_pixels):
-    mode = os.environ.get("AESR_WGRAD_STREAM", "auto")
-    if mode in ("0", "1"):
-        return mode == "1"
-    return n_pixels <= SIDE_STREAM_MAX_PIXELS
-
-
-SIDE_STREAM_MAX_PIXELS = 0       # gradient pixels (images x H x W of the pass output) up to which the side stream is used by default: none
-
-
-def issue_pending_wgrads(beside):
-    """Issue the queued weight-gradient launches: on the side stream (ordered after everything enqueued so far on the current
-    stream) when ``beside``, else on the current stream."""
-    if not _PENDING:
-        return
-    jobs = list(_PENDING)
-    del _PENDING[:]
-    if not beside:
-        for launch, _ in jobs:
-            launch()
-        return
-    cur = torch.cuda.current_stream()
-    side = _SIDE.get(cur.device.index)
-    if side is None:
-        side = _SIDE[cur.device.index] = torch.cuda.Stream(device=cur.device)
-    side.wait_stream(cur)
-    _SIDE_OPEN[0] = True
-    with torch.cuda.stream(side):
-        for launch, tensors in jobs:
-            _SIDE_HOLD.extend(t for t in tensors if t is not None)
-            launch()
-
-
-def join_side_stream():
-    """Queued launches run now (main stream); the current stream then waits for the side stream (no-op when nothing is pending)."""
-    issue_pending_wgrads(False)
-    if _SIDE_OPEN[0]:
-        cur = torch.cuda.current_stream()
-        cur.wait_stream(_SIDE[cur.device.index])
-        _SIDE_OPEN[0] = False
-        del _SIDE_HOLD[:]
-
-
 def flush_wgrad_reductions(jobs):
     """ONE aesr_conv2d_wgrad_reduce_many launch per 16 layers for the slab sets in ``jobs``."""
-    join_side_stream()
     for k in range(0, len(jobs), _hip.REDUCE_MAX_JOBS):
         part = jobs[k:k + _hip.REDUCE_MAX_JOBS]
         arr = (_hip.WgradReduceJob * len(part))(*[j[0] for j in part])

@@ -200,9 +200,6 @@ class DataParallelContext(object):
         "rccl"); with the gloo data backend (CPU tests, one-GPU rehearsals) they are staged through the host.  Host tensors always
         use gloo."""
         self.n_collectives += 1
-        if self.segments is not None and self.segments.capturing:
-            from . import engine
-            engine.join_side_stream()       # a cut ends a graph segment: no fork (weight gradients on the side stream) stays open across it
         if t.is_cuda and self.data_backend == "rccl":
             if self.segments is not None and self.segments.capturing:
                 self.segments.cut(lambda: self._rccl(t, op))      # eager enqueue between two graph segments, replayed on this tensor

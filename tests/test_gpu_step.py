@@ -180,28 +180,6 @@ def test_step_graph_replay_equals_eager():
     assert float(graphed.opt_ae.dev_state[0]) == 6.0
 
 
-def test_weight_gradients_on_the_side_stream_change_nothing(monkeypatch):
-    """engine._on_side_stream: the weight-gradient launches of a step fork onto a second stream and join before their slabs are
-    summed -- the same kernels on the same data, so parameters and logged losses after 6 steps (2 eager, 4 replayed from the captured
-    fork/join graph) are bit-identical to the single-stream step."""
-    rec = dict(np.load(os.path.join(GOLDEN, "step_k3_brain_lpips.npz")))
-    results = []
-    for mode in ("0", "1"):
-        monkeypatch.setenv("AESR_WGRAD_STREAM", mode)
-        tr = make_trainer("brain_lpips", rec)
-        tr.enable_step_graph(eager_steps=2)
-        for step in range(6):
-            k = step % 3
-            tr.train({"image": torch.from_numpy(rec["image_%d" % k]), "slice_between": torch.from_numpy(rec["between_%d" % k]),
-                      "alpha_from": torch.from_numpy(rec["alpha_from"]), "alpha_to": torch.from_numpy(rec["alpha_to"])},
-                     keep_predictions=False)
-        torch.cuda.synchronize()
-        results.append((tr.losses["loss_ae"].floats(), {k: v.clone() for k, v in tr.model.state_dict().items()}))
-    assert results[0][0] == results[1][0]
-    for k in results[0][1]:
-        assert torch.equal(results[0][1][k], results[1][1][k]), k
-
-
 @pytest.mark.parametrize("loss", ["mse", "perceptual"])
 def test_twenty_steps_track_the_oracle(loss):
     """20 consecutive training steps (lr 1e-4, distinct batches) on the HIP trainer and on the CPU oracle from the same start:
