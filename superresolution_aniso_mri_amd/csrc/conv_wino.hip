@@ -169,6 +169,7 @@ __global__ __launch_bounds__(WN_NT, 2) void conv_wino_f32(WinoArgs a) {
     // ---- prologue: chunk 0 of the first item into buffer 0 -----------------------------------------------------
     WN_COMPUTE_GOFF(l_item)
     WN_STAGE(l_item, 0, ldsP0, ldsW0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (explicit, as at the chunk barrier below)
     __syncthreads();
     // advance the load state to the chunk that will be staged during the first compute phase
     if (1 < nchunks) {
@@ -281,10 +282,11 @@ __global__ __launch_bounds__(WN_NT, 2) void conv_wino_f32(WinoArgs a) {
 #undef WN_V
         }
         WN_STAMP(0)
-        if (stamp) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            WN_STAMP(4)
-        }
+        // OUR wait, not the compiler's: the barrier below is what makes the other waves' DMAs (buffer_load ... lds) visible, which holds
+        // only if every wave has waited for its own before arriving (the compiler emits this wait today; conv_wgrad_wino once raced
+        // when it did not)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (stamp) { WN_STAMP(4) }
         __syncthreads();            // every wave is done with `buf`; the next chunk is complete in `buf ^ 1`
         WN_STAMP(1)
         buf ^= 1;

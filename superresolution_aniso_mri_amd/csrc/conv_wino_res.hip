@@ -136,6 +136,7 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
         locate(item);
         fetch(item, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // explicit: this wave's share of the filter DMAs has landed before it arrives
     __syncthreads();            // U and bias are in LDS (every wave waited for its own part); the only barrier of the kernel
 
     f32x4 acc[16][WR_NB];

@@ -109,6 +109,8 @@ class BaseTrainer(object):
         if t is None:
             t = batch_item["image"]
         self._log_count[eval_type] = int(t.shape[0])
+        seen = self.__dict__.setdefault("_log_seen", {})
+        seen[eval_type] = seen.get(eval_type, 0) + int(t.shape[0])      # triplets behind this rank's epoch means (reset_losses clears it)
 
     _capture_sink = None      # dict while a step is being captured into a HIP graph (see AEBaseTrainer._train_graphed)
 
@@ -125,6 +127,7 @@ class BaseTrainer(object):
         (self.losses_test if is_test else self.losses)[key].append(_scalar(value))
 
     def reset_losses(self):
+        self.__dict__["_log_seen"] = {}
         for d in (self.losses, self.losses_test):
             for k in list(d.keys()):
                 d[k] = LossLog()
@@ -149,7 +152,9 @@ class BaseTrainer(object):
         if dp is not None and dp.active and means:
             # data parallel: every rank logged the mean over ITS shard; model selection and the loss files must see the mean
             # over the global batch (= what the single-process run logs): sum_r n_r * mean_r / sum_r n_r, one all-reduce
-            n_local = float(self._log_count.get(eval_type, 0) or 0)
+            # weight = the triplets that went into this rank's means since reset_losses() (uneven shards, partial last batches).
+            # COLLECTIVE: under data parallel every rank must call this with the same keys (a rank-0-only caller would hang).
+            n_local = float(self.__dict__.get("_log_seen", {}).get(eval_type, 0) or self._log_count.get(eval_type, 0) or 0)
             means = dp.reduce_means(means, n_local)
         for key, mean_value in means.items():
             if self.args.get("log_tensorboard") and getattr(self, "tb_writer", None) is not None:

@@ -13,6 +13,9 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+DIRECT_CONTROL = os.environ.get("AESR_WINO") == "0" and os.environ.get("AESR_WGRAD_WINO") == "0"
+
+
 def rel_l2(a, b):
     a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
@@ -74,8 +77,13 @@ def test_three_train_steps(tag):
             assert rel_l2(trainer.train_predictions["slice_inbetween_mix"], rec["s_mix_0"]) < 1e-5
             assert rel_l2(trainer.train_predictions["reconstruction"], rec["out_0"]) < 1e-5
             assert rel_l2(trainer.train_predictions["z_mix"], rec["z_mix_0"]) < 1e-5
+            # first-step gradients: 2e-4 through the Winograd kernels (their rounding differs from the reference's direct convolution;
+            # LeakyReLU inputs within that rounding of zero flip their derivative), 1e-4 -- round 1's bound -- through the direct
+            # fp32 kernels (AESR_WINO=0 AESR_WGRAD_WINO=0: test_direct_kernels_hold_the_round1_bounds runs this test that way)
+            # (LPIPS as the RECONSTRUCTION loss: 1.2e-4 on the 8-element enc.0.bias even through the direct kernels)
+            gtol = (1.5e-4 if tag == "cardiac_percept" else 1e-4) if DIRECT_CONTROL else 2e-4
             for k, p in trainer.model.named_parameters():
-                assert rel_l2(p.grad, rec["grad0/" + k]) < 2e-4, k
+                assert rel_l2(p.grad, rec["grad0/" + k]) < gtol, k
     assert trainer.iters == int(rec["iters"]) == 4
     sd = trainer.model.state_dict()
     nbt = 3 if tag == "ae_plain" else 6          # BatchNorm calls per layer: plain ae = one train-mode pass per step, ae_combined = two
@@ -97,6 +105,19 @@ def test_three_train_steps(tag):
             # lr 1e-5 fixture pins momentum / unbiased-variance details at 2e-5)
             np.testing.assert_allclose(a, b, rtol=(1e-2 if tag == "cardiac_percept" else 2e-3) if lr > 1e-4 else 2e-5, atol=1e-2 * lr + 1e-7,
                                        err_msg=k)
+
+
+@pytest.mark.skipif(DIRECT_CONTROL, reason="this IS the control run")
+def test_direct_kernels_hold_the_round1_bounds():
+    """Control for the looser Winograd-path bounds: the same golden step fixtures through the exact-fp32 direct kernels (implicit GEMM
+    forward / data gradient, direct weight gradient) must still meet round 1's tighter gradient bound -- so a fixture or host-logic
+    change cannot hide behind kernel rounding.  (The library reads AESR_WGRAD_WINO once per process: a child process.)"""
+    import subprocess
+    import sys
+    env = dict(os.environ, AESR_WINO="0", AESR_WGRAD_WINO="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "three_train_steps", "-p", "no:cacheprovider"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
 
 
 def test_loss_annealing_under_the_step_graph():
