@@ -43,9 +43,13 @@ def main():
         out_i, out_w = torch.empty(N, H, W, Cout, device="cuda"), torch.full((N, H, W, Cout), float("nan"), device="cuda")
         dx_i, dx_w = torch.empty(N, H, W, Cin, device="cuda"), torch.full((N, H, W, Cin), float("nan"), device="cuda")
         f_i = lambda: hip.check(L.aesr_conv2d_fwd(hip.ptr(x), hip.ptr(pf), hip.ptr(b), hip.ptr(out_i), N, H, W, Cin, Cout, 3, 1, 1, 0.01, hip.stream()), "fwd")
-        f_w = lambda: hip.check(L.aesr_conv2d_wino_fwd(hip.ptr(x), hip.ptr(uf), hip.ptr(b), hip.ptr(out_w), N, H, W, Cin, Cout, 1, 0.01, hip.stream()), "wino_fwd")
+        # as the product calls it: with the workspace the library asks for (channel split of small / deep layers)
+        nwf, nwd = L.aesr_conv2d_wino_workspace_floats(N, H, W, Cin, Cout, 0), L.aesr_conv2d_wino_workspace_floats(N, H, W, Cin, Cout, 1)
+        wsf = torch.empty(nwf, device="cuda") if nwf else None
+        wsd = torch.empty(nwd, device="cuda") if nwd else None
+        f_w = lambda: hip.check(L.aesr_conv2d_wino_fwd_ws(hip.ptr(x), hip.ptr(uf), hip.ptr(b), hip.ptr(out_w), hip.ptr(wsf), nwf, N, H, W, Cin, Cout, 1, 0.01, hip.stream()), "wino_fwd")
         d_i = lambda: hip.check(L.aesr_conv2d_dgrad(hip.ptr(dy), hip.ptr(pb), hip.ptr(x), hip.ptr(dx_i), N, H, W, Cin, Cout, 3, 1, 1, 0.01, hip.stream()), "dgrad")
-        d_w = lambda: hip.check(L.aesr_conv2d_wino_dgrad(hip.ptr(dy), hip.ptr(ub), hip.ptr(x), hip.ptr(dx_w), N, H, W, Cin, Cout, 1, 0.01, hip.stream()), "wino_dgrad")
+        d_w = lambda: hip.check(L.aesr_conv2d_wino_dgrad_ws(hip.ptr(dy), hip.ptr(ub), hip.ptr(x), hip.ptr(dx_w), hip.ptr(wsd), nwd, N, H, W, Cin, Cout, 1, 0.01, hip.stream()), "wino_dgrad")
         f_i(); f_w(); d_i(); d_w()
         torch.cuda.synchronize()
         # fp64 reference on two images
