@@ -66,9 +66,12 @@ __device__ __forceinline__ int rg_lane() {
 __device__ __forceinline__ f32x4 rg_ld(__amdgpu_buffer_rsrc_t rs, int byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
 }
-// (the slab offset of a channel split is added to the per-lane offset, not passed as the instruction's scalar offset: with an SGPR
-// soffset -- even one holding 0 -- the tiles 12..15 of all-tail layers came out wrong in their odd channels on the box, cause not
-// found; scripts/diag_ring_tail.py reproduces it)
+// The slab offset of a channel split is added to the per-lane offset, NOT passed as the instruction's scalar offset.  With an SGPR
+// soffset the compiler (ROCm 7.2 clang) leaves out the wait state between "buffer_store_dwordx4 v[128:131], v, s[..], sN offen" and
+// the next VALU instruction that overwrites v[128:131] -- its hazard recognizer holds that this store-data hazard "only exists if the
+// instruction is not using a register in the soffset field" -- and on gfx950 the store then picks up the NEW contents in part of its
+// lanes: odd output channels of tiles 12..15 came out wrong (scripts/diag_ring_tail.py; the ISA of the two forms differs by exactly
+// that s_nop).  With soffset = 0 the compiler inserts the wait state.
 __device__ __forceinline__ void rg_st(__amdgpu_buffer_rsrc_t rs, int byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), rs, byte_off, 0, 0);
 }
