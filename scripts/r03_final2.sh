@@ -1,0 +1,9 @@
+#!/bin/bash
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+cd $GRAFT_REPO_ROOT
+timeout -k 10 1000 python3 -m pytest tests -m gpu -q > $OUT/r03_gpu_tests.txt 2>&1; tail -4 $OUT/r03_gpu_tests.txt | cut -c1-250
+bash scripts/profile_all.sh r03 c2 > $OUT/r03_prof_c2.log 2>&1; echo "c2 profile rc $?"
+bash scripts/profile_all.sh r03 c3 > $OUT/r03_prof_c3.log 2>&1; echo "c3 profile rc $?"
+cd $GRAFT_REPO_ROOT
+bash scripts/small_shards.sh r03 c2 > /dev/null 2>&1
+timeout -k 10 300 python3 scripts/bench_wino.py vgg > $OUT/r03_wino_layers_vgg.txt 2>&1; tail -2 $OUT/r03_wino_layers_vgg.txt | cut -c1-200

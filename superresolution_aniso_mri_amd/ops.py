@@ -170,9 +170,17 @@ def _mse3_workspace(device):
     """Partial sums + ticket counter of aesr_mse3_fwd: zeroed ONCE (the kernel leaves it consistent), one per (device, stream) --
     two steps in flight on different streams must not share partial sums and tickets -- allocated outside any graph capture (the
     first, eager steps)."""
+    if torch.cuda.is_current_stream_capturing():
+        # a capture runs on a stream of its own: the captured graphs of a device (replayed one after the other on one stream) share one
+        # workspace, created by the eager steps before the capture -- a fresh one here would be a memset node in every replay
+        key = (str(device), "graph")
+        if key not in _MSE3_WS:
+            raise RuntimeError("aesr_mse3_fwd: run the loss eagerly once before capturing it into a HIP graph")
+        return _MSE3_WS[key]
     key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
     if key not in _MSE3_WS:
         _MSE3_WS[key] = torch.zeros(_hip.MSE3_WS, device=device, dtype=torch.float64)
+        _MSE3_WS.setdefault((str(device), "graph"), torch.zeros(_hip.MSE3_WS, device=device, dtype=torch.float64))
     return _MSE3_WS[key]
 
 
