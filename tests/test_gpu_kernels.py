@@ -626,6 +626,50 @@ def test_conv_wino_channel_split(hip, case, monkeypatch):
     assert L.aesr_conv2d_wino_ring_timeouts() == 0
 
 
+def test_conv_wino_channel_split_random_shapes(hip, monkeypatch):
+    """30 seeded random small layers (odd sizes, channel counts that leave ragged splits, all-tail item lists): the split launch equals
+    the unsplit launch of the same kernel to summation order, forward and data gradient, and both equal fp64."""
+    L = hip.lib
+    monkeypatch.setenv("AESR_WINO_RING", "2")
+    rng = np.random.RandomState(7)
+    g = torch.Generator().manual_seed(7)
+    nsplit = 0
+    for _ in range(30):
+        N, H, W = int(rng.randint(1, 6)), int(rng.randint(3, 30)), int(rng.randint(3, 30))
+        Cin, Cout = int(rng.choice([48, 64, 80, 96, 160, 256, 320])), int(rng.choice([32, 64, 96]))
+        S = int(rng.choice([2, 4, 8, 16]))
+        monkeypatch.setenv("AESR_RING_KSPLIT", str(S))
+        x = torch.randn(N, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+        b = torch.randn(Cout, generator=g)
+        xd, up, bd = D(nhwc(x)), D(_pack_wino(hip, w.cuda(), 0)), b.cuda()
+        nws = L.aesr_conv2d_wino_workspace_floats(N, H, W, Cin, Cout, 0)
+        ws = torch.full((max(nws, 1),), float("nan"), device="cuda")
+        out, out1 = (torch.full((N, H, W, Cout), float("nan"), device="cuda") for _ in range(2))
+        hip.check(L.aesr_conv2d_wino_fwd_ws(hip.ptr(xd), hip.ptr(up), hip.ptr(bd), hip.ptr(out), hip.ptr(ws), nws, N, H, W, Cin, Cout, 2, 0.0, hip.stream()), "fwd_ws")
+        hip.check(L.aesr_conv2d_wino_fwd_ws(hip.ptr(xd), hip.ptr(up), hip.ptr(bd), hip.ptr(out1), None, 0, N, H, W, Cin, Cout, 2, 0.0, hip.stream()), "fwd")
+        # data gradient of a layer Cout -> Cin (its K side has Cin channels), LeakyReLU mask
+        dy = torch.randn(N, Cin, H, W, generator=g)
+        wt = torch.randn(Cin, Cout, 3, 3, generator=g) / np.sqrt(Cin * 9)
+        xs = torch.randn(N, Cout, H, W, generator=g)
+        dyd, upt, xsd = D(nhwc(dy)), D(_pack_wino(hip, wt.cuda(), 1)), D(nhwc(xs))
+        nwd = L.aesr_conv2d_wino_workspace_floats(N, H, W, Cout, Cin, 1)
+        wsd = torch.full((max(nwd, 1),), float("nan"), device="cuda")
+        dx, dx1 = (torch.full((N, H, W, Cout), float("nan"), device="cuda") for _ in range(2))
+        hip.check(L.aesr_conv2d_wino_dgrad_ws(hip.ptr(dyd), hip.ptr(upt), hip.ptr(xsd), hip.ptr(dx), hip.ptr(wsd), nwd, N, H, W, Cout, Cin, 1, 0.01, hip.stream()), "dgrad_ws")
+        hip.check(L.aesr_conv2d_wino_dgrad_ws(hip.ptr(dyd), hip.ptr(upt), hip.ptr(xsd), hip.ptr(dx1), None, 0, N, H, W, Cout, Cin, 1, 0.01, hip.stream()), "dgrad")
+        torch.cuda.synchronize()
+        case = (N, H, W, Cin, Cout, S, nws // out.numel(), nwd // dx.numel())
+        ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+        refd = torch.nn.grad.conv2d_input((N, Cout, H, W), wt.double(), dy.double(), padding=1) * torch.where(xs > 0, 1.0, 0.01).double()
+        assert rel_l2(nchw(out), ref) < 1e-5 and rel_l2(nchw(out1), ref) < 1e-5, case
+        assert rel_l2(nchw(dx), refd) < 1e-5 and rel_l2(nchw(dx1), refd) < 1e-5, case
+        assert rel_l2(out, out1) < 2e-6 and rel_l2(dx, dx1) < 2e-6, case
+        nsplit += (nws > 0) + (nwd > 0)
+    assert nsplit >= 40                       # most of the 60 launches really ran split
+    assert L.aesr_conv2d_wino_ring_timeouts() == 0
+
+
 def test_conv_wino_channel_split_is_planned_for_small_deep_layers(hip):
     """Without any forcing: the launcher asks for slabs on the deep VGG layers of a small shard (few blocks x 512 channels) and on none of
     the layers of a full batch that fills the chip."""
