@@ -380,6 +380,11 @@ def main():
             sec["small_shards"] = small_shards(device)
             sec["inference"] = inference_bench(device)
             line["secondary"] = sec
+        # kernel sources of this run (the hash the PMC files are matched against) and the ring kernel's protocol watchdog (0 = no wait
+        # on an LDS arrival counter ever gave up in this process)
+        from superresolution_aniso_mri_amd._hip import lib as _lib
+        line["csrc_sha"] = csrc_sha()
+        line["ring_watchdog_timeouts"] = int(_lib.aesr_conv2d_wino_ring_timeouts())
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     finally:
         dp.shutdown()
