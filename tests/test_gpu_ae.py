@@ -117,6 +117,7 @@ def test_grouped_passes_equal_sequential_passes():
             assert int(sd[k]) == int(v) == 2
 
 
+@pytest.mark.skipif(os.environ.get("AESR_FUSE_STEM") == "0", reason="the folded pass is switched off")
 @pytest.mark.parametrize("cname,args", [("VanillaACAI", SMALL), ("LargerAE", SMALL), ("VanillaACAIStrided", SMALL),
                                         ("VanillaACAI", dict(SMALL, width=64, latent_width=16, depth=32, latent=32))])
 def test_stem_folded_pass_equals_unfolded_pass(cname, args):
