@@ -47,14 +47,18 @@ def stem_folded_gflop(B, H):
 
 
 def csrc_sha():
-    """Hash of the kernel sources: the PMC traffic files under profiles/ carry the hash they were measured at, and a stale one is
-    not quoted (``traffic: null``)."""
+    """Hash of the kernel sources' CODE (comments and white space removed, so that editing a comment does not orphan a measurement):
+    the PMC traffic files under profiles/ carry the hash they were measured at, and a stale one is not quoted (``traffic: null``)."""
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "superresolution_aniso_mri_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".h")):
+            src = open(os.path.join(d, name), "r", errors="replace").read()
+            src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)            # block comments
+            src = re.sub(r"//[^\n]*", " ", src)                          # line comments (no "//" occurs inside a string of these files)
             h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+            h.update(" ".join(src.split()).encode())
     return h.hexdigest()[:16]
 
 

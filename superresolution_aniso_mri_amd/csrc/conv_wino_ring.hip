@@ -24,7 +24,12 @@
 //    time of a full round), the other waves of such a group only stream their share of the filter.  Small layers (VGG conv5: 48
 //    blocks x 16 cout tiles) are all "tail" and still occupy every CU;
 //  * workgroups are renumbered so that the items of one spatial block group (all cout tiles) and its neighbours run on ONE XCD
-//    at about the same time: the input patches are fetched into that XCD's L2 once.
+//    at about the same time: the input patches are fetched into that XCD's L2 once;
+//  * channel split: a layer with fewer items than the chip has SIMDs would stream its K side serially per item (512 channels = 32
+//    chunks of ~3 us: VGG conv4 / conv5, every deep layer of a small data-parallel shard).  With a caller workspace the launcher may
+//    make S <= 16 items per (block group, cout tile), each streaming 1/S of the chunks and storing raw partial sums into its own
+//    output-shaped slab; wino_split_reduce_kernel adds the slabs in fixed order and applies bias, activation and derivative mask.
+//    S comes from the same cost model (+ the reduce launch and its (S + 1) output-sized streams).
 // U packing, the in-register input transform, bias in the accumulator of position (1,1), the derivative mask and the folded
 // Upsample(x2) in both directions are those of conv_wino.hip; results equal to rounding (the summation order over channels is
 // the same).
