@@ -240,9 +240,13 @@ def secondary_config(engine, config, device, scales3=False, steps=10, warmup=4, 
 
 
 def small_shards(device):
-    """What strong scaling over 12 triplets runs on: the replayed step at 1 / 2 / 3 / 6 triplets on ONE GPU (c2 and c3), and the rate an
-    8-rank run is bounded by -- 36 slices per step of the slowest rank (2 triplets: 12 over 8 ranks = 2,2,2,2,1,1,1,1) plus the
-    enqueue cost of the step's 9 collectives measured on a one-rank communicator (no wire time: a lower bound on the step)."""
+    """What strong scaling over 12 triplets runs on, measured on ONE GPU: the replayed single-process step at 1 / 2 / 3 / 6 triplets (c2 and
+    c3), and -- what a RANK of a data-parallel run executes -- the same step at 1 / 2 triplets with the data-parallel machinery switched
+    on over a communicator of one (``*_dp_ms``: SyncBN partial-sum kernels, the 8 SyncBN + 1 gradient collectives as RCCL enqueues, the
+    default graph form; no wire time, no waiting for peers).  8 ranks on 12 triplets are bounded by 36 slices per step of the slowest
+    rank (2 triplets: 2,2,2,2,1,1,1,1)."""
+    import torch.distributed as dist
+    from superresolution_aniso_mri_amd.parallel import DataParallelContext
     out = {}
     for config in ("c2", "c3"):
         row = {}
@@ -252,17 +256,33 @@ def small_shards(device):
             del trainer, pool
         torch.cuda.empty_cache()
         out[config] = row
-    coll_us = None
+    dp, saved = None, os.environ.get("AESR_FORCE_DP")
     try:
-        from superresolution_aniso_mri_amd.parallel import one_rank_collective_cost_us
-        coll_us = one_rank_collective_cost_us(device)
-    except Exception as e:       # no RCCL on this box: the projection is quoted without the collectives
-        out["collectives_note"] = "one-rank RCCL communicator unavailable (%s)" % (str(e)[:120],)
+        os.environ["AESR_FORCE_DP"] = "1"
+        if not dist.is_initialized():          # a group of one without a network port
+            dist.init_process_group("gloo", store=dist.HashStore(), rank=0, world_size=1)
+        dp = DataParallelContext(device=device)
+        for config in ("c2", "c3"):
+            for t in (1, 2):
+                trainer, pool = make_trainer(config, device, t, 160, npool=2, dp=dp)
+                out[config]["%d_triplets_dp_ms" % t] = round(1e3 * timed_steps(trainer, pool, 20, 6, dp) / 20, 3)
+                del trainer, pool
+            torch.cuda.empty_cache()
+        out["dp_form"] = "communicator of one, data plane %s, graph form %s" % (dp.data_backend, dp.graph_mode)
+    except Exception as e:       # no RCCL on this box: the projection falls back to the single-process step
+        out["dp_note"] = "one-rank data-parallel step not measured (%s)" % (str(e)[:160],)
+    finally:
+        if dp is not None:
+            dp.shutdown()
+        if saved is None:
+            os.environ.pop("AESR_FORCE_DP", None)
+        else:
+            os.environ["AESR_FORCE_DP"] = saved
     for config in ("c2", "c3"):
-        step_ms = out[config]["2_triplets_ms"] + (9 * coll_us * 1e-3 if coll_us is not None else 0.0)
+        step_ms = out[config].get("2_triplets_dp_ms", out[config]["2_triplets_ms"])
         out[config]["projected_8_rank_slices_per_s"] = round(36.0 / step_ms * 1e3, 1)
-    out["collective_enqueue_us"] = None if coll_us is None else round(coll_us, 2)
-    out["projection"] = "36 slices / (2-triplet step + 9 collectives x the one-rank enqueue cost): an upper bound on the 8-rank rate"
+    out["projection"] = ("36 slices / the 2-triplet step of one rank with SyncBN and the 9 collectives enqueued on a communicator of one: an UPPER "
+                         "bound on the 8-rank rate (wire time and waiting for the slowest peer come on top)")
     return out
 
 
@@ -347,7 +367,8 @@ def main():
         if use_graph:
             launch = ("captured HIP graph replay" if not dp.active else
                       "one HIP graph per step, RCCL collectives (library-owned communicator) as graph nodes" if dp.graph_mode == "whole" else
-                      "HIP graph segments between eager host-staged (gloo) collectives")
+                      ("HIP graph segments between eager RCCL collectives (library-owned communicator)" if dp.data_backend == "rccl" else
+                       "HIP graph segments between eager host-staged (gloo) collectives"))
             if not getattr(trainer, "_graphs", None):
                 raise SystemExit("bench: the step graph was requested but never captured")
         loss = trainer.losses["loss_ae"][-1]

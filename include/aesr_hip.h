@@ -164,6 +164,14 @@ int aesr_bn_stats_finalize(const float* y, float* partial, const double* counts_
 /* out = scale[g]*f(y) + shift[g], f = identity / 2x2 mean (floor) / nearest x2. */
 int aesr_bn_apply(const float* y, const float* scale, const float* shift, float* out, int N, int H, int W, int C, int mode,
                   int G, const int* nstart_host, void* stream);
+/* Data parallel, train mode: finalize (from the all-reduced [G][2][C] sums) + apply in ONE launch -- every block derives scale / shift
+ * itself, block 0 writes mean / invstd / scale / shift for the backward pass and updates the running statistics (same arithmetic as
+ * aesr_bn_finalize + aesr_bn_apply).  aesr_bn_fused_supported: G * C <= 1024.  aesr_bn_bwd_apply fuses its finalize the same way. */
+int aesr_bn_fused_supported(int C, int G);
+int aesr_bn_finalize_apply(const double* sums, const double* counts_host, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                           const float* y, float* out, int N, int H, int W, int C, int mode, int G, const int* nstart_host, float momentum,
+                           float eps, int update_running, void* stream);
 /* backward, step 1: sums[G][2][C] (double) = sum(g), sum(g*xhat) with g the gradient w.r.t. the BN output seen
  * through the pool / upsample.  gout is [N,Ho,Wo,C] (pool: Ho=H/2; up: Ho=2H; none: Ho=H). */
 int aesr_bn_bwd_reduce(const float* gout, const float* y, const float* mean, const float* invstd, float* partial,

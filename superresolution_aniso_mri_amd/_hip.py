@@ -71,6 +71,8 @@ SIGNATURES = {
     "aesr_bn_finalize": (c_int, [P, DP] + [P] * 9 + [c_int, c_int, c_float, c_float, c_int, c_int, P]),
     "aesr_bn_stats_finalize": (c_int, [P, P, DP] + [P] * 9 + [c_int, c_int, c_int, IP, c_float, c_float, c_int, P]),
     "aesr_bn_bwd": (c_int, [P] * 6 + [DP] + [P] * 4 + [c_int] * 6 + [c_float, c_int, IP, P]),
+    "aesr_bn_fused_supported": (c_int, [c_int, c_int]),
+    "aesr_bn_finalize_apply": (c_int, [P] * 13 + [c_int] * 6 + [P, c_float, c_float, c_int, P]),
     "aesr_bn_apply": (c_int, [P, P, P, P] + [c_int] * 6 + [IP, P]),
     "aesr_bn_bwd_reduce": (c_int, [P] * 6 + [c_int] * 6 + [IP, P]),
     "aesr_bn_bwd_apply": (c_int, [P] * 6 + [DP] + [P] * 4 + [c_int] * 6 + [c_float, c_int, IP, P]),

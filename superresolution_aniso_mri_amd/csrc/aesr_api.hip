@@ -814,6 +814,23 @@ int aesr_bn_apply(const float* y, const float* scale, const float* shift, float*
     return aesr_launch_bn_apply(a, (hipStream_t)stream);
 }
 
+int aesr_bn_fused_supported(int C, int G) { return aesr_bn_fused_ok(C, G) ? 1 : 0; }
+
+int aesr_bn_finalize_apply(const double* sums, const double* counts_host, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                           const float* y, float* out, int N, int H, int W, int C, int mode, int G, const int* nstart_host, float momentum,
+                           float eps, int update_running, void* stream) {
+    BnApplyArgs a;
+    AESR_CHECK_ARG(sums && counts_host && gamma && beta && mean && invstd && scale && shift && y && out && fill_groups(&a.gr, G, nstart_host),
+                   "aesr_bn_finalize_apply: bad arguments");
+    AESR_CHECK_ARG(aesr_bn_fused_ok(C, G), "aesr_bn_finalize_apply: %d groups x %d channels exceed the kernel's tables (aesr_bn_fused_supported)", G, C);
+    a.y = y; a.scale = scale; a.shift = shift; a.out = out; a.N = N; a.H = H; a.W = W; a.C = C; a.mode = mode;
+    bn_out_dims(H, W, mode, &a.Ho, &a.Wo);
+    AESR_CHECK_ARG(a.Ho > 0 && a.Wo > 0, "aesr_bn_finalize_apply: empty output");
+    return aesr_launch_bn_finalize_apply(sums, counts_host, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, mean, invstd,
+                                         scale, shift, momentum, eps, update_running && running_mean && running_var, G, a, (hipStream_t)stream);
+}
+
 int aesr_bn_bwd_reduce(const float* gout, const float* y, const float* mean, const float* invstd, float* partial, double* sums,
                        int N, int H, int W, int C, int mode, int G, const int* nstart_host, void* stream) {
     BnBwdArgs a;
@@ -834,10 +851,12 @@ int aesr_bn_bwd_apply(const float* gout, const float* y, const float* mean, cons
     memset(&a, 0, sizeof(a));
     AESR_CHECK_ARG(gout && y && mean && invstd && scale && sums && counts_host && coef && dgamma && dbeta && dpre &&
                        fill_groups(&a.gr, G, nstart_host), "aesr_bn_bwd_apply: bad arguments");
-    if (int e = aesr_launch_bn_bwd_finalize(sums, counts_host, coef, dgamma, dbeta, C, G, (hipStream_t)stream)) return e;
     a.gout = gout; a.y = y; a.mean = mean; a.invstd = invstd; a.scale = scale; a.coef = coef; a.dpre = dpre;
     a.N = N; a.H = H; a.W = W; a.C = C; a.mode = mode; a.act = act; a.slope = slope;
     bn_out_dims(H, W, mode, &a.Ho, &a.Wo);
+    if (aesr_bn_fused_ok(C, G))          // coef / dgamma / dbeta from the sums in the apply kernel's prologue: one launch
+        return aesr_launch_bn_bwd_finalize_apply(sums, counts_host, coef, dgamma, dbeta, G, a, (hipStream_t)stream);
+    if (int e = aesr_launch_bn_bwd_finalize(sums, counts_host, coef, dgamma, dbeta, C, G, (hipStream_t)stream)) return e;
     return aesr_launch_bn_bwd_apply(a, (hipStream_t)stream);
 }
 

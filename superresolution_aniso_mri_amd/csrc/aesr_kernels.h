@@ -170,6 +170,13 @@ int aesr_launch_bn_apply(const BnApplyArgs& a, hipStream_t st);
 int aesr_launch_bn_bwd_reduce(const BnBwdArgs& a, int nwg, hipStream_t st);
 int aesr_launch_bn_bwd_finalize(const double* sums, const double* counts, float* coef, float* dgamma, float* dbeta, int C, int G, hipStream_t st);
 int aesr_launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t st);
+// data parallel: finalize (from the all-reduced sums) + apply in one launch, forward and backward
+bool aesr_bn_fused_ok(int C, int G);
+int aesr_launch_bn_finalize_apply(const double* sums, const double* counts, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, long long* nbt, float* mean, float* invstd, float* scale, float* shift, float momentum,
+                                  float eps, int update_running, int G, const BnApplyArgs& a, hipStream_t st);
+int aesr_launch_bn_bwd_finalize_apply(const double* sums, const double* counts, float* coef, float* dgamma, float* dbeta, int G,
+                                      const BnBwdArgs& a, hipStream_t st);
 
 int aesr_launch_lerp_fwd(const float* z, const float* af, const float* at, float* zmix, int B, size_t per, hipStream_t st);
 int aesr_launch_lerp_bwd(const float* dmix, const float* af, const float* at, float* dz, int B, size_t per, hipStream_t st);

@@ -63,7 +63,21 @@ __global__ __launch_bounds__(1024) void bn_reduce_kernel(const float* __restrict
     if (o < n) {
         const int g = o / (2 * C), r = o - g * 2 * C;
         const float* base = partial + (size_t)g * nwg * 2 * C + r;
-        for (int k = rl; k < nwg; k += 16) s += (double)base[(size_t)k * 2 * C];
+        const size_t rs = (size_t)2 * C;
+        // 8 independent loads in flight per thread (one load per trip = a round of memory latency per row: 10 us for 512 rows)
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int k = rl;
+        for (; k + 7 * 16 < nwg; k += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(k + u * 16) * rs];
+            s0 += (double)v[0] + (double)v[4];
+            s1 += (double)v[1] + (double)v[5];
+            s2 += (double)v[2] + (double)v[6];
+            s3 += (double)v[3] + (double)v[7];
+        }
+        for (; k < nwg; k += 16) s0 += (double)base[(size_t)k * rs];
+        s = (s0 + s1) + (s2 + s3);
     }
     red[rl][col] = s;
     __syncthreads();
@@ -187,6 +201,82 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
         const int g = group_of(a.gr, n);
         const f32x4 sc = *(const f32x4*)(a.scale + g * a.C + c4 * 4);
         const f32x4 sh = *(const f32x4*)(a.shift + g * a.C + c4 * 4);
+        f32x4 v;
+        if (a.mode == BN_MODE_POOL) {
+            const float* b = a.y + (((size_t)n * a.H + 2 * yy) * a.W + 2 * x) * a.C + c4 * 4;
+            const f32x4 v00 = *(const f32x4*)b, v01 = *(const f32x4*)(b + a.C);
+            const f32x4 v10 = *(const f32x4*)(b + (size_t)a.W * a.C), v11 = *(const f32x4*)(b + (size_t)a.W * a.C + a.C);
+            v = ((v00 + v01) + (v10 + v11)) * 0.25f;
+        } else if (a.mode == BN_MODE_UP) {
+            v = *(const f32x4*)(a.y + (((size_t)n * a.H + (yy >> 1)) * a.W + (x >> 1)) * a.C + c4 * 4);
+        } else {
+            v = *(const f32x4*)(a.y + (((size_t)n * a.H + yy) * a.W + x) * a.C + c4 * 4);
+        }
+        *(f32x4*)(a.out + idx * 4) = v * sc + sh;
+    }
+}
+
+// Data parallel (SyncBN): finalize + apply in ONE launch.  The all-reduced sums are [G][2][C] doubles -- a few hundred values -- so every
+// block derives scale / shift for all groups and channels itself (into LDS, the arithmetic of bn_finalize_one) and block 0 alone
+// writes mean / invstd / scale / shift for the backward pass and updates the running statistics, group after group.
+constexpr int BN_FUSE_MAX = 1024;       // G * C values a block keeps in LDS
+
+__device__ __forceinline__ void bn_finalize_vals(const BnFinArgs& f, int g, double s0, double s1, float* m, float* iv, double* unb) {
+    const double M = f.counts.c[g];
+    const double mu = s0 / M;
+    double var = s1 / M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    *m = (float)mu;
+    *iv = (float)(1.0 / sqrt(var + (double)f.eps));
+    *unb = M > 1.0 ? var * M / (M - 1.0) : var;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const double* __restrict__ sums, BnFinArgs f, BnApplyArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_sc[BN_FUSE_MAX], s_sh[BN_FUSE_MAX];
+    const int GC = f.G * f.C;
+    for (int i = threadIdx.x; i < GC; i += 256) {
+        const int g = i / f.C, c = i - g * f.C;
+        float m, iv;
+        double unb;
+        bn_finalize_vals(f, g, sums[(g * 2 + 0) * f.C + c], sums[(g * 2 + 1) * f.C + c], &m, &iv, &unb);
+        const float sc = f.gamma[c] * iv, sh = f.beta[c] - m * sc;
+        s_sc[i] = sc;
+        s_sh[i] = sh;
+        if (blockIdx.x == 0) {
+            f.mean[i] = m;
+            f.invstd[i] = iv;
+            f.scale[i] = sc;
+            f.shift[i] = sh;
+        }
+    }
+    if (blockIdx.x == 0 && f.update_running) {
+        if (threadIdx.x == 0 && f.nbt) *f.nbt += f.G;
+        for (int c = threadIdx.x; c < f.C; c += 256) {
+            float rm = f.running_mean[c], rv = f.running_var[c];
+            for (int g = 0; g < f.G; ++g) {             // group after group, as the reference's successive calls
+                float m, iv;
+                double unb;
+                bn_finalize_vals(f, g, sums[(g * 2 + 0) * f.C + c], sums[(g * 2 + 1) * f.C + c], &m, &iv, &unb);
+                rm = (1.f - f.momentum) * rm + f.momentum * m;
+                rv = (1.f - f.momentum) * rv + f.momentum * (float)unb;
+            }
+            f.running_mean[c] = rm;
+            f.running_var[c] = rv;
+        }
+    }
+    __syncthreads();
+    const int C4 = a.C >> 2;
+    const size_t total = (size_t)a.N * a.Ho * a.Wo * C4;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c4 = idx % C4;
+        size_t pix = idx / C4;
+        const int x = pix % a.Wo;
+        pix /= a.Wo;
+        const int yy = pix % a.Ho;
+        const int n = pix / a.Ho;
+        const int g = group_of(a.gr, n);
+        const f32x4 sc = *(const f32x4*)(s_sc + g * a.C + c4 * 4);
+        const f32x4 sh = *(const f32x4*)(s_sh + g * a.C + c4 * 4);
         f32x4 v;
         if (a.mode == BN_MODE_POOL) {
             const float* b = a.y + (((size_t)n * a.H + 2 * yy) * a.W + 2 * x) * a.C + c4 * 4;
@@ -363,6 +453,54 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     }
 }
 
+// the same for the backward pass: coef = sums / M per block in LDS, block 0 writes coef / dgamma / dbeta
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_apply_kernel(const double* __restrict__ sums, BnCounts counts, float* __restrict__ coef,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int G, BnBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_k[2 * BN_FUSE_MAX];       // [g][2][C]
+    const int GC2 = G * 2 * a.C;
+    for (int i = threadIdx.x; i < GC2; i += 256) {
+        const int g = i / (2 * a.C);
+        const float k = (float)(sums[i] / counts.c[g]);
+        s_k[i] = k;
+        if (blockIdx.x == 0) coef[i] = k;
+    }
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < a.C; c += 256) {
+            double dg = 0.0, db = 0.0;
+            for (int g = 0; g < G; ++g) {
+                db += sums[(g * 2 + 0) * a.C + c];
+                dg += sums[(g * 2 + 1) * a.C + c];
+            }
+            dgamma[c] = (float)dg;
+            dbeta[c] = (float)db;
+        }
+    __syncthreads();
+    const int C4 = a.C >> 2;
+    const size_t total = (size_t)a.N * a.H * a.W * C4;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c4 = idx % C4;
+        size_t pix = idx / C4;
+        const int x = pix % a.W;
+        pix /= a.W;
+        const int yy = pix % a.H;
+        const int n = pix / a.H;
+        const int g = group_of(a.gr, n);
+        const f32x4 mu = *(const f32x4*)(a.mean + g * a.C + c4 * 4);
+        const f32x4 iv = *(const f32x4*)(a.invstd + g * a.C + c4 * 4);
+        const f32x4 sc = *(const f32x4*)(a.scale + g * a.C + c4 * 4);
+        const f32x4 k1 = *(const f32x4*)(s_k + (g * 2 + 0) * a.C + c4 * 4);
+        const f32x4 k2 = *(const f32x4*)(s_k + (g * 2 + 1) * a.C + c4 * 4);
+        const f32x4 yv = *(const f32x4*)(a.y + idx * 4);
+        const f32x4 gg = bn_gather_g_t<MODE>(a, n, yy, x, c4);
+        const f32x4 xh = (yv - mu) * iv;
+        f32x4 d = sc * (gg - k1 - xh * k2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] *= act_grad_from_output(yv[e], a.act, a.slope);
+        *(f32x4*)(a.dpre + idx * 4) = d;
+    }
+}
+
 // ---- launchers ----------------------------------------------------------------------------------------------
 static int bn_check_c(int C, const char* who) {
     if (C % 4 != 0 || 256 % (C / 4) != 0 || C > 1024) {
@@ -480,5 +618,37 @@ int aesr_launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t st) {
     else if (a.mode == BN_MODE_UP) hipLaunchKernelGGL(bn_bwd_apply_kernel<BN_MODE_UP>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(grid), dim3(256), 0, st, a);
     AESR_LAUNCH_CHECK("bn_bwd_apply");
+    return AESR_OK;
+}
+
+// finalize + apply / backward finalize + apply in one launch (data parallel, train mode); false: too many values for the LDS tables
+bool aesr_bn_fused_ok(int C, int G) { return G * C <= BN_FUSE_MAX && G >= 1 && G <= 4; }
+
+int aesr_launch_bn_finalize_apply(const double* sums, const double* counts, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, long long* nbt, float* mean, float* invstd, float* scale, float* shift, float momentum,
+                                  float eps, int update_running, int G, const BnApplyArgs& a, hipStream_t st) {
+    if (int e = bn_check_c(a.C, "bn_finalize_apply")) return e;
+    const BnFinArgs f = bn_fin_args(counts, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale, shift, a.C, G, momentum, eps, 1,
+                                    update_running);
+    const size_t total = (size_t)a.N * a.Ho * a.Wo * (a.C / 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(grid), dim3(256), 0, st, sums, f, a);
+    AESR_LAUNCH_CHECK("bn_finalize_apply");
+    return AESR_OK;
+}
+
+int aesr_launch_bn_bwd_finalize_apply(const double* sums, const double* counts, float* coef, float* dgamma, float* dbeta, int G,
+                                      const BnBwdArgs& a, hipStream_t st) {
+    if (int e = bn_check_c(a.C, "bn_bwd_finalize_apply")) return e;
+    BnCounts cnt;
+    for (int g = 0; g < 4; ++g) cnt.c[g] = (counts && g < G) ? counts[g] : 1.0;
+    const size_t total = (size_t)a.N * a.H * a.W * (a.C / 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (a.mode == BN_MODE_POOL) hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<BN_MODE_POOL>, dim3(grid), dim3(256), 0, st, sums, cnt, coef, dgamma, dbeta, G, a);
+    else if (a.mode == BN_MODE_UP) hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<BN_MODE_UP>, dim3(grid), dim3(256), 0, st, sums, cnt, coef, dgamma, dbeta, G, a);
+    else hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<0>, dim3(grid), dim3(256), 0, st, sums, cnt, coef, dgamma, dbeta, G, a);
+    AESR_LAUNCH_CHECK("bn_bwd_finalize_apply");
     return AESR_OK;
 }

@@ -439,11 +439,12 @@ class SequentialRunner:
                 cur, H, W = out, Ho, Wo
             else:
                 bn = s.mod
-                st = self._bn_forward_stats(bn, cur, N, H, W, C, nstart, train)
                 Ho, Wo = s.out_hw(H, W)
                 out = _empty((N, Ho, Wo, C), x)
-                check(lib.aesr_bn_apply(ptr(cur), ptr(st["scale"]), ptr(st["shift"]), ptr(out), N, H, W, C, s.run_mode, G,
-                                        _hip.int_array(nstart), stream()), "aesr_bn_apply")
+                st = self._bn_forward_stats(bn, cur, N, H, W, C, nstart, train, out, s.run_mode)
+                if not st.pop("applied", False):
+                    check(lib.aesr_bn_apply(ptr(cur), ptr(st["scale"]), ptr(st["shift"]), ptr(out), N, H, W, C, s.run_mode, G,
+                                            _hip.int_array(nstart), stream()), "aesr_bn_apply")
                 if save:
                     saved.append((cur, st))
                 cur, H, W = out, Ho, Wo
@@ -452,7 +453,9 @@ class SequentialRunner:
     sync_bn = None      # optional callable(sums[G,2,C] double) -> all-reduced in place across ranks (data parallel SyncBN)
     count_scale = 1.0   # data parallel: global / local sub-batch size (B_global / B_local of this rank)
 
-    def _bn_forward_stats(self, bn, y, N, H, W, C, nstart, train):
+    def _bn_forward_stats(self, bn, y, N, H, W, C, nstart, train, out=None, run_mode=0):
+        """Statistics of a BatchNorm call -> {mean, invstd, scale, shift, counts}.  Data parallel (``sync_bn``) with ``out`` given: the
+        finalize runs inside the apply launch (``"applied": True`` in the result -- the caller must not apply again)."""
         G = len(nstart) - 1
         dev = y.device
         st = {k: torch.empty((G, C), device=dev, dtype=torch.float32) for k in ("mean", "invstd", "scale", "shift")}
@@ -475,6 +478,15 @@ class SequentialRunner:
             check(lib.aesr_bn_stats(ptr(y), ptr(partial), ptr(sums), H * W, C, G, _hip.int_array(nstart), stream()),
                   "aesr_bn_stats")
             self.sync_bn(sums)
+            if out is not None and lib.aesr_bn_fused_supported(C, G):
+                st["counts"] = counts
+                check(lib.aesr_bn_finalize_apply(ptr(sums), _hip.double_array(counts), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+                                                 ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(st["mean"]), ptr(st["invstd"]),
+                                                 ptr(st["scale"]), ptr(st["shift"]), ptr(y), ptr(out), N, H, W, C, run_mode, G,
+                                                 _hip.int_array(nstart), momentum, float(bn.eps), int(update), stream()),
+                      "aesr_bn_finalize_apply")
+                st["applied"] = True
+                return st
         st["counts"] = counts
         check(lib.aesr_bn_finalize(ptr(sums), _hip.double_array(counts) if counts else None, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
                                    ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(st["mean"]), ptr(st["invstd"]),

@@ -400,6 +400,18 @@ def test_bn_groups_fwd_bwd(hip, mode, shape):
     assert int(nbt2) == 2
     for got, want in zip(st2 + [rm2, rv2, coef2, dgam2, dbet2, dpre2], st + [rm, rv, coef, dgam, dbet, dpre]):
         assert rel_l2(got, want) < 2e-6
+    # the data-parallel composite: finalize (from the sums) inside the apply launch -- the SAME numbers as finalize + apply, bit for bit
+    assert L.aesr_bn_fused_supported(C, G) == 1
+    rm3, rv3, nbt3 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros((), dtype=torch.int64, device="cuda")
+    st3 = [torch.full((G, C), float("nan"), device="cuda") for _ in range(4)]
+    out3 = torch.full((N, Ho, Wo, C), float("nan"), device="cuda")
+    hip.check(L.aesr_bn_finalize_apply(hip.ptr(sums), counts, hip.ptr(gam), hip.ptr(bet), hip.ptr(rm3), hip.ptr(rv3), hip.ptr(nbt3),
+                                       *[hip.ptr(t) for t in st3], hip.ptr(yd), hip.ptr(out3), N, H, W, C, mode, G, ns, 0.1, 1e-5, 1, hip.stream()),
+              "finalize_apply")
+    torch.cuda.synchronize()
+    assert int(nbt3) == 2 and torch.equal(out3, out) and torch.equal(rm3, rm) and torch.equal(rv3, rv)
+    for got, want in zip(st3, st):
+        assert torch.equal(got, want)
 
 
 def test_lerp_mse_act_adam(hip):
