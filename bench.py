@@ -150,6 +150,9 @@ def make_trainer(config, device, B, H, scales3=False, graph=True, npool=4, dp=No
         if dp is not None and dp.active:
             b = shard_batch(b, dp.rank, dp.world)
         pool.append({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items()})
+    import gc
+    gc.collect()
+    gc.freeze()         # as train_aesr.py does: no full collection over the long-lived object graph inside the timed steps
     return trainer, pool
 
 

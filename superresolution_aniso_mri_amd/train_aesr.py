@@ -97,6 +97,11 @@ def main(argv=None, brain=False):
     if dp.active:
         dp.attach(trainer)
         dp.set_batch(B)
+    # everything built so far lives for the whole run: take it out of the garbage collector's sight, so that a full collection does not
+    # walk the module / ctypes object graph in the middle of training (measured: one 95 ms pause around step 100 of a 0.9 ms step)
+    import gc
+    gc.collect()
+    gc.freeze()
     if args_dict.get("use_step_graph"):
         # single process: one HIP graph per step; data parallel: graph segments between the eager collectives
         trainer.enable_step_graph(dp_segments=dp.active)
