@@ -373,49 +373,45 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
         accb[o] += __shfl_xor(accb[o], 16, 64);
         accb[o] += __shfl_xor(accb[o], 32, 64);
     }
-    // the planes are dead (barrier at the end of the last tile): waves 1-3 park their partial sums in LDS, wave 0 adds them up
-    f32x4* ex = (f32x4*)lds;                               // [wave - 1][36][64 lanes]
-    float* exb = lds + 3 * 36 * 64 * 4;                    // [wave - 1][2][16]
-    if (wave > 0) {
+    // the planes are dead (barrier at the end of the last tile): every wave parks its partial sums in LDS and then adds up and stores a
+    // QUARTER of the slab (9 of the 36 [tap][ci block][co block] pieces) -- waves 0..3 in the same fixed order as before (wave 0 alone
+    // used to read 108 KB and issue all 144 stores while the other three waves idled)
+    f32x4* ex = (f32x4*)lds;                               // [wave][36][64 lanes]
+    float* exb = lds + 4 * 36 * 64 * 4;                    // [wave][2][16]
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int o = 0; o < 2; ++o) ex[((wave - 1) * 36 + (t * 4 + i * 2 + o)) * 64 + lane] = dg[t][i][o];
-        if (g == 0) {
-            exb[(wave - 1) * 32 + l15] = accb[0];
-            exb[(wave - 1) * 32 + 16 + l15] = accb[1];
-        }
+            for (int o = 0; o < 2; ++o) ex[(wave * 36 + (t * 4 + i * 2 + o)) * 64 + lane] = dg[t][i][o];
+    if (g == 0) {
+        exb[wave * 32 + l15] = accb[0];
+        exb[wave * 32 + 16 + l15] = accb[1];
     }
     __syncthreads();
-    if (wave == 0) {
-        const size_t plane = (size_t)a.CinP * a.CoutP;
-        float* sl = a.slab + (size_t)split * 10 * plane;
+    const size_t plane = (size_t)a.CinP * a.CoutP;
+    float* sl = a.slab + (size_t)split * 10 * plane;
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+    for (int q = 0; q < 9; ++q) {
+        const int blk = wave * 9 + q;                      // uniform: piece (t, i, o)
+        const int t = blk >> 2, i = (blk >> 1) & 1, o = blk & 1;
+        f32x4 v = ex[(0 * 36 + blk) * 64 + lane];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int w = 1; w < 4; ++w) v += ex[(w * 36 + blk) * 64 + lane];
+        const int co = co0 + o * 16 + l15;
 #pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                    f32x4 v = dg[t][i][o];
+        for (int e = 0; e < 4; ++e) {
+            const int ci = ci0 + i * 16 + g * 4 + e;
+            sl[t * plane + (size_t)ci * a.CoutP + co] = v[e];
+        }
+    }
+    if (wave == 0 && do_bias && g == 0) {
 #pragma unroll
-                    for (int w = 0; w < 3; ++w) v += ex[(w * 36 + (t * 4 + i * 2 + o)) * 64 + lane];
-                    const int co = co0 + o * 16 + l15;
+        for (int o = 0; o < 2; ++o) {
+            float bsum = exb[0 * 32 + o * 16 + l15];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int ci = ci0 + i * 16 + g * 4 + e;
-                        sl[t * plane + (size_t)ci * a.CoutP + co] = v[e];
-                    }
-                }
-        if (do_bias && g == 0) {
-#pragma unroll
-            for (int o = 0; o < 2; ++o) {
-                float b = accb[o];
-#pragma unroll
-                for (int w = 0; w < 3; ++w) b += exb[w * 32 + o * 16 + l15];
-                sl[9 * plane + co0 + o * 16 + l15] = b;
-            }
+            for (int w = 1; w < 4; ++w) bsum += exb[w * 32 + o * 16 + l15];
+            sl[9 * plane + co0 + o * 16 + l15] = bsum;
         }
     }
 }
@@ -423,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_wino_f32(WgradArgs a) {
 size_t aesr_wgrad_wino_lds_bytes(int TH, int TW) {
     const size_t xfl = (size_t)(TH + 2) * (TW == 8 ? 16 : 32) * 32, dfl = (size_t)TH * TW * 32;
     const size_t bufs = 2 * (xfl + dfl) * sizeof(float);
-    const size_t exch = ((size_t)3 * 36 * 64 * 4 + 3 * 32) * sizeof(float);
+    const size_t exch = ((size_t)4 * 36 * 64 * 4 + 4 * 32) * sizeof(float);
     return bufs > exch ? bufs : exch;
 }
 
