@@ -424,7 +424,7 @@ int aesr_conv2d_wino_kernel(int N, int H, int W, int Cin, int Cout, int KS, int 
     a.CinP = p.CinP; a.CoutP = p.CoutP;
     a.plan_cost = p.cost;
     if (aesr_wino_res_ok(a)) return 2;
-    a.ws = (float*)(size_t)16;          // as called with the workspace aesr_conv2d_wino_workspace_floats asks for
+    a.ws = nullptr;                     // a query: as called with the workspace aesr_conv2d_wino_workspace_floats asks for
     a.ws_floats = ~(size_t)0;
     return aesr_wino_ring_takes(a) ? 3 : 1;
 }

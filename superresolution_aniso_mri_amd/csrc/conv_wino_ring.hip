@@ -563,7 +563,7 @@ int aesr_wino_ring_mode() {
 // used) and on layers too small for a round of ring items (VGG conv5)
 // The channel split the workspace in ``a`` allows: the unconstrained plan's if its slabs fit, else none
 static int ring_smax(const WinoArgs& a) {
-    if (!a.ws || a.out_sum2) return 1;
+    if (a.ws_floats == 0 || a.out_sum2) return 1;       // (queries pass ws_floats = SIZE_MAX without a buffer: "whatever the plan wants")
     const size_t out_floats = (size_t)a.N * a.H * a.W * a.Cout;
     const RingPlan p = plan_ring(a, RG_KSPLIT_MAX);
     return (size_t)p.ksplit * out_floats <= a.ws_floats ? RG_KSPLIT_MAX : 1;
@@ -578,7 +578,7 @@ bool aesr_wino_ring_takes(const WinoArgs& a) {
 
 size_t aesr_wino_ring_workspace_floats(const WinoArgs& a) {
     WinoArgs b = a;
-    b.ws = (float*)(size_t)16;            // "a workspace of any size": the plan's wish
+    b.ws = nullptr;                       // a query, nothing is launched: "a workspace of any size" = the plan's wish
     b.ws_floats = ~(size_t)0;
     if (!aesr_wino_ring_takes(b)) return 0;
     const RingPlan p = plan_ring(b, RG_KSPLIT_MAX);
@@ -648,6 +648,10 @@ int aesr_launch_conv_wino_ring(const WinoArgs& a_in, hipStream_t st) {
     a.nblk = ceil_div(a.N, a.TI) * a.bpi;
     a.nfull = p.nfull; a.tail_k = p.tail_k;
     a.ksplit = p.ksplit;
+    if (a.ksplit > 1 && !a.ws) {
+        aesr_set_error("conv_wino_ring: a channel split of %d was planned without a workspace", a.ksplit);
+        return AESR_ERR_ARG;
+    }
     a.kchunks = ceil_div(a.CinP / 16, p.ksplit);
     const size_t out_floats = (size_t)a.N * (a.out_sum2 ? a.H / 2 : a.H) * (a.out_sum2 ? a.W / 2 : a.W) * a.Cout;
     if (out_floats * 4 * (size_t)a.ksplit >= (size_t)RG_OOB) {
