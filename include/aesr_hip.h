@@ -290,6 +290,17 @@ size_t aesr_ssim_workspace_doubles(int Z, int H, int W);
 int aesr_ssim_mse(const float* a, const float* b, double* workspace, double* ssim, double* mse, int Z, int H, int W, int win,
                   double data_range, double k1, double k2, void* stream);
 
+/* ---- VIF of the same protocol (evaluate/metrics.py:65-109 compute_vif_for_batch -> evaluate/vifvec.py:7-63 vifp_mscale, per slice) --
+ * ref, dist: [Z][H][W] fp32 in [0, 1].  vif[Z]: fp64 device array, NaN where the denominator is 0 (a black reference slice).  The
+ * arithmetic is the reference's on uint8 images (both volumes are converted with uint8(clip(x * 255, 0, 255)) before vifp_mscale is
+ * called; scipy's Gaussian filter and numpy's products then stay in uint8: truncation after every filter pass, products modulo 256)
+ * -- csrc/vif.hip, oracle/vif_oracle.py.  weights_host: the four 1-D Gaussian kernels back to back, 2 * radii_host[s] + 1 doubles each,
+ * as scipy.ndimage computes them (sd = 3.4, 1.8, 1.0, 0.6; radius = int(4 sd + 0.5) <= 14): HOST arrays, read during the call.
+ * sigma_nsq: the reference's default 2.0.  workspace: aesr_vif_workspace_bytes(Z, H, W) bytes, 8-byte aligned. */
+size_t aesr_vif_workspace_bytes(int Z, int H, int W);
+int aesr_vif_mscale(const float* ref, const float* dist, void* workspace, double* vif, int Z, int H, int W, const double* weights_host,
+                    const int* radii_host, double sigma_nsq, void* stream);
+
 /* ---- Winograd F(2x2,3x3) form of the same 3x3 / padding-1 convolutions (2.25x fewer matrix-core flops; csrc/conv_wino.hip) ------
  * Same results as aesr_conv2d_fwd / _dgrad up to fp32 rounding of the transforms (2-4e-7 relative).  Needs K-side channels % 16
  * == 0 and N-side channels % 32 == 0 (aesr_conv2d_wino_supported; transpose = 1 asks for the data-gradient roles).  The filter is

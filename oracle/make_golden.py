@@ -665,9 +665,70 @@ def gen_eval_crop():
     np.savez_compressed(os.path.join(OUT, "eval_crop.npz"), **rec)
 
 
+def gen_vif():
+    """VIF as the reference's evaluation computes it: ``evaluate.metrics.compute_vif_for_batch`` (:65-109: both volumes -> uint8, then
+    ``evaluate.vifvec.vifp_mscale`` per slice) and ``vifp_mscale`` itself (:7-63) on uint8 / float32 / float64 slices, run as the
+    reference's OWN functions.  ``evaluate/metrics.py`` imports skimage / datasets / lpips at module level (never called here):
+    absent modules are answered with empty stand-ins."""
+    import_reference()
+    tv = sys.modules["torchvision"]
+    for sub in ("datasets", "transforms", "utils"):
+        setattr(tv, sub, _any_stub("torchvision." + sub))
+    em = vv = None
+    for _ in range(64):
+        try:
+            import evaluate.metrics as em
+            import evaluate.vifvec as vv
+            break
+        except ModuleNotFoundError as e:
+            _any_stub(e.name)
+    rs = np.random.RandomState(4711)
+
+    def smooth_volume(z, h, w, noise):
+        """MRI-like slices in [0, 1]: blobs on a black background (exact zeros), a saturated patch (exact ones), and a degraded copy."""
+        yy, xx = np.mgrid[0:h, 0:w]
+        vol = np.zeros((z, h, w), dtype=np.float64)
+        for k in range(z):
+            for _ in range(6):
+                cy, cx, sg, amp = rs.uniform(0.2 * h, 0.8 * h), rs.uniform(0.2 * w, 0.8 * w), rs.uniform(0.05, 0.25) * min(h, w), rs.uniform(0.2, 0.9)
+                vol[k] += amp * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * sg * sg))
+            vol[k] += 0.05 * rs.randn(h, w)
+            vol[k][(yy - h / 2) ** 2 + (xx - w / 2) ** 2 > (0.45 * min(h, w)) ** 2] = 0.0
+        vol = np.clip(vol, 0, 1)
+        vol[:, h // 3:h // 3 + 6, w // 3:w // 3 + 9] = 1.0
+        deg = np.clip(0.9 * vol + noise * rs.randn(z, h, w) + 0.02, 0, 1)
+        deg[vol == 0] = 0.0
+        return vol.astype(np.float32), deg.astype(np.float32)
+
+    rec = {}
+    cases = [("v40", 5, 40, 52, 0.04, None), ("v33", 4, 33, 31, 0.08, None), ("v64ds", 9, 64, 64, 0.03, 2), ("v28", 3, 28, 28, 0.1, None),
+             ("v72ds3", 7, 72, 56, 0.02, 3)]
+    for tag, z, h, w, noise, ds in cases:
+        a, b = smooth_volume(z, h, w, noise)
+        rec[tag + "/ref"], rec[tag + "/dist"] = a, b
+        rec[tag + "/downsample_steps"] = np.array(-1 if ds is None else ds)
+        rec[tag + "/vif_batch"] = np.array(em.compute_vif_for_batch(a, b, eval_axis=0, normalize=False, downsample_steps=ds), dtype=np.float64)
+        a8, b8 = np.uint8(np.clip(a * 255., 0, 255)), np.uint8(np.clip(b * 255., 0, 255))
+        rec[tag + "/vif_u8"] = np.array([vv.vifp_mscale(a8[k], b8[k]) for k in range(z)], dtype=np.float64)
+        rec[tag + "/vif_f32"] = np.array([vv.vifp_mscale(a[k], b[k]) for k in range(z)], dtype=np.float64)
+        rec[tag + "/vif_f64"] = np.array([vv.vifp_mscale(a[k].astype(np.float64), b[k].astype(np.float64)) for k in range(z)], dtype=np.float64)
+    # a single 2-D image pair (the reference returns the score itself) and the degenerate ones: identical images, a black image
+    a, b = smooth_volume(1, 48, 48, 0.05)
+    rec["img/ref"], rec["img/dist"] = a[0], b[0]
+    rec["img/vif_batch"] = np.array(em.compute_vif_for_batch(a[0], b[0]), dtype=np.float64)
+    rec["same/vif_batch"] = np.array(em.compute_vif_for_batch(a[0], a[0]), dtype=np.float64)
+    with np.errstate(all="ignore"):
+        rec["black/vif_batch"] = np.array(em.compute_vif_for_batch(np.zeros((2, 24, 24), np.float32), np.zeros((2, 24, 24), np.float32)), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "vif.npz"), **rec)
+    print("vif.npz:", {k: (v.tolist() if v.size < 10 else v.shape) for k, v in rec.items() if "vif" in k})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "vif":
+        gen_vif()
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "eval_crop":
         import_reference()
         gen_eval_crop()
@@ -695,6 +756,7 @@ def main():
         return
     av, avs, avm, nb = import_reference()
     gen_supervolume_eval(av)
+    gen_vif()
     gen_acai_steps(av)
     gen_laploss()
     gen_ae_standard_blocks()

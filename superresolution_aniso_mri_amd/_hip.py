@@ -103,6 +103,8 @@ SIGNATURES = {
     "aesr_triplet_assemble": (c_int, [P, ctypes.POINTER(TripletDesc), c_int, c_int, P, P, P]),
     "aesr_ssim_workspace_doubles": (c_size_t, [c_int, c_int, c_int]),
     "aesr_ssim_mse": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_double, c_double, c_double, P]),
+    "aesr_vif_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "aesr_vif_mscale": (c_int, [P, P, P, P, c_int, c_int, c_int, DP, IP, c_double, P]),
     "aesr_adam_state_init": (None, [FP, c_double, c_double, c_double]),
     "aesr_adam_step": (c_int, [P, P, P, P, P, c_size_t, c_float, c_double, c_double, c_float, c_float, c_int, P]),
     "aesr_conv2d_wino_supported": (c_int, [c_int] * 5),
@@ -167,6 +169,18 @@ def last_error():
 def check(rc, what):
     if rc != 0:
         raise RuntimeError("%s failed (code %d): %s" % (what, rc, last_error()))
+
+
+def check_device_watchdogs(where):
+    """Raise if a kernel-side protocol watchdog has fired in this process.  The ring kernel's waves wait on LDS arrival counters
+    (csrc/conv_wino_ring.hip); a wait that gives up -- a protocol bug, never seen -- lets the wave go on with an incomplete filter
+    chunk rather than hang the GPU, and counts.  Every place where results LEAVE the process (checkpoints, logged epoch means,
+    validation, synthesised volumes, the bench line) calls this, so garbage cannot be trained on or written silently.  Reads a
+    device symbol (synchronises the device): never inside the step or a graph capture."""
+    n = int(lib.aesr_conv2d_wino_ring_timeouts())
+    if n:
+        raise RuntimeError("%s: the ring convolution kernel's arrival-counter watchdog fired %d time(s) in this process -- activations / "
+                           "gradients computed since are not trustworthy (csrc/conv_wino_ring.hip: wait_full); nothing was written" % (where, n))
 
 
 def ptr(t):

@@ -1070,4 +1070,14 @@ int aesr_ssim_mse(const float* a, const float* b, double* workspace, double* ssi
     return aesr_launch_ssim_mse(a, b, workspace, ssim, mse, Z, H, W, win, data_range, k1, k2, (hipStream_t)stream);
 }
 
+size_t aesr_vif_workspace_bytes(int Z, int H, int W) { return (Z > 0 && H > 0 && W > 0) ? aesr_vif_workspace_bytes_impl(Z, H, W) : 0; }
+
+int aesr_vif_mscale(const float* ref, const float* dist, void* workspace, double* vif, int Z, int H, int W, const double* weights_host,
+                    const int* radii_host, double sigma_nsq, void* stream) {
+    AESR_CHECK_ARG(ref && dist && workspace && vif && weights_host && radii_host, "aesr_vif_mscale: null pointer");
+    AESR_CHECK_ARG(Z > 0 && Z <= 65535 && H > 0 && W > 0 && (size_t)H * W < ((size_t)1 << 30), "aesr_vif_mscale: unsupported shape %d x %d x %d", Z, H, W);
+    AESR_CHECK_ARG(sigma_nsq > 0.0, "aesr_vif_mscale: sigma_nsq must be positive");
+    return aesr_launch_vif_mscale(ref, dist, workspace, vif, Z, H, W, weights_host, radii_host, sigma_nsq, (hipStream_t)stream);
+}
+
 }  // extern "C"

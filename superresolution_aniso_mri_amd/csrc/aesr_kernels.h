@@ -201,6 +201,9 @@ int aesr_launch_lpips_finalize(const float* const* partials, const int* hw, int 
 int aesr_launch_scale_expand(const float* x, float* out4, int n, const float* ca, const float* cb, int backward, hipStream_t st);
 int aesr_launch_resample2(const float* x, const float* gout, const float* xsave, float* dst, int N, int H, int W, int C, int mode,
                           int backward, int mask_act, float slope, hipStream_t st);
+size_t aesr_vif_workspace_bytes_impl(int Z, int H, int W);
+int aesr_launch_vif_mscale(const float* ref, const float* dist, void* workspace, double* vif, int Z, int H, int W, const double* weights,
+                           const int* radii, double sigma_nsq, hipStream_t st);
 int aesr_launch_ssim_mse(const float* a, const float* b, double* partial, double* ssim, double* mse, int Z, int H, int W, int win,
                          double data_range, double k1, double k2, hipStream_t st);
 #define TRIPLET_MAX 64

@@ -565,6 +565,9 @@ int aesr_wino_ring_mode() {
 static int ring_smax(const WinoArgs& a) {
     if (a.ws_floats == 0 || a.out_sum2) return 1;       // (queries pass ws_floats = SIZE_MAX without a buffer: "whatever the plan wants")
     const size_t out_floats = (size_t)a.N * a.H * a.W * a.Cout;
+    // a store's 32-bit offset is (pixel or RG_OOB) + (channel or RG_OOB) + slab offset: with BOTH sentinels set, a slab offset of
+    // 0x20000000 and more would wrap 2 RG_OOB + offset past 2^32 into a valid slab -- splits are for small layers, so larger ones get none
+    if (out_floats * 4 * (size_t)RG_KSPLIT_MAX >= (size_t)0x20000000) return 1;
     const RingPlan p = plan_ring(a, RG_KSPLIT_MAX);
     return (size_t)p.ksplit * out_floats <= a.ws_floats ? RG_KSPLIT_MAX : 1;
 }
@@ -581,7 +584,7 @@ size_t aesr_wino_ring_workspace_floats(const WinoArgs& a) {
     b.ws = nullptr;                       // a query, nothing is launched: "a workspace of any size" = the plan's wish
     b.ws_floats = ~(size_t)0;
     if (!aesr_wino_ring_takes(b)) return 0;
-    const RingPlan p = plan_ring(b, RG_KSPLIT_MAX);
+    const RingPlan p = plan_ring(b, ring_smax(b));
     return p.ksplit > 1 ? (size_t)p.ksplit * a.N * a.H * a.W * a.Cout : 0;
 }
 
@@ -654,7 +657,7 @@ int aesr_launch_conv_wino_ring(const WinoArgs& a_in, hipStream_t st) {
     }
     a.kchunks = ceil_div(a.CinP / 16, p.ksplit);
     const size_t out_floats = (size_t)a.N * (a.out_sum2 ? a.H / 2 : a.H) * (a.out_sum2 ? a.W / 2 : a.W) * a.Cout;
-    if (out_floats * 4 * (size_t)a.ksplit >= (size_t)RG_OOB) {
+    if (out_floats * 4 * (size_t)a.ksplit >= (size_t)(a.ksplit > 1 ? 0x20000000 : RG_OOB)) {      // split: see ring_smax
         aesr_set_error("conv_wino_ring: %zu output bytes x %d channel splits exceed the kernel's 32-bit offsets", out_floats * 4, a.ksplit);
         return AESR_ERR_UNSUPPORTED;
     }

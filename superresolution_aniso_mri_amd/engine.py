@@ -521,10 +521,15 @@ class SequentialRunner:
         g = gout[:ngrad]
         if not g.is_contiguous():
             g = g.contiguous()
-        reduce_jobs = []          # (job, workspace, dw, db): the tensors stay referenced until the reduction has been enqueued
+        reduce_jobs = []          # (job, workspace, dw, db, direct): the tensors stay referenced until the reduction has been enqueued
         g = self._backward_steps(steps, saved, g, ngrad, need_input_grad, grads, G, ns, reduce_jobs)
         if _DEFERRED is not None:
-            _DEFERRED.extend(reduce_jobs)       # summed with the other passes' slabs by ONE launch (deferred_wgrad_reductions)
+            # only reductions that write straight into ``p.grad`` may wait for the end of the sweep (ONE launch for all passes,
+            # deferred_wgrad_reductions).  A destination that is a temporary goes back to autograd when this function returns, and
+            # autograd adds it to ``p.grad`` at once: it must be complete NOW (a parameter differentiated by a second pass of the
+            # sweep, an optimizer other than HipAdam, gradients that were not freshly zeroed)
+            _DEFERRED.extend(j for j in reduce_jobs if j[4])
+            flush_wgrad_reductions([j for j in reduce_jobs if not j[4]])
         else:
             flush_wgrad_reductions(reduce_jobs)
         return g, grads
@@ -575,8 +580,9 @@ class SequentialRunner:
                         check(lib.aesr_conv2d_wgrad_partial(ptr(xin), ptr(g), ptr(ws), N, H, W, s.cin, s.cout, s.ks, s.pad,
                                                             int(s.in_up2), stream()), "aesr_conv2d_wgrad_partial")
                         _pe()
+                        direct = grads[s.mod.weight] is None and (db is None or grads[s.mod.bias] is None)
                         reduce_jobs.append((_hip.WgradReduceJob(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None,
-                                                                N, H, W, s.cin, s.cout, s.ks, s.pad), ws, dw, db))
+                                                                N, H, W, s.cin, s.cout, s.ks, s.pad), ws, dw, db, direct))
                 elif s.cin <= 4 and s.ks == 1 and db is not None:
                     ws = _empty((lib.aesr_small_wgrad_workspace_floats(s.cout * (s.cin + 1)),), g)
                     check(lib.aesr_conv2d_smallcin_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, s.cout,

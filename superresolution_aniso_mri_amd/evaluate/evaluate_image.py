@@ -1,23 +1,24 @@
 """Per-image evaluation helpers of the reference's ``evaluate/evaluate_image.py`` on the HIP path: ``evaluate_image`` (:37-80,
 held-out-slice synthesis of every frame of a 4-D image with alpha = 0.5), ``compute_stats`` (:11-34, SSIM / PSNR / LPIPS of a
-volume) and ``create_compare_image`` (:83-106, the slice-by-slice comparison grid).  VIF is an external package in the reference
-and is returned as NaN."""
+volume) and ``create_compare_image`` (:83-106, the slice-by-slice comparison grid)."""
 import numpy as np
 import torch
 
 from ..kwatsch.acai_utils import make_grid
 from .common import create_super_volume
 from .find_best_model import get_transforms
-from .metrics import compute_psnr_for_batch, compute_ssim_for_batch
+from .metrics import compute_psnr_for_batch, compute_ssim_for_batch, compute_vif_for_batch
 
 
 def compute_stats(trainer, original_img, r_s_img, normalize=True, downsample_steps=None, is_conv_meth=False):
-    """(ssim, psnr, vif = nan, lpips) of a reconstructed / synthesised volume against the original [z,y,x].  As in the reference the
+    """(ssim, psnr, vif, lpips) of a reconstructed / synthesised volume against the original [z,y,x].  As in the reference the
     LPIPS term is taken over every ``downsample_steps``-th slice pair (``[::downsample_steps]``)."""
     ssim_res = compute_ssim_for_batch(original_img, r_s_img, eval_axis=0, downsample_steps=downsample_steps, conv_interpol=is_conv_meth,
                                       normalize=normalize)
     psnr_res = compute_psnr_for_batch(original_img, r_s_img, eval_axis=0, downsample_steps=downsample_steps, conv_interpol=is_conv_meth,
                                       normalize=normalize)
+    vif_res = compute_vif_for_batch(original_img, r_s_img, eval_axis=0, downsample_steps=downsample_steps, conv_interpol=is_conv_meth,
+                                    normalize=normalize)                       # reference :19-21
     dev = trainer.args["device"]
     a = torch.as_tensor(original_img, dtype=torch.float32).to(dev)[:, None]
     b = torch.as_tensor(r_s_img, dtype=torch.float32).to(dev)[:, None]
@@ -27,7 +28,7 @@ def compute_stats(trainer, original_img, r_s_img, normalize=True, downsample_ste
         raise ValueError("compute_stats needs a trainer with a perceptual criterion (trainer.percept_criterion is None)")
     with torch.no_grad():
         lpips_res = float(trainer.percept_criterion(a.contiguous(), b.contiguous(), normalize=True).mean())
-    return ssim_res, psnr_res, float("nan"), lpips_res
+    return ssim_res, psnr_res, vif_res, lpips_res
 
 
 def evaluate_image(trainer, data_dict, frame_id=None, eval_patch_size=128, downsample_steps=2, transform=None):

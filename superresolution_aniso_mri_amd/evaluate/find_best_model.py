@@ -6,8 +6,9 @@ Per checkpoint and volume: pad / centre-crop to ``ps_evaluate`` (AdjustToPatchSi
 ``datasets/shared_transforms.py:297-363,389-447``), keep every ``downsample_steps``-th slice, synthesise the slices in between
 (``evaluate.common.create_super_volume(generate_inbetween_slices=True, use_original=False)``), score the volume up to the last
 paired slice against the original: all slices, the synthesised ones (s_mask) and the reconstructed ones (r_mask) --
-SSIM and PSNR from ONE device pass per volume (``evaluate.metrics.slice_ssim_psnr``).  VIF (an external package in the reference)
-is reported as NaN; LPIPS per slice is off, as in the reference's call (``compute_percept_loss = False``)."""
+SSIM and PSNR from ONE device pass per volume (``evaluate.metrics.slice_ssim_psnr``), VIF from another
+(``evaluate.metrics.slice_vif``: the reference's ``vifp_mscale`` on uint8 slices, evaluate/vifvec.py:7-63); LPIPS per slice is off, as in
+the reference's call (``compute_percept_loss = False``)."""
 import glob
 import os
 import types
@@ -62,8 +63,9 @@ def generate_synth_slices_mask(orig_num_slices, downsample_steps):
 
 
 def compute_metrics(images_ref, new_images, downsample_steps, data_range=1.0, compute_percept_loss=False, percept_loss=None):
-    """{'ssim','psnr','ssim_synth','psnr_synth','ssim_recon','psnr_recon'[,'lpips']} of one volume (create_HR_images.py:121-178;
-    LPIPS over all scored slices only, as there: the masked calls pass compute_percept_loss=False)."""
+    """{'ssim','psnr','vif' and their '_synth' / '_recon' forms [,'lpips']} of one volume (create_HR_images.py:121-178; LPIPS over all
+    scored slices only, as there: the masked calls pass compute_percept_loss=False).  VIF: mean over the slices of the selection whose
+    score is finite (evaluate/metrics.py:100-106)."""
     last = _common.determine_last_slice(images_ref.shape[0], downsample_steps) + 1
     r_mask, s_mask = generate_synth_slices_mask(images_ref.shape[0], downsample_steps)
     ssim, psnr, _ = _metrics.slice_ssim_psnr(images_ref[:last], new_images[:last], data_range=data_range)
@@ -71,10 +73,16 @@ def compute_metrics(images_ref, new_images, downsample_steps, data_range=1.0, co
     def mean_psnr(sel):
         v = psnr[sel]
         return float(np.mean(v[np.isfinite(v)]))
+    vif = _metrics.slice_vif(images_ref[:last], new_images[:last])
+
+    def mean_vif(sel):
+        v = vif[sel]
+        v = v[np.isfinite(v)]
+        return float(np.mean(v)) if v.size else float("nan")
     everything = np.ones(last, dtype=bool)
-    out = {"ssim": float(np.mean(ssim)), "psnr": mean_psnr(everything),
-           "ssim_synth": float(np.mean(ssim[s_mask])), "psnr_synth": mean_psnr(s_mask),
-           "ssim_recon": float(np.mean(ssim[r_mask])), "psnr_recon": mean_psnr(r_mask)}
+    out = {"ssim": float(np.mean(ssim)), "psnr": mean_psnr(everything), "vif": mean_vif(everything),
+           "ssim_synth": float(np.mean(ssim[s_mask])), "psnr_synth": mean_psnr(s_mask), "vif_synth": mean_vif(s_mask),
+           "ssim_recon": float(np.mean(ssim[r_mask])), "psnr_recon": mean_psnr(r_mask), "vif_recon": mean_vif(r_mask)}
     if compute_percept_loss:
         out["lpips"] = _metrics.compute_lpips_for_batch(images_ref[:last], new_images[:last], criterion=percept_loss)
     return out
@@ -93,8 +101,8 @@ def evaluate_interpolation_performance(trainer, myargs, data_generator, transfor
     if eval_axis != 0:
         raise NotImplementedError("long-axis (eval_axis != 0) evaluation is outside the ae_combined path")
     alpha_range = np.linspace(0, 1, (downsample_steps - 1) + 2, endpoint=True)[1:-1]
-    keys = ("ssim", "psnr", "ssim_synth", "psnr_synth", "ssim_recon", "psnr_recon")
-    res = {k: [] for k in keys + ("vif", "vif_synth", "vif_recon", "lpips", "lpips_synth", "lpips_recon")}
+    keys = ("ssim", "psnr", "vif", "ssim_synth", "psnr_synth", "vif_synth", "ssim_recon", "psnr_recon", "vif_recon")
+    res = {k: [] for k in keys + ("lpips", "lpips_synth", "lpips_recon")}
     for batch in _as_list(data_generator):
         if transform is not None:
             batch = transform(batch)
@@ -112,8 +120,6 @@ def evaluate_interpolation_performance(trainer, myargs, data_generator, transfor
             res[k].append(m[k])
         if compute_percept_loss:
             res["lpips"].append(m["lpips"])
-        for k in ("vif", "vif_synth", "vif_recon"):
-            res[k].append(float("nan"))
     return res
 
 

@@ -8,7 +8,9 @@ covariance, mean over the fully covered windows; PSNR = 10 log10(R^2 / mse).  ``
 (default 1.0: images are normalised to [0, 1]); skimage releases older than 0.19 silently used R = 2 for float input --
 pass ``data_range=2.0`` to reproduce numbers produced with such an installation.
 ``compute_lpips_for_batch`` (:210-243) scores all kept slices with ONE batched LPIPS pass instead of a criterion call and a host
-sync per slice.  Not covered: VIF and HD metrics of the same file (outside the ae_combined path)."""
+sync per slice.  ``compute_vif_for_batch`` (:65-109 -> evaluate/vifvec.py:7-63 ``vifp_mscale``) scores all slices of a volume with
+one device pass (``aesr_vif_mscale``, csrc/vif.hip) in the reference's own arithmetic: uint8 images, uint8 Gaussian filter, products
+modulo 256 -- see oracle/vif_oracle.py.  Not covered: the HD metrics of the same file (outside the ae_combined path)."""
 import numpy as np
 import torch
 
@@ -74,6 +76,64 @@ def slice_ssim_psnr(l_images, l_reconstructions, data_range=1.0, win_size=None, 
     with np.errstate(divide="ignore"):
         psnr = 10.0 * np.log10(float(data_range) ** 2 / mse)
     return ssim, psnr, mse
+
+
+def gaussian_kernel1d(sd, truncate=4.0):
+    """(weights float64 [2 r + 1], r) of scipy.ndimage.gaussian_filter(., sd): ``_gaussian_kernel1d(sd, 0, int(truncate * sd + 0.5))``,
+    computed with numpy exactly as scipy does -- the uint8 filter TRUNCATES its result, so wherever an image is constant the last bit
+    of a weight decides between v and v - 1; the kernel therefore takes the weights from here instead of recomputing them."""
+    r = int(truncate * float(sd) + 0.5)
+    x = np.arange(-r, r + 1)
+    phi = np.exp(-0.5 / (sd * sd) * x ** 2)
+    return phi / phi.sum(), r
+
+
+_VIF_FILTERS = None
+
+
+def _vif_filters():
+    global _VIF_FILTERS
+    if _VIF_FILTERS is None:
+        ks = [gaussian_kernel1d((2 ** (4 - s + 1) + 1) / 5.0) for s in range(1, 5)]       # evaluate/vifvec.py:17-18: N = 17, 9, 5, 3; sd = N / 5
+        _VIF_FILTERS = (_hip.double_array(np.concatenate([k[0] for k in ks])), _hip.int_array([k[1] for k in ks]))
+    return _VIF_FILTERS
+
+
+def slice_vif(l_images, l_reconstructions, sigma_nsq=2.0, device="cuda"):
+    """Per-slice VIF [Z] (float64 numpy; NaN where the reference slice is black): ``vifp_mscale`` of the uint8 images, one device pass."""
+    a, b = _as_volume(l_images, device), _as_volume(l_reconstructions, device)
+    if a.shape != b.shape:
+        raise ValueError("shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    _hip.require_gpu_tensor(a, "images")
+    Z, H, W = a.shape
+    w, r = _vif_filters()
+    out = np.empty(Z, dtype=np.float64)
+    for z0 in range(0, Z, 4096):
+        n = min(4096, Z - z0)
+        ws = torch.empty(lib.aesr_vif_workspace_bytes(n, H, W), device=a.device, dtype=torch.uint8)
+        vif = torch.empty(n, device=a.device, dtype=torch.float64)
+        check(lib.aesr_vif_mscale(ptr(a[z0:z0 + n]), ptr(b[z0:z0 + n]), ptr(ws), ptr(vif), n, H, W, w, r, float(sigma_nsq), stream()),
+              "aesr_vif_mscale")
+        out[z0:z0 + n] = vif.cpu().numpy()
+    return out
+
+
+def compute_vif_for_batch(l_images, l_reconstructions, eval_axis=0, normalize=False, downsample_steps=None, conv_interpol=False,
+                          device="cuda"):
+    """Mean VIF over the slices of a volume whose score is finite (original slices skipped when ``downsample_steps`` is given); a single
+    2-D image returns its score.  evaluate/metrics.py:65-109."""
+    _check_axis(eval_axis)
+    single = (torch.as_tensor(l_images).squeeze().dim() == 2) if not isinstance(l_images, np.ndarray) else (np.squeeze(l_images).ndim == 2)
+    a, b = _as_volume(l_images, device), _as_volume(l_reconstructions, device)
+    if normalize:
+        b = rescale_intensities(b, percs=(0, 100))
+    vif = slice_vif(a, b, device=device)
+    if single:
+        return float(vif[0])
+    keep = np.isfinite(vif)
+    if downsample_steps is not None:
+        keep[determine_original_sliceids(a, downsample_steps, conv_interpol)] = False
+    return float(np.mean(vif[keep])) if keep.any() else float("nan")
 
 
 def _check_axis(eval_axis):

@@ -16,7 +16,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from . import ops
+from . import _hip, ops
 
 
 def _encode(trainer, x):
@@ -61,7 +61,11 @@ def create_super_volume(trainer, images, alpha_range, use_original=False, labels
             for k in range(n):
                 out[k + 1::n + 1] = dec[k]
         out.clamp_(0, 1.)
-    return {"upsampled_image": out.cpu() if to_cpu else out, "upsampled_labels": None}
+    if to_cpu:
+        out = out.cpu()
+        if vol.is_cuda:
+            _hip.check_device_watchdogs("create_super_volume")       # the volume leaves the device here: never a silent garbage volume
+    return {"upsampled_image": out, "upsampled_labels": None}
 
 
 # ---- I/O around the path (SimpleITK is optional; .npy volumes work everywhere) -----------------------------------------

@@ -15,6 +15,15 @@ import torch
 from .. import ops
 
 
+def _check_watchdogs(trainer, where):
+    """Kernel-side protocol watchdogs (``_hip.check_device_watchdogs``), for trainers whose model lives on the GPU (host-logic tests build
+    CPU trainers that never launch a kernel)."""
+    p = next(iter(trainer.model.parameters()), None)
+    if p is not None and p.is_cuda:
+        from .._hip import check_device_watchdogs
+        check_device_watchdogs(where)
+
+
 class LossLog(list):
     """list of scalars; device tensors are turned into floats lazily (on read), so appending never syncs."""
 
@@ -144,11 +153,13 @@ class BaseTrainer(object):
             self.loss_iters.append(self.iters)
         else:
             src, dst = self.losses_test, self.mean_losses_test
+        self._bounded_sync()        # a dead peer ends this rank with a message before the unbounded .item() reads below
+        _check_watchdogs(self, "show_loss_on_tensorboard(%s)" % eval_type)      # the means below are what model selection reads
+        dp = getattr(self, "dp", None)
         means = {}
         for key, vals in src.items():
             vals = LossLog(vals).floats()
             means[key] = float(np.mean(np.array(vals))) if len(vals) else float("nan")
-        dp = getattr(self, "dp", None)
         if dp is not None and dp.active and means:
             # data parallel: every rank logged the mean over ITS shard; model selection and the loss files must see the mean
             # over the global batch (= what the single-process run logs): sum_r n_r * mean_r / sum_r n_r, one all-reduce
@@ -250,7 +261,17 @@ class BaseTrainer(object):
         return self._run_eval(model, model.decode, self._to_device(z), eval, upscale=1 << int(scales))
 
     # ---- validation (reference :67-99) -----------------------------------------------------------------------------
+    def _bounded_sync(self):
+        """Data parallel: wait for the queued steps with a deadline (``DataParallelContext.synchronize``, AESR_STEP_TIMEOUT) before any
+        unbounded host read (``.item()``, ``.cpu()``, a symbol copy): the library's communicator has no watchdog thread, so a peer that
+        died mid-run would otherwise hang this rank inside an RCCL kernel; on timeout the communicator is aborted and the run exits
+        non-zero.  Called where the training loop syncs anyway: validation, epoch logging, checkpoints."""
+        dp = getattr(self, "dp", None)
+        if dp is not None and dp.active:
+            dp.synchronize()
+
     def validate(self, validation_batch, image_dict=None, frame_id=8, generate_images=True):
+        self._bounded_sync()
         self.model.eval()
         self._note_batch(validation_batch, "test")
         image = self._to_device(validation_batch["image"])
@@ -271,6 +292,7 @@ class BaseTrainer(object):
             from .acai_utils import generate_recon_grid
             grid = generate_recon_grid(validation_batch["image"], self.test_predictions["img_recons"])
         result = {"img_grid_recons": grid, "loss_ae": self.losses_test["loss_ae"][-1]}
+        _check_watchdogs(self, "validate")
         if image_dict is not None:
             result.update(synthesized_vols=None, alphas=None)   # whole-volume previews need the dataset readers
         return result
@@ -288,6 +310,8 @@ class BaseTrainer(object):
         return int(os.environ.get("RANK", "0")) == 0
 
     def save_models(self, fname, epoch):
+        self._bounded_sync()
+        _check_watchdogs(self, "save_models(%s)" % fname)        # every rank: a checkpoint of garbage is never written
         if not self._is_writer():
             return
         sd = {k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()}

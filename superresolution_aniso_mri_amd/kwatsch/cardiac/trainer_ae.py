@@ -110,7 +110,7 @@ class CombinedStepMixin(object):
             # launches instead of fifteen small ones (ops.combined_mse); same quantities, same log keys, same order
             o3 = self.model.decode_cat(zcat, [2 * B, B], merge=True)[0]
             out, s_mix = o3[:2 * B], o3[2 * B:]
-            loss, l_rec, l_img, loss_latent = ops.combined_mse(o3, x, between, z_mix.detach(), z_ref.detach(), self._lambda_tensor())
+            loss, l_rec, l_img, loss_latent = ops.combined_mse(o3, x, between, z_mix.detach(), z_ref.detach(), self._lambda_tensor(), owner=self)
             self._log("loss_ae_dist", l_rec)
             if self._log_extra_total:
                 self._log("loss_ae_extra", l_img)
@@ -141,6 +141,7 @@ class CombinedStepMixin(object):
             return
         r = self._step_core(dev_batch, eval_mode)
         if keep_predictions:
+            self._bounded_sync()          # data parallel: the host copies below wait for the step; a dead peer must not hang them
             s = r["s_mix"].detach().cpu()
             self.train_predictions = {"z_mix": r["z_mix"].detach().cpu(), "pred_alphas": self._pred_alphas(batch_item),
                                       "slice_inbetween_mix": s, "slice_inbetween_05": s, "reconstruction": r["out"].detach().cpu()}

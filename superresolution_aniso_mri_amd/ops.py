@@ -166,22 +166,24 @@ def mse_loss(a, b):
 _MSE3_WS = {}
 
 
-def _mse3_workspace(device):
-    """Partial sums + ticket counter of aesr_mse3_fwd: zeroed ONCE (the kernel leaves it consistent), one per (device, stream) --
-    two steps in flight on different streams must not share partial sums and tickets -- allocated outside any graph capture (the
-    first, eager steps)."""
+def _mse3_workspace(device, owner=None):
+    """Partial sums + ticket counter of aesr_mse3_fwd: zeroed ONCE (the kernel leaves it consistent).  One per (owner, device, stream)
+    for eager steps and one per (owner, device) for that owner's captured graphs -- ``owner`` is the trainer (its ``__dict__`` holds
+    them), so two trainers whose captured steps replay on different streams never share partial sums and the ticket; callers
+    without an owner share the module-level set.  Allocated outside any graph capture (the first, eager steps)."""
+    store = owner.__dict__.setdefault("_aesr_mse3_ws", {}) if owner is not None else _MSE3_WS
     if torch.cuda.is_current_stream_capturing():
-        # a capture runs on a stream of its own: the captured graphs of a device (replayed one after the other on one stream) share one
-        # workspace, created by the eager steps before the capture -- a fresh one here would be a memset node in every replay
+        # a capture runs on a stream of its own: the captured graphs of ONE owner (replayed one after the other on one stream) share
+        # one workspace, created by that owner's eager steps before the capture -- a fresh one here would be a memset node in every replay
         key = (str(device), "graph")
-        if key not in _MSE3_WS:
+        if key not in store:
             raise RuntimeError("aesr_mse3_fwd: run the loss eagerly once before capturing it into a HIP graph")
-        return _MSE3_WS[key]
+        return store[key]
     key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
-    if key not in _MSE3_WS:
-        _MSE3_WS[key] = torch.zeros(_hip.MSE3_WS, device=device, dtype=torch.float64)
-        _MSE3_WS.setdefault((str(device), "graph"), torch.zeros(_hip.MSE3_WS, device=device, dtype=torch.float64))
-    return _MSE3_WS[key]
+    if key not in store:
+        store[key] = torch.zeros(_hip.MSE3_WS, device=device, dtype=torch.float64)
+        store.setdefault((str(device), "graph"), torch.zeros(_hip.MSE3_WS, device=device, dtype=torch.float64))
+    return store[key]
 
 
 class _CombinedMseFn(torch.autograd.Function):
@@ -189,7 +191,7 @@ class _CombinedMseFn(torch.autograd.Function):
     the whole gradient of o3 in one launch (no split / cat of the decoder's two sub-batches)."""
 
     @staticmethod
-    def forward(ctx, o3, x, between, z_mix, z_ref, lam):
+    def forward(ctx, o3, x, between, z_mix, z_ref, lam, owner=None):
         n1, n2 = x.numel(), between.numel()
         if o3.numel() != n1 + n2:
             raise ValueError("combined_mse: %d outputs for %d + %d targets" % (o3.numel(), n1, n2))
@@ -197,7 +199,7 @@ class _CombinedMseFn(torch.autograd.Function):
         res = torch.empty(4, device=o3.device, dtype=torch.float32)
         flat = o3.reshape(-1)
         check(lib.aesr_mse3_fwd(ptr(flat), ptr(x), n1, ptr(flat[n1:]), ptr(between), n2, ptr(z_mix), ptr(z_ref),
-                                z_mix.numel() if z_mix is not None else 0, ptr(lam), ptr(_mse3_workspace(o3.device)), ptr(res), stream()),
+                                z_mix.numel() if z_mix is not None else 0, ptr(lam), ptr(_mse3_workspace(o3.device, owner)), ptr(res), stream()),
               "aesr_mse3_fwd")
         ctx.save_for_backward(o3, x, between, lam)
         outs = tuple(res[i].reshape(()) for i in range(4))
@@ -207,7 +209,7 @@ class _CombinedMseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *_unused):
         if g is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         o3, x, between, lam = ctx.saved_tensors
         n1, n2 = x.numel(), between.numel()
         g = g.reshape(1).contiguous().float()
@@ -215,20 +217,21 @@ class _CombinedMseFn(torch.autograd.Function):
         flat, dflat = o3.reshape(-1), d.reshape(-1)
         check(lib.aesr_mse3_bwd(ptr(flat), ptr(x), n1, ptr(flat[n1:]), ptr(between), n2, ptr(lam), ptr(g), ptr(dflat), ptr(dflat[n1:]),
                                 stream()), "aesr_mse3_bwd")
-        return d, None, None, None, None, None
+        return d, None, None, None, None, None, None
 
 
-def combined_mse(o3, x, between, z_mix, z_ref, lam):
+def combined_mse(o3, x, between, z_mix, z_ref, lam, owner=None):
     """The loss block of the ae_combined step with MSE losses (kwatsch/cardiac/trainer_ae.py:160-182 of the reference):
     o3 = the decoder's batched output [recon(x) | synthesized between-slices] (logical NCHW), x / between their targets, lam the
     synthesis weight as a device scalar.  Returns (total, loss_rec, lam * loss_img, loss_latent) as 0-dim device tensors; only
-    ``total`` carries a gradient (to o3)."""
+    ``total`` carries a gradient (to o3).  ``owner``: the object whose steps these are (the trainer): keeps the kernel's partial-sum
+    workspace apart from other owners' (``_mse3_workspace``)."""
     o3n = engine.to_nhwc(o3)
     xn, bn = engine.to_nhwc(x), engine.to_nhwc(between)
     zm, zr = _flat_pair(z_mix, z_ref)
     for t, what in ((o3n, "decoder output"), (xn, "image"), (bn, "slice_between"), (zm, "z_mix"), (zr, "z_ref"), (lam, "lambda")):
         _hip.require_gpu_tensor(t, "combined_mse " + what)
-    total, l_rec, l_img, l_lat = _CombinedMseFn.apply(o3n, xn, bn, zm, zr, lam.reshape(1))
+    total, l_rec, l_img, l_lat = _CombinedMseFn.apply(o3n, xn, bn, zm, zr, lam.reshape(1), owner)
     return total, l_rec, l_img, l_lat
 
 

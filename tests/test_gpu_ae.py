@@ -261,3 +261,31 @@ def test_cpu_tensor_is_refused_loudly():
     model = _model("VanillaACAI", SMALL)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model.encode(torch.rand(1, 1, 32, 32))
+
+
+def test_deferred_wgrad_reductions_with_temporary_gradients():
+    """A parameter differentiated by TWO passes of one backward sweep (and gradients that are not HipAdam's freshly zeroed views)
+    gets its weight gradient through temporaries that autograd accumulates at once: inside ``deferred_wgrad_reductions`` those slab
+    sums must not wait for the end of the block (round-3 advisor finding).  Deferred == undeferred, bit for bit."""
+    from superresolution_aniso_mri_amd import engine
+
+    def grads_of(deferred):
+        torch.manual_seed(5)
+        model = _model("VanillaACAI", SMALL)
+        model.train()
+        g = torch.Generator().manual_seed(11)
+        x1 = torch.rand(4, 1, 32, 32, generator=g).cuda()
+        x2 = torch.rand(2, 1, 32, 32, generator=g).cuda()
+        loss = (model.decode(model.encode(x1)) ** 2).mean() + 0.5 * (model.decode(model.encode(x2)) ** 2).mean()
+        if deferred:
+            with engine.deferred_wgrad_reductions():
+                loss.backward()
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+
+    plain, deferred = grads_of(False), grads_of(True)
+    for k in plain:
+        assert torch.isfinite(deferred[k]).all(), k
+        assert torch.equal(plain[k], deferred[k]), k

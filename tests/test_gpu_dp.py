@@ -234,10 +234,15 @@ def test_two_gpus_rccl_equal_single_process(tmp_path, graph_form, B):
     try:
         mp.spawn(_rccl2_worker, args=(_free_port(), B, out, graph_form, steps), nprocs=2, join=True)
     except Exception as e:                                  # noqa: BLE001
-        if graph_form == "whole":
-            # the opt-in form (multi-rank RCCL collectives captured as graph nodes) has never met two devices before this run: its
-            # failure is a finding about that form, not about the default path -- reported, and the suite goes on
-            pytest.xfail("AESR_DP_GRAPH=whole on two devices: %s" % (str(e)[-400:],))
+        # the opt-in form (multi-rank RCCL collectives captured as graph nodes) has never met two devices before this run.  Only a
+        # REFUSAL to capture (RCCL / HIP saying the operation is not permitted or not supported while a stream is capturing) is an
+        # expected finding about that form; a deadline abort, a GPU fault or a wrong number inside the worker fails the test, so
+        # that its cause is found from this evidence
+        msg = str(e).lower()
+        refused = any(k in msg for k in ("operation not permitted when stream is capturing", "streamcaptureunsupported",
+                                         "capture unsupported", "not supported during capture", "hiperrorstreamcapture"))
+        if graph_form == "whole" and refused and "assert" not in msg and "did not finish within" not in msg:
+            pytest.xfail("AESR_DP_GRAPH=whole on two devices: capture refused: %s" % (str(e)[-400:],))
         raise
     res = torch.load(out)
     assert res["graph_dp"] == graph_form or graph_form is None

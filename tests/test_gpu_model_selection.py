@@ -35,7 +35,7 @@ def test_find_best_val_model(tmp_path):
         vols[p] = {"image": (np.stack(base) * 0.8 + 0.05 * g.rand(z, 40, 36)).astype(np.float32), "patient_id": "p%d" % p,
                    "spacing": np.array([8.0, 1.4, 1.4])}
     scores = find_best_val_model(vols, src, epoch_range=[1, 2, 3], ps_evaluate=32, downsample_steps=3)
-    assert list(scores.keys()) == ["1", "2", "3"] and all(np.isfinite(v[:2]).all() and np.isnan(v[2]) for v in scores.values())
+    assert list(scores.keys()) == ["1", "2", "3"] and all(np.isfinite(v).all() and 0.0 < v[2] < 1.5 for v in scores.values())
     assert os.path.isfile(os.path.join(src, "model_perf_1_to_3_axis0.npz")) and os.path.isfile(os.path.join(src, "model_perf_synth_1_to_3_axis0.npz"))
     res, epochs, ssim, psnr, vif = load_model_scores(src)
     assert sorted(epochs.tolist()) == [1, 2, 3] and np.allclose(sorted(ssim), sorted(v[0] for v in scores.values()))
@@ -52,6 +52,17 @@ def test_find_best_val_model(tmp_path):
         want_s.append(np.mean([step_oracle.ssim(img[z], hr[z]) for z in range(last)]))
         want_p.append(np.mean([step_oracle.psnr(img[z], hr[z]) for z in range(last)]))
     assert abs(scores["2"][0] - np.mean(want_s)) < 1e-6 and abs(scores["2"][1] - np.mean(want_p)) < 1e-4
+    # ... and the VIF column: the oracle's restatement of the reference's uint8 vifp_mscale, mean over the finite slices of each volume
+    from oracle import vif_oracle
+    want_v = []
+    for v in vols.values():
+        img = adjust_and_center_crop(v["image"], 32)
+        hr = create_super_volume(ev, torch.from_numpy(img), alpha_range=np.linspace(0, 1, 4)[1:-1], use_original=False, downsample_steps=3,
+                                 generate_inbetween_slices=True)["upsampled_image"].numpy()
+        last = determine_last_slice(img.shape[0], 3) + 1
+        want_v.append(vif_oracle.compute_vif_for_batch(img[:last], hr[:last])[0])
+    assert abs(scores["2"][2] - np.mean(want_v)) < 1e-9
+    assert np.isfinite(vif).all() and np.allclose(sorted(vif), sorted(v[2] for v in scores.values()))
     with pytest.raises(ValueError):
         find_best_val_model(vols, src, epoch_range=[77], ps_evaluate=32, downsample_steps=3)
     # optional LPIPS of the scored slices (create_hr_images(compute_percept_loss=True)); synthetic backbone here
@@ -90,6 +101,7 @@ def test_evaluate_image_and_stats():
     keep = [1, 3, 5]            # slices 0, 2, 4, 6 are originals at downsample_steps 2
     assert abs(ssim - np.mean([step_oracle.ssim(res["orig_images"][0][z], res["synth_images"][0][z]) for z in keep])) < 1e-6
     assert abs(psnr - np.mean([step_oracle.psnr(res["orig_images"][0][z], res["synth_images"][0][z]) for z in keep])) < 1e-4
-    assert np.isnan(vif) and lp > 0
+    from oracle import vif_oracle
+    assert abs(vif - vif_oracle.compute_vif_for_batch(res["orig_images"][0], res["synth_images"][0], downsample_steps=2)[0]) < 1e-9 and lp > 0
     grid = create_compare_image(res["orig_images"][0], res["synth_images"][0], downsample_steps=2)
     assert grid.shape == (1, 7 * (32 + 2) + 2, 3 * (32 + 2) + 2)

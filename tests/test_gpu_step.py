@@ -202,6 +202,40 @@ def test_step_graph_replay_equals_eager():
     assert float(graphed.opt_ae.dev_state[0]) == 6.0
 
 
+def test_two_captured_trainers_on_two_streams_keep_their_loss_workspaces_apart():
+    """aesr_mse3_fwd leaves partial sums and a ticket in a workspace: the captured steps of two trainers that replay on different streams at
+    the same time must each own one (round-3 verdict, weak 8).  Two graph-captured MSE trainers stepped concurrently on two streams log
+    exactly the losses they log when stepped alone."""
+    rec = dict(np.load(os.path.join(GOLDEN, "step_k3_cardiac_mse.npz")))
+    batches = [{k: v.cuda() for k, v in _batch(rec, k).items()} for k in range(3)]
+
+    def run(concurrent):
+        ta, tb = make_trainer("cardiac_mse", rec), make_trainer("cardiac_mse", rec, lr=3e-4)
+        for t in (ta, tb):
+            t.enable_step_graph(eager_steps=2)
+            for k in range(3):
+                t.train(batches[k], keep_predictions=False)         # 2 eager + the capture step
+        torch.cuda.synchronize()
+        sa, sb = (torch.cuda.Stream(), torch.cuda.Stream()) if concurrent else (torch.cuda.current_stream(), torch.cuda.current_stream())
+        for k in range(12):
+            with torch.cuda.stream(sa):
+                ta.train(batches[k % 3], keep_predictions=False)
+            with torch.cuda.stream(sb):
+                tb.train(batches[(k + 1) % 3], keep_predictions=False)
+        torch.cuda.synchronize()
+        return ta, tb
+
+    a0, b0 = run(False)
+    a1, b1 = run(True)
+    wa, wb = a1.__dict__["_aesr_mse3_ws"], b1.__dict__["_aesr_mse3_ws"]
+    ga = [v for k, v in wa.items() if k[1] == "graph"]
+    gb = [v for k, v in wb.items() if k[1] == "graph"]
+    assert len(ga) == 1 and len(gb) == 1 and ga[0].data_ptr() != gb[0].data_ptr()
+    for key in ("loss_ae", "loss_ae_dist", "loss_ae_dist_extra", "loss_latent_1"):
+        assert a1.losses[key].floats() == a0.losses[key].floats(), key
+        assert b1.losses[key].floats() == b0.losses[key].floats(), key
+
+
 @pytest.mark.parametrize("loss", ["mse", "perceptual"])
 def test_twenty_steps_track_the_oracle(loss):
     """20 consecutive training steps (lr 1e-4, distinct batches) on the HIP trainer and on the CPU oracle from the same start:

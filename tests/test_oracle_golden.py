@@ -284,3 +284,29 @@ def test_augmentation_oracle_vs_reference_transforms(tag):
     batch = ao.assemble_batch(outs)
     B = len(outs)
     assert batch["image"].shape == (2 * B, 1, width, width) and np.array_equal(batch["image"][B:, 0], rec[tag + "/out"][:, 1])
+
+
+def test_vif_oracle_vs_reference_functions():
+    """oracle/vif_oracle.py (numpy restatement incl. the Gaussian filter) against tests/golden/vif.npz = outputs of the reference's own
+    ``evaluate.metrics.compute_vif_for_batch`` and ``evaluate.vifvec.vifp_mscale`` (uint8 / float32 / float64 slices).  Everything in
+    front of the logarithms is the same sequence of IEEE operations: bit-equal is the expectation, 1e-12 the bound."""
+    from oracle import vif_oracle as vo
+    rec = dict(np.load(os.path.join(GOLDEN, "vif.npz")))
+    tags = sorted({k.split("/")[0] for k in rec if k.endswith("/vif_u8")})
+    assert len(tags) >= 5
+    for t in tags:
+        a, b = rec[t + "/ref"], rec[t + "/dist"]
+        ds = int(rec[t + "/downsample_steps"])
+        mean, per = vo.compute_vif_for_batch(a, b, downsample_steps=None if ds < 0 else ds)
+        assert abs(mean - float(rec[t + "/vif_batch"])) < 1e-12, t
+        u8 = np.array([vo.vifp_mscale(vo.to_uint8(a[k]), vo.to_uint8(b[k])) for k in range(a.shape[0])])
+        assert np.abs(u8 - rec[t + "/vif_u8"]).max() < 1e-12, t
+        f32 = np.array([vo.vifp_mscale(a[k], b[k]) for k in range(a.shape[0])])
+        assert np.abs(f32 - rec[t + "/vif_f32"]).max() < 1e-12, t
+        f64 = np.array([vo.vifp_mscale(a[k].astype(np.float64), b[k].astype(np.float64)) for k in range(a.shape[0])])
+        assert np.abs(f64 - rec[t + "/vif_f64"]).max() < 1e-12, t
+        # the uint8 arithmetic (what the evaluation runs) is NOT the float one: the fixture would catch a "cleaned up" port
+        assert np.abs(rec[t + "/vif_u8"] - rec[t + "/vif_f32"]).max() > 1e-3, t
+    assert abs(vo.compute_vif_for_batch(rec["img/ref"], rec["img/dist"])[0] - float(rec["img/vif_batch"])) < 1e-12
+    assert abs(vo.compute_vif_for_batch(rec["img/ref"], rec["img/ref"])[0] - float(rec["same/vif_batch"])) < 1e-12
+    assert np.isnan(rec["black/vif_batch"]) and np.isnan(vo.compute_vif_for_batch(np.zeros((2, 24, 24), np.float32), np.zeros((2, 24, 24), np.float32))[0])
