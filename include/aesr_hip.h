@@ -49,6 +49,28 @@ typedef struct aesr_pack_job {
 } aesr_pack_job;
 int aesr_conv2d_pack_many(const aesr_pack_job* jobs_host, int njobs, void* stream);
 
+/* ALL parameter-side preparation of a training step in ONE launch per 32 jobs (csrc/prep.hip): what aesr_conv2d_pack_many,
+ * aesr_conv2d_wino_pack_many, aesr_stemconv_fold and the filter flip inside aesr_conv2d_cout1_dgrad do in four to five launches (at a
+ * small data-parallel shard each is a ~5 us graph node).  Same code, bitwise the same results.  kind:
+ *   AESR_PREP_PACK       w [Cout][Cin][KS][KS] -> out = the implicit-GEMM operand (aesr_conv2d_packed_floats), transpose as there
+ *   AESR_PREP_WINO_PACK  ... -> out = U = G g G^T (aesr_conv2d_wino_packed_floats), KS = 3
+ *   AESR_PREP_STEM_FOLD  w = W1 [C1][Cs][3][3], aux0 / aux1 = stem weight / bias [Cs] (aux1 may be NULL), Cout = C1, Cin = Cs
+ *                        -> out = aesr_stemconv_folded_floats(C1) floats (as aesr_stemconv_fold)
+ *   AESR_PREP_COUT1_FLIP w [1][Cin][3][3] -> out [9][Cin], the flipped filter aesr_conv2d_cout1_dgrad_pre takes
+ * The job array is read on the host during the call; pointers are device pointers. */
+#define AESR_PREP_PACK 0
+#define AESR_PREP_WINO_PACK 1
+#define AESR_PREP_STEM_FOLD 2
+#define AESR_PREP_COUT1_FLIP 3
+typedef struct aesr_prep_job {
+    const float* w;
+    const float* aux0;
+    const float* aux1;
+    float* out;
+    int kind, Cout, Cin, KS, transpose;
+} aesr_prep_job;
+int aesr_weight_prep_many(const aesr_prep_job* jobs_host, int njobs, void* stream);
+
 /* out = act(conv(in, w) + bias)                         [MFMA implicit GEMM; Cin % 4 == 0]
  * `packed` from aesr_conv2d_pack(transpose=0).  bias may be NULL.  Ho = H + 2*pad - KS + 1. */
 int aesr_conv2d_fwd(const float* in, const float* packed, const float* bias, float* out, int N, int H, int W, int Cin,
@@ -102,6 +124,9 @@ int aesr_conv2d_cout1_wgrad(const float* x, const float* dy, float* dw, float* d
  * activation that produced the conv's input, or NULL).  Cin = 4 * 2^k <= 256.  workspace: >= 9*Cin floats (the flipped filter). */
 int aesr_conv2d_cout1_dgrad(const float* dy, const float* w, const float* y_saved, float* dx, float* workspace, int N, int H,
                             int W, int Cin, int mask_act, float slope, void* stream);
+/* The same with the flipped filter [9][Cin] prepared beforehand (AESR_PREP_COUT1_FLIP of aesr_weight_prep_many): one launch. */
+int aesr_conv2d_cout1_dgrad_pre(const float* dy, const float* w_flipped, const float* y_saved, float* dx, int N, int H, int W, int Cin,
+                                int mask_act, float slope, void* stream);
 
 /* ---- encoder stem folded into the first 3x3 convolution (networks/acai_vanilla.py:51,55) ------------------------
  * Conv2d(1, Cs, 1, padding=stem_pad) followed directly (no non-linearity) by Conv2d(Cs, C1, 3, padding=1) + activation,

@@ -30,6 +30,15 @@ class WgradReduceJob(ctypes.Structure):
                 ("Cout", c_int), ("KS", c_int), ("pad", c_int)]
 
 
+class PrepJob(ctypes.Structure):
+    """aesr_prep_job of include/aesr_hip.h"""
+    _fields_ = [("w", c_void_p), ("aux0", c_void_p), ("aux1", c_void_p), ("out", c_void_p), ("kind", c_int), ("Cout", c_int), ("Cin", c_int),
+                ("KS", c_int), ("transpose", c_int)]
+
+
+PREP_PACK, PREP_WINO_PACK, PREP_STEM_FOLD, PREP_COUT1_FLIP = 0, 1, 2, 3
+
+
 class PackJob(ctypes.Structure):
     """aesr_pack_job of include/aesr_hip.h"""
     _fields_ = [("w", c_void_p), ("packed", c_void_p), ("Cout", c_int), ("Cin", c_int), ("KS", c_int), ("transpose", c_int)]
@@ -42,6 +51,8 @@ SIGNATURES = {
     "aesr_conv2d_packed_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "aesr_conv2d_pack": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "aesr_conv2d_pack_many": (c_int, [ctypes.POINTER(PackJob), c_int, P]),
+    "aesr_weight_prep_many": (c_int, [ctypes.POINTER(PrepJob), c_int, P]),
+    "aesr_conv2d_cout1_dgrad_pre": (c_int, [P, P, P, P] + [c_int] * 5 + [c_float, P]),
     "aesr_conv2d_fwd": (c_int, [P, P, P, P] + [c_int] * 8 + [c_float, P]),
     "aesr_conv2d_workspace_floats": (c_size_t, [c_int] * 7),
     "aesr_conv2d_dgrad_workspace_floats": (c_size_t, [c_int] * 7),

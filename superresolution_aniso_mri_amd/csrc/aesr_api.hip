@@ -359,6 +359,50 @@ int aesr_conv2d_pack_many(const aesr_pack_job* jobs_host, int njobs, void* strea
     return AESR_OK;
 }
 
+int aesr_weight_prep_many(const aesr_prep_job* jobs_host, int njobs, void* stream) {
+    AESR_CHECK_ARG(jobs_host && njobs > 0, "aesr_weight_prep_many: no jobs");
+    for (int j0 = 0; j0 < njobs; j0 += PACK_MAX_JOBS) {
+        PrepTable t;
+        memset(&t, 0, sizeof(t));
+        t.njobs = njobs - j0 < PACK_MAX_JOBS ? njobs - j0 : PACK_MAX_JOBS;
+        int nb = 0;
+        for (int k = 0; k < t.njobs; ++k) {
+            const aesr_prep_job& jb = jobs_host[j0 + k];
+            AESR_CHECK_ARG(jb.w && jb.out && jb.Cout > 0 && jb.Cin > 0, "aesr_weight_prep_many: bad job %d", j0 + k);
+            PrepJob& o = t.job[k];
+            o.w = jb.w; o.aux0 = jb.aux0; o.aux1 = jb.aux1; o.out = jb.out; o.kind = jb.kind; o.Cout = jb.Cout; o.Cin = jb.Cin; o.KS = jb.KS;
+            o.transpose = jb.transpose; o.block0 = nb;
+            const int kin = jb.transpose ? jb.Cout : jb.Cin, nout = jb.transpose ? jb.Cin : jb.Cout;
+            size_t threads = 0;
+            if (jb.kind == AESR_PREP_PACK) {                       // as aesr_conv2d_pack_many
+                AESR_CHECK_ARG(jb.KS == 1 || jb.KS == 3, "aesr_weight_prep_many: job %d: KS=%d", j0 + k, jb.KS);
+                int NP, NB;
+                cout_padding(nout, &NP, &NB);
+                o.KinP = round_up(kin, 16); o.NoutP = NP; o.TN = 16 * NB;
+                threads = ((size_t)jb.KS * jb.KS * o.KinP * NP + 3) / 4;            // 4 elements per thread
+            } else if (jb.kind == AESR_PREP_WINO_PACK) {           // as aesr_conv2d_wino_pack_many
+                AESR_CHECK_ARG(jb.KS == 3, "aesr_weight_prep_many: job %d: the Winograd transform is for 3x3 filters", j0 + k);
+                o.KinP = round_up(kin, 16); o.NoutP = round_up(nout, 32); o.TN = 32;
+                threads = (size_t)o.KinP * o.NoutP;
+            } else if (jb.kind == AESR_PREP_STEM_FOLD) {           // as aesr_stemconv_fold: Cout = C1, Cin = Cs, aux0 / aux1 = stem weight / bias
+                AESR_CHECK_ARG(jb.aux0, "aesr_weight_prep_many: job %d: stem fold needs the stem weight", j0 + k);
+                threads = (size_t)9 * jb.Cout;
+            } else if (jb.kind == AESR_PREP_COUT1_FLIP) {
+                threads = (size_t)9 * jb.Cin;
+            } else {
+                aesr_set_error("aesr_weight_prep_many: job %d: unknown kind %d", j0 + k, jb.kind);
+                return AESR_ERR_ARG;
+            }
+            int blocks = (int)((threads + 255) / 256);
+            if (blocks > 256) blocks = 256;
+            nb += blocks;
+        }
+        t.nblocks = nb;
+        if (int e = aesr_launch_prep_many(t, (hipStream_t)stream)) return e;
+    }
+    return AESR_OK;
+}
+
 int aesr_conv2d_fwd(const float* in, const float* packed, const float* bias, float* out, int N, int H, int W, int Cin,
                     int Cout, int KS, int pad, int act, float slope, void* stream) {
     AESR_CHECK_ARG(in && packed && out && N > 0 && H > 0 && W > 0, "aesr_conv2d_fwd: null pointer or empty shape");
@@ -708,6 +752,18 @@ int aesr_conv2d_cout1_dgrad(const float* dy, const float* w, const float* y_save
     ThinArgs a;
     memset(&a, 0, sizeof(a));
     a.s = dy; a.w = workspace; a.ysave = y_saved; a.out = dx;
+    a.N = N; a.Hs = H; a.Ws = W; a.Ho = H; a.Wo = W; a.C = Cin; a.ps = 0;
+    a.act = ACT_NONE; a.mask_act = y_saved ? mask_act : ACT_NONE; a.slope = slope;
+    return aesr_launch_thin_expand(a, (hipStream_t)stream);
+}
+
+int aesr_conv2d_cout1_dgrad_pre(const float* dy, const float* w_flipped, const float* y_saved, float* dx, int N, int H, int W, int Cin,
+                                int mask_act, float slope, void* stream) {
+    AESR_CHECK_ARG(dy && w_flipped && dx && N > 0 && H > 0 && W > 0, "aesr_conv2d_cout1_dgrad_pre: null pointer or empty shape");
+    AESR_CHECK_ARG(thin_channels_ok(Cin), "aesr_conv2d_cout1_dgrad_pre: Cin=%d must be 4 times a power of two (4..256)", Cin);
+    ThinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.s = dy; a.w = w_flipped; a.ysave = y_saved; a.out = dx;
     a.N = N; a.Hs = H; a.Ws = W; a.Ho = H; a.Wo = W; a.C = Cin; a.ps = 0;
     a.act = ACT_NONE; a.mask_act = y_saved ? mask_act : ACT_NONE; a.slope = slope;
     return aesr_launch_thin_expand(a, (hipStream_t)stream);

@@ -60,6 +60,11 @@ size_t aesr_wino_lds_bytes(int patch_pixels);
 struct PackJob { const float* w; float* p; int Cout, Cin, KS, KinP, NoutP, TN, transpose, block0; };
 struct PackTable { int njobs, nblocks; PackJob job[PACK_MAX_JOBS]; };
 int aesr_launch_pack_many(const PackTable& t, hipStream_t st);
+// all parameter-side preparation of a step in one launch (prep.hip)
+enum { PREP_PACK = 0, PREP_WINO_PACK = 1, PREP_STEM_FOLD = 2, PREP_COUT1_FLIP = 3 };
+struct PrepJob { const float* w; const float* aux0; const float* aux1; float* out; int kind, Cout, Cin, KS, KinP, NoutP, TN, transpose, block0; };
+struct PrepTable { int njobs, nblocks; PrepJob job[PACK_MAX_JOBS]; };
+int aesr_launch_prep_many(const PrepTable& t, hipStream_t st);
 int aesr_launch_wino_pack_many(const PackTable& t, hipStream_t st);
 
 struct WgradArgs {

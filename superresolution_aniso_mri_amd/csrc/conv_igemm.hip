@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "aesr_kernels.h"
+#include "aesr_pack_dev.h"
 
 
 constexpr int IG_S = 20;     // LDS floats per patch pixel: 16 channels + 4 pad (80 B keeps b128 alignment)
@@ -408,36 +409,7 @@ _Pragma("unroll")  \
 #undef IG_ISSUE_LOADS
 }
 
-// ---- weight packing --------------------------------------------------------------------------------
-// P[ci chunk][cout tile][tap][q(4)][col(TN)][r(4)]   K-side channel kc = chunk*16 + q*4 + r, N-side channel no = tile*TN + col
-// forward : P = W[no][kc][ky][kx],                  tap = ky*KS+kx
-// dgrad   : P = W[kc][no][KS-1-ky][KS-1-kx]         (the "input channels" of the dgrad GEMM are the forward Cout)
-__device__ __forceinline__ void pack_elements(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int KS,
-                                              int KinP, int NoutP, int TN, int transpose, size_t first, size_t stride) {
-    const size_t total = (size_t)KS * KS * KinP * NoutP;
-    const int ncot = NoutP / TN, KS2 = KS * KS;
-    for (size_t idx = first; idx < total; idx += stride) {
-        const int r = idx & 3;
-        size_t rest = idx >> 2;
-        const int col = rest % TN;
-        rest /= TN;
-        const int q = rest & 3;
-        rest >>= 2;
-        const int tap = rest % KS2;
-        rest /= KS2;
-        const int cot = rest % ncot;
-        const int chunk = rest / ncot;
-        const int kc = chunk * 16 + q * 4 + r, no = cot * TN + col;
-        float v = 0.f;
-        if (!transpose) {
-            if (kc < Cin && no < Cout) v = w[(((size_t)no * Cin + kc) * KS + tap / KS) * KS + tap % KS];
-        } else {
-            const int ky = KS - 1 - tap / KS, kx = KS - 1 - tap % KS;
-            if (kc < Cout && no < Cin) v = w[(((size_t)kc * Cin + no) * KS + ky) * KS + kx];
-        }
-        p[idx] = v;
-    }
-}
+// ---- weight packing: pack_elements lives in aesr_pack_dev.h (shared with the one-launch weight preparation, prep.hip) ----
 
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int KS,
                                     int KinP, int NoutP, int TN, int transpose) {

@@ -21,6 +21,7 @@
 // single-channel patch (tile + halo) sits in LDS.  16-byte accesses on the multi-channel side, 1 KiB contiguous per
 // wave.
 #include "aesr_kernels.h"
+#include "aesr_pack_dev.h"
 
 #define THIN_TH 8
 #ifndef THIN_ETH
@@ -280,21 +281,10 @@ __global__ __launch_bounds__(256) void thin_collapse_kernel(const float* __restr
 
 // ---- tiny parameter-side kernels ----------------------------------------------------------------------------------
 
-// folded[0][t][co] = sum_c W1[co,c,t]*ws[c]   folded[1][t][co] = sum_c W1[co,c,t]*bs[c]   (double accumulation)
 __global__ __launch_bounds__(256) void thin_stem_fold_kernel(const float* __restrict__ ws, const float* __restrict__ bs,
                                                              const float* __restrict__ w1, float* __restrict__ folded, int Cs,
                                                              int C1) {
-    for (int o = blockIdx.x * 256 + threadIdx.x; o < 9 * C1; o += gridDim.x * 256) {
-        const int t = o / C1, co = o - t * C1;
-        double sw = 0.0, sb = 0.0;
-        for (int c = 0; c < Cs; ++c) {
-            const double wv = (double)w1[((size_t)co * Cs + c) * 9 + t];
-            sw += wv * (double)ws[c];
-            if (bs) sb += wv * (double)bs[c];
-        }
-        folded[o] = (float)sw;
-        folded[9 * C1 + o] = (float)sb;
-    }
+    stem_fold_elements(ws, bs, w1, folded, Cs, C1, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 // R rows: [0..8] dweff[t][co], [9..17] dbeff[t][co].  Chain rule back to the four parameter tensors.
@@ -341,12 +331,8 @@ __global__ __launch_bounds__(256) void thin_stem_finish_kernel(const float* __re
         for (int co = tid; co < C1; co += nth) db1[co] = R[(9 + 4) * C1 + co];     // centre tap is always inside the grid
 }
 
-// Cout == 1 conv: wexp[t][ci] = W[0,ci,8-t] (flipped filter for the data gradient)
 __global__ __launch_bounds__(256) void thin_cout1_flip_kernel(const float* __restrict__ w, float* __restrict__ wexp, int Cin) {
-    for (int o = blockIdx.x * 256 + threadIdx.x; o < 9 * Cin; o += gridDim.x * 256) {
-        const int t = o / Cin, ci = o - t * Cin;
-        wexp[o] = w[ci * 9 + (8 - t)];
-    }
+    cout1_flip_elements(w, wexp, Cin, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 // Cout == 1 conv: dw[ci*9+k] = R[8-k][ci], db = R[9][0]

@@ -38,6 +38,7 @@
 #include <type_traits>
 
 #include "aesr_kernels.h"
+#include "aesr_pack_dev.h"
 
 constexpr int WN_S = 16;            // LDS floats per patch pixel: 16 channels, no padding (the DMA destination is lane-linear)
 constexpr int WN_NT = 512;          // threads per workgroup
@@ -386,58 +387,7 @@ __global__ __launch_bounds__(WN_NT, 2) void conv_wino_f32(WinoArgs a) {
 #undef WN_DIV
 }
 
-// ---- weight transform + packing ----------------------------------------------------------------------------------------
-// U[ci chunk][cout tile][xi = 4i+j][q(4)][col(32)][r(4)] = (G g G^T)[i][j] for K-side channel kc = chunk*16 + q*4 + r and
-// N-side channel no = tile*32 + col.   forward: g = w[no][kc][.][.];   data gradient: g = flip(w[kc][no][.][.])
-__device__ __forceinline__ void wino_pack_elements(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int KinP,
-                                                   int NoutP, int transpose, size_t first, size_t stride) {
-    // one thread per (chunk, tile, q, col, r) = per (kc, no) pair: reads the 9 taps, writes the 16 positions
-    const size_t pairs = (size_t)KinP * NoutP;
-    const int ncot = NoutP / WN_TN;
-    for (size_t idx = first; idx < pairs; idx += stride) {
-        const int r = idx & 3;
-        size_t rest = idx >> 2;
-        const int col = rest % WN_TN;
-        rest /= WN_TN;
-        const int q = rest & 3;
-        rest >>= 2;
-        const int cot = rest % ncot;
-        const int chunk = rest / ncot;
-        const int kc = chunk * 16 + q * 4 + r, no = cot * WN_TN + col;
-        float gk[3][3];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                float v = 0.f;
-                if (!transpose) {
-                    if (kc < Cin && no < Cout) v = w[(((size_t)no * Cin + kc) * 3 + ky) * 3 + kx];
-                } else {
-                    if (kc < Cout && no < Cin) v = w[(((size_t)kc * Cin + no) * 3 + (2 - ky)) * 3 + (2 - kx)];
-                }
-                gk[ky][kx] = v;
-            }
-        float Gg[4][3];                 // G g: rows g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            Gg[0][kx] = gk[0][kx];
-            Gg[1][kx] = 0.5f * (gk[0][kx] + gk[1][kx] + gk[2][kx]);
-            Gg[2][kx] = 0.5f * (gk[0][kx] - gk[1][kx] + gk[2][kx]);
-            Gg[3][kx] = gk[2][kx];
-        }
-        float* dst = p + ((((size_t)chunk * ncot + cot) * 16) * 4 + q) * (WN_TN * 4) + col * 4 + r;      // + xi * (4*TN*4)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float u0 = Gg[i][0], u3 = Gg[i][2];
-            const float u1 = 0.5f * (Gg[i][0] + Gg[i][1] + Gg[i][2]);
-            const float u2 = 0.5f * (Gg[i][0] - Gg[i][1] + Gg[i][2]);
-            dst[(size_t)(i * 4 + 0) * (4 * WN_TN * 4)] = u0;
-            dst[(size_t)(i * 4 + 1) * (4 * WN_TN * 4)] = u1;
-            dst[(size_t)(i * 4 + 2) * (4 * WN_TN * 4)] = u2;
-            dst[(size_t)(i * 4 + 3) * (4 * WN_TN * 4)] = u3;
-        }
-    }
-}
+// ---- weight transform + packing: wino_pack_elements lives in aesr_pack_dev.h (shared with prep.hip) ----
 
 __global__ __launch_bounds__(256) void wino_pack_many_kernel(PackTable t) {
     int j = 0;

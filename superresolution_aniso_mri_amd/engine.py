@@ -128,6 +128,7 @@ class ConvStep:
         self.packed_t = None    # data-gradient operand
         self.packed_w = None    # forward operand, Winograd-transformed (U = G g G^T)
         self.packed_wt = None   # data-gradient operand, Winograd-transformed
+        self.flipped = None     # Cout == 1: the flipped filter [9][Cin] of the data gradient (aesr_conv2d_cout1_dgrad_pre)
         self.packed_epoch = -1
         self.wino_fwd = (not self.s2d) and wino_ok(self.cin, self.cout, self.ks, self.pad, 0)
         self.wino_dgrad = (not self.s2d) and wino_ok(self.cin, self.cout, self.ks, self.pad, 1)
@@ -298,58 +299,60 @@ class SequentialRunner:
     def mark_weights_dirty(self):
         self.weights_epoch += 1
 
-    # ---- weight packing ------------------------------------------------------------------------------------
-    def _ensure_packed(self, steps):
-        """Refresh the packed MFMA operands of every convolution in ``steps`` whose filter changed since the last call
-        (after an optimizer step: all of them) with ONE aesr_conv2d_pack_many launch."""
-        stale = []
+    # ---- weight preparation ---------------------------------------------------------------------------------
+    def _prep_jobs(self, steps):
+        """(jobs, commits) for every parameter-side operand of ``steps`` that is stale (after an optimizer step: all of them): the
+        packed MFMA operands of the convolutions -- each direction in the form of the kernel that will run it: Winograd where it
+        applies, implicit GEMM otherwise --, the flipped filter of a single-output-channel convolution's data gradient and the
+        folded encoder stem.  ``commits``: closures that mark the operands fresh once the launch has been enqueued."""
+        jobs, commits = [], []
         for s in steps:
+            if s.kind == "stemconv":
+                ws, w1 = s.stem.weight, s.mod.weight
+                epoch = (self.weights_epoch, ws._version, s.stem.bias._version, w1._version, ws.data_ptr(), w1.data_ptr())
+                if s.folded_epoch == epoch:
+                    continue
+                _hip.require_gpu_tensor(w1, "conv weight")
+                n = lib.aesr_stemconv_folded_floats(s.cout)
+                if s.folded is None or s.folded.numel() != n:
+                    s.folded = _empty((n,), w1)
+                jobs.append(_hip.PrepJob(w1.data_ptr(), ws.data_ptr(), s.stem.bias.data_ptr(), s.folded.data_ptr(), _hip.PREP_STEM_FOLD,
+                                         s.cout, s.cs, 3, 0))
+                commits.append(lambda s=s, epoch=epoch: setattr(s, "folded_epoch", epoch))
+                continue
             if s.kind != "conv":
                 continue
             w = s.mod.weight
             epoch = (self.weights_epoch, w._version, w.data_ptr())
-            if s.packed_epoch != epoch:
-                stale.append((s, epoch))
-        if not stale:
-            return
-        jobs, wjobs = [], []
-        for s, _ in stale:
-            _hip.require_gpu_tensor(s.mod.weight, "conv weight")
+            if s.packed_epoch == epoch:
+                continue
+            _hip.require_gpu_tensor(w, "conv weight")
             wk = s.weight_for_kernels()
-            # each direction is packed for the kernel that will run it: Winograd where it applies, implicit GEMM otherwise
-            forms = ((0, "packed", s.cin % 4 == 0 and not s.wino_fwd, False), (1, "packed_t", s.cout % 4 == 0 and not s.wino_dgrad, False),
-                     (0, "packed_w", s.wino_fwd, True), (1, "packed_wt", s.wino_dgrad, True))
-            for transpose, attr, ok, wino in forms:
+            forms = ((0, "packed", s.cin % 4 == 0 and not s.wino_fwd, _hip.PREP_PACK), (1, "packed_t", s.cout % 4 == 0 and not s.wino_dgrad, _hip.PREP_PACK),
+                     (0, "packed_w", s.wino_fwd, _hip.PREP_WINO_PACK), (1, "packed_wt", s.wino_dgrad, _hip.PREP_WINO_PACK))
+            for transpose, attr, ok, kind in forms:
                 if not ok:
                     continue
-                n = (lib.aesr_conv2d_wino_packed_floats(s.cout, s.cin, transpose) if wino
+                n = (lib.aesr_conv2d_wino_packed_floats(s.cout, s.cin, transpose) if kind == _hip.PREP_WINO_PACK
                      else lib.aesr_conv2d_packed_floats(s.cout, s.cin, s.ks, transpose))
                 buf = getattr(s, attr)
                 if buf is None or buf.numel() != n:
                     buf = _empty((n,), wk)
                     setattr(s, attr, buf)
-                (wjobs if wino else jobs).append(_hip.PackJob(wk.data_ptr(), buf.data_ptr(), s.cout, s.cin, s.ks, transpose))
-        if jobs:
-            arr = (_hip.PackJob * len(jobs))(*jobs)
-            check(lib.aesr_conv2d_pack_many(arr, len(jobs), stream()), "aesr_conv2d_pack_many")
-        if wjobs:
-            arr = (_hip.PackJob * len(wjobs))(*wjobs)
-            check(lib.aesr_conv2d_wino_pack_many(arr, len(wjobs), stream()), "aesr_conv2d_wino_pack_many")
-        for s, epoch in stale:
-            s.packed_epoch = epoch
+                jobs.append(_hip.PrepJob(wk.data_ptr(), None, None, buf.data_ptr(), kind, s.cout, s.cin, s.ks, transpose))
+            if s.cout == 1 and s.ks == 3 and s.pad == 1 and _thin_channels(s.cin) and not s.s2d:
+                if s.flipped is None or s.flipped.numel() != 9 * s.cin:
+                    s.flipped = _empty((9 * s.cin,), wk)
+                jobs.append(_hip.PrepJob(wk.data_ptr(), None, None, s.flipped.data_ptr(), _hip.PREP_COUT1_FLIP, 1, s.cin, 3, 0))
+            commits.append(lambda s=s, epoch=epoch: setattr(s, "packed_epoch", epoch))
+        return jobs, commits
 
-    def _ensure_folded(self, s):
-        ws, w1 = s.stem.weight, s.mod.weight
-        epoch = (self.weights_epoch, ws._version, s.stem.bias._version, w1._version, ws.data_ptr(), w1.data_ptr())
-        if s.folded_epoch == epoch:
-            return
-        _hip.require_gpu_tensor(w1, "conv weight")
-        n = lib.aesr_stemconv_folded_floats(s.cout)
-        if s.folded is None or s.folded.numel() != n:
-            s.folded = _empty((n,), w1)
-        check(lib.aesr_stemconv_fold(ptr(ws), ptr(s.stem.bias), ptr(w1), ptr(s.folded), s.cs, s.cout, stream()),
-              "aesr_stemconv_fold")
-        s.folded_epoch = epoch
+    def _ensure_prepared(self, steps):
+        prepare_weights([(self, steps)])
+
+    def train_steps(self):
+        """The step list a training pass runs (the stem-folded one when it exists): what ``prepare_weights`` readies ahead of the pass."""
+        return self.steps_fused if self.steps_fused is not None else self.steps
 
     def forward(self, x, nstart, train, save, fused=True, first=0, last=None, raw_last=False):
         """x: NHWC fp32 [N,H,W,C]; nstart: group boundaries (len G+1).  Returns (out, saved, steps): ``steps`` is the
@@ -363,7 +366,7 @@ class SequentialRunner:
         cur = x
         partial = first != 0 or last is not None
         steps = self.steps_fused if (fused and self.steps_fused is not None and not partial) else self.steps
-        self._ensure_packed(steps)
+        self._ensure_prepared(steps)
         if partial:
             if save:
                 raise RuntimeError("a partial pass keeps nothing for a backward pass")
@@ -374,7 +377,6 @@ class SequentialRunner:
             if s.kind == "stemconv":
                 if C != 1:
                     raise RuntimeError("channel mismatch: tensor has %d channels, the stem expects 1" % C)
-                self._ensure_folded(s)
                 Ho, Wo = s.out_hw(H, W)
                 out = _empty((N, Ho, Wo, s.cout), x)
                 check(lib.aesr_stemconv_fwd(ptr(cur), ptr(s.folded), ptr(s.mod.bias), ptr(out), N, H, W, s.cout, s.stem_pad,
@@ -629,9 +631,15 @@ class SequentialRunner:
                                                    s.ks, s.pad, mask_act, mslope, stream()), "aesr_conv2d_dgrad_ws")
                     _pe()
                 elif s.cout == 1 and s.ks == 3 and s.pad == 1 and _thin_channels(s.cin):
-                    wsf = _empty((9 * s.cin,), g)
-                    check(lib.aesr_conv2d_cout1_dgrad(ptr(g), ptr(s.mod.weight), ptr(mask), ptr(dx), ptr(wsf), N, H, W, s.cin,
-                                                      mask_act, mslope, stream()), "aesr_conv2d_cout1_dgrad")
+                    w = s.mod.weight
+                    if s.flipped is not None and s.packed_epoch == (self.weights_epoch, w._version, w.data_ptr()):
+                        # the flipped filter was made with the rest of the step's operands (prepare_weights): one launch
+                        check(lib.aesr_conv2d_cout1_dgrad_pre(ptr(g), ptr(s.flipped), ptr(mask), ptr(dx), N, H, W, s.cin, mask_act, mslope,
+                                                              stream()), "aesr_conv2d_cout1_dgrad_pre")
+                    else:
+                        wsf = _empty((9 * s.cin,), g)
+                        check(lib.aesr_conv2d_cout1_dgrad(ptr(g), ptr(w), ptr(mask), ptr(dx), ptr(wsf), N, H, W, s.cin,
+                                                          mask_act, mslope, stream()), "aesr_conv2d_cout1_dgrad")
                 elif s.cout <= 4:
                     # data gradient of a tiny-Cout conv == small-Cin forward conv with the flipped/transposed filter
                     check(lib.aesr_conv2d_smallcin_fwd(ptr(g), ptr(s.mod.weight), None, ptr(mask), ptr(dx), N, Ho, Wo, s.cout,
@@ -681,6 +689,22 @@ class SequentialRunner:
                                                 N, H, W, C, s.run_mode, prev.act, prev.slope, G, nsa, stream()), "aesr_bn_bwd_apply")
                 g = dpre
         return g
+
+
+def prepare_weights(pairs):
+    """ONE aesr_weight_prep_many launch (per 32 jobs) for everything stale in ``pairs`` = [(runner, step list), ...]: the operands of all
+    networks of a training step at once (AEBaseTrainer calls this at the top of the step for encoder + decoder: one graph node instead
+    of four to five); a pass calls it for its own list, which then finds nothing left to do."""
+    jobs, commits = [], []
+    for runner, steps in pairs:
+        j, c = runner._prep_jobs(steps)
+        jobs += j
+        commits += c
+    if jobs:
+        arr = (_hip.PrepJob * len(jobs))(*jobs)
+        check(lib.aesr_weight_prep_many(arr, len(jobs), stream()), "aesr_weight_prep_many")
+    for c in commits:
+        c()
 
 
 _DEFERRED = None      # list of pending weight-gradient reduction jobs while a deferred_wgrad_reductions() block is open

@@ -99,6 +99,8 @@ class CombinedStepMixin(object):
         """The ae_combined step on device-resident inputs; logs through ``_log`` and returns the tensors callers keep."""
         x, between = batch_item["image"], batch_item["slice_between"]
         B = x.shape[0] // 2
+        if hasattr(self.model, "prepare_weights"):
+            self.model.prepare_weights()          # encoder + decoder operands after the last optimizer step: ONE launch
         # enc(x[2B]) and the logging-only enc(slice_between[B]): one batched pass, two BatchNorm statistic groups
         z, z_ref = self.model.encode_multi([x, between], needs_grad=[True, False])
         a_from, a_to = self._mix_coefficients(batch_item, B)

@@ -166,6 +166,8 @@ class AEBaseTrainer(BaseTrainer):
         self._set_mode(not eval_mode)
         self._iters += 1
         self._note_batch(batch_item, "train")
+        if hasattr(self.model, "prepare_weights"):
+            self.model.prepare_weights()
         z = self.model.encode(x)
         out = self.model.decode(z)
         loss_ae = self.get_loss(x, out, is_test=False)["loss_ae"]

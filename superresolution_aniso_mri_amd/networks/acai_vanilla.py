@@ -120,6 +120,11 @@ class HipAE(nn.Module):
         for r in self.__dict__.get("_runners", {}).values():
             r.mark_weights_dirty()
 
+    def prepare_weights(self, names=("enc", "dec")):
+        """Ready the parameter-side operands of ALL networks of a training step with one launch (engine.prepare_weights) instead of one
+        to three per network when their passes start; a no-op when nothing changed since the last call."""
+        engine.prepare_weights([(self._runner(n), self._runner(n).train_steps()) for n in names if hasattr(self, n)])
+
     def set_sync_bn(self, fn, count_scale=1.0):
         """Data parallel: ``fn(sums)`` all-reduces BatchNorm partial sums across ranks (SyncBN); ``count_scale`` =
         B_global / B_local turns local element counts into global ones."""

@@ -916,3 +916,56 @@ def test_combined_mse_loss_block(hip, sizes):
         assert abs(float(total) - float(t2)) <= 2e-7 * float(t2) and abs(float(l3) - float(ops.mse_loss(zm, zr))) <= 2e-7
         assert abs(float(l1) + float(l2) - float(total)) <= 1e-7
         assert rel_l2(o3.grad, o3r.grad) < 1e-6
+
+
+def test_weight_prep_many_equals_the_separate_launches(hip):
+    """aesr_weight_prep_many (csrc/prep.hip): implicit-GEMM packing, Winograd transform (both directions), the folded encoder stem and
+    the flipped Cout == 1 filter of a whole step in ONE launch -- bitwise what aesr_conv2d_pack_many, aesr_conv2d_wino_pack_many,
+    aesr_stemconv_fold and the flip inside aesr_conv2d_cout1_dgrad produce; more than 32 jobs span several launches."""
+    g = torch.Generator().manual_seed(77)
+    L = hip.lib
+    jobs, checks = [], []
+
+    def rnd(*shape):
+        return D(torch.randn(*shape, generator=g))
+
+    for k, (cout, cin, ks) in enumerate([(32, 32, 3), (64, 32, 3), (128, 64, 3), (16, 8, 3), (32, 12, 1), (64, 64, 3), (8, 4, 3)] * 3):
+        w = rnd(cout, cin, ks, ks)
+        for transpose in (0, 1):
+            if (cin if not transpose else cout) % 4 == 0:
+                n = L.aesr_conv2d_packed_floats(cout, cin, ks, transpose)
+                got, want = D(torch.full((n,), float("nan"))), D(torch.empty(n))
+                jobs.append(hip.PrepJob(w.data_ptr(), None, None, got.data_ptr(), hip.PREP_PACK, cout, cin, ks, transpose))
+                one = (hip.PackJob * 1)(hip.PackJob(w.data_ptr(), want.data_ptr(), cout, cin, ks, transpose))
+                hip.check(L.aesr_conv2d_pack_many(one, 1, hip.stream()), "pack")
+                checks.append(("pack %d t%d" % (k, transpose), got, want))
+            if ks == 3 and L.aesr_conv2d_wino_supported(cin, cout, 3, 1, transpose):
+                got = D(torch.full((L.aesr_conv2d_wino_packed_floats(cout, cin, transpose),), float("nan")))
+                jobs.append(hip.PrepJob(w.data_ptr(), None, None, got.data_ptr(), hip.PREP_WINO_PACK, cout, cin, 3, transpose))
+                checks.append(("wino %d t%d" % (k, transpose), got, _pack_wino(hip, w, transpose)))
+    # folded stem: Conv2d(1, 32, 1, padding=1) -> Conv2d(32, 32, 3, padding=1)
+    ws, bs, w1 = rnd(32), rnd(32), rnd(32, 32, 3, 3)
+    nf = L.aesr_stemconv_folded_floats(32)
+    got, want = D(torch.full((nf,), float("nan"))), D(torch.empty(nf))
+    jobs.append(hip.PrepJob(w1.data_ptr(), ws.data_ptr(), bs.data_ptr(), got.data_ptr(), hip.PREP_STEM_FOLD, 32, 32, 3, 0))
+    hip.check(L.aesr_stemconv_fold(hip.ptr(ws), hip.ptr(bs), hip.ptr(w1), hip.ptr(want), 32, 32, hip.stream()), "fold")
+    checks.append(("stem fold", got, want))
+    # flipped Cout == 1 filter: wexp[t][ci] = W[0, ci, 8 - t]
+    wc = rnd(1, 32, 3, 3)
+    flipped = D(torch.full((9 * 32,), float("nan")))
+    jobs.append(hip.PrepJob(wc.data_ptr(), None, None, flipped.data_ptr(), hip.PREP_COUT1_FLIP, 1, 32, 3, 0))
+    assert len(jobs) > 64          # three launches of <= 32 jobs
+    arr = (hip.PrepJob * len(jobs))(*jobs)
+    hip.check(L.aesr_weight_prep_many(arr, len(jobs), hip.stream()), "prep_many")
+    torch.cuda.synchronize()
+    for what, a, b in checks:
+        assert torch.equal(a, b), what
+    assert torch.equal(flipped.cpu().reshape(9, 32), wc.cpu().reshape(32, 9).flip(1).t())
+    # ... and the data gradient that takes it equals the one that flips for itself
+    dy, ys = rnd(2, 20, 24, 1), rnd(2, 20, 24, 32)
+    dx0, dx1, wsf = D(torch.empty(2, 20, 24, 32)), D(torch.empty(2, 20, 24, 32)), D(torch.empty(9 * 32))
+    hip.check(L.aesr_conv2d_cout1_dgrad(hip.ptr(dy), hip.ptr(wc), hip.ptr(ys), hip.ptr(dx0), hip.ptr(wsf), 2, 20, 24, 32, hip.ACT_LRELU, 0.01, hip.stream()), "d0")
+    hip.check(L.aesr_conv2d_cout1_dgrad_pre(hip.ptr(dy), hip.ptr(flipped), hip.ptr(ys), hip.ptr(dx1), 2, 20, 24, 32, hip.ACT_LRELU, 0.01, hip.stream()), "d1")
+    assert torch.equal(dx0, dx1)
+    bad = (hip.PrepJob * 1)(hip.PrepJob(wc.data_ptr(), None, None, flipped.data_ptr(), 9, 1, 32, 3, 0))
+    assert L.aesr_weight_prep_many(bad, 1, hip.stream()) != 0 and "kind" in hip.last_error()
