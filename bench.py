@@ -289,6 +289,69 @@ def small_shards(device):
     return out
 
 
+def e2e_bench(device, steps=300, warmup=20):
+    """The training LOOP, not only the step (train_cardiac_aesr.py:153-204 + datasets/shared_transforms.py:48-120 of the
+    reference): as train_aesr.py runs it with --volumes_dir -- per step the host draws the batch's random numbers from a numpy RandomState
+    in the reference's order (slice pair, from/to order, crop origin, intensity curve, rotation: ~10 draws per triplet), ONE launch
+    (aesr_triplet_assemble) gathers, crops, intensity-maps and rotates the 12 triplets out of a device-resident volume cache into the
+    buffer the captured step reads, and the step graph is replayed.  Synthetic ACDC-shaped cache: 60 volumes of 10 x 216 x 256,
+    aug_patch_size 180, width 160 (configs[1]).  Beside it, the same trainer fed ONE resident batch (the headline's regime)."""
+    import numpy as np
+    from superresolution_aniso_mri_amd.data_device import TripletAugmenter
+    rs = np.random.RandomState(892372)
+    vols = []
+    for _ in range(60):
+        low = rs.rand(10, 27, 32).astype(np.float32)
+        vols.append(np.clip(np.kron(low, np.ones((1, 8, 8), np.float32)) * 0.8 + 0.1 * rs.rand(10, 216, 256).astype(np.float32), 0, 1))
+    aug = TripletAugmenter(vols, 160, 180, rs=np.random.RandomState(892372), device=device)
+    B = 12
+    trainer, pool = make_trainer("c2", device, B, 160, npool=1)
+    host = [0.0]
+
+    def loop(n, from_cache):
+        for _ in range(n):
+            if from_cache:
+                t0 = time.perf_counter()
+                batch = aug.next_batch(B, step=2, reuse_output=True)
+                host[0] += time.perf_counter() - t0
+            else:
+                batch = pool[0]
+            trainer.train(batch, keep_predictions=False)
+
+    out = {}
+    # host cost of a batch with an idle device (inside the loop the host runs ahead of the GPU until the launch queue pushes back, so
+    # its per-call times there are waiting times)
+    for _ in range(5):
+        aug.next_batch(B, step=2, reuse_output=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        aug.next_batch(B, step=2, reuse_output=True)
+    out["host_batch_us_idle_device"] = round(1e4 * (time.perf_counter() - t0), 1)
+    torch.cuda.synchronize()
+    for name, from_cache in (("resident_batch", False), ("volume_cache", True)):
+        # the static inputs of the captured step: adopted from the first batch it is captured on -- capture on the kind it will run on
+        trainer, pool = make_trainer("c2", device, B, 160, npool=1)
+        loop(warmup, from_cache)
+        torch.cuda.synchronize()
+        host[0] = 0.0
+        t0 = time.perf_counter()
+        loop(steps, from_cache)
+        t_enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[name] = {"ms_per_step": round(1e3 * dt / steps, 3), "slices_per_s": round(3 * B * steps / dt, 1),
+                     "host_enqueue_ms_per_step": round(1e3 * t_enq / steps, 3)}
+        if from_cache:
+            out[name]["host_batch_us_in_loop"] = round(1e6 * host[0] / steps, 1)
+        del trainer, pool
+        torch.cuda.empty_cache()
+    out["e2e_over_resident"] = round(out["volume_cache"]["slices_per_s"] / out["resident_batch"]["slices_per_s"], 4)
+    out["workload"] = ("train_aesr.py's loop at configs[1]: %d steps, TripletAugmenter (host RandomState draws in the reference's order + one assemble "
+                       "launch per batch) over a synthetic device-resident cache of 60 volumes 10x216x256 -> captured step" % steps)
+    return out
+
+
 def inference_bench(device):
     """BASELINE configs[4] inference leg: generate_hr_volumes.create_super_volume on a synthetic dHCP-shaped volume cropped to the
     evaluation patch (z = 30 slices of 224 x 224, 3 interpolations per pair), volume resident in HBM, output left in HBM."""
@@ -407,6 +470,7 @@ def main():
             sec["c5"] = secondary_config(engine, "c5", device, steps=6, warmup=3)
             sec["small_shards"] = small_shards(device)
             sec["inference"] = inference_bench(device)
+            sec["e2e"] = e2e_bench(device)
             line["secondary"] = sec
         # kernel sources of this run (the hash the PMC files are matched against) and the ring kernel's protocol watchdog (0 = no wait
         # on an LDS arrival counter ever gave up in this process)

@@ -24,7 +24,9 @@ def get_random_adjacent_slice(slice_id, num_slices, rs, step=1):
         return step
     if slice_id - step < 0:
         return slice_id + step
-    return int(rs.choice([slice_id - step, slice_id + step]))
+    # rs.choice([a, b]) draws ONE rs.randint(0, 2) (numpy legacy RandomState.choice without p): the same stream position and result
+    # at a third of the host time (8.6 -> 2.7 us per draw; the training loop makes ~10 draws per sample)
+    return (slice_id - step, slice_id + step)[int(rs.randint(0, 2))]
 
 
 def rescale_intensities(vol, percs=(1, 99)):
@@ -80,6 +82,7 @@ class TripletAugmenter:
             n += v.size
         self.offsets = offs
         self.cache = torch.from_numpy(np.concatenate(flat)).to(device)        # the device-resident volume cache
+        self._out = {}          # B -> (joined [3B,1,W,W] output buffer, alpha_from, alpha_to): reused by every batch of that size
 
     # ---- host-side random draws, in the reference's order ---------------------------------------------------------
     def _geometry(self, H, W):
@@ -99,7 +102,7 @@ class TripletAugmenter:
         Z = self.shapes[vol_id][0]
         other = get_random_adjacent_slice(slice_id, Z, self.rs, step)
         between = (slice_id + other) // 2
-        if self.rs.choice([0, 1]) == 0:
+        if int(self.rs.randint(0, 2)) == 0:            # == rs.choice([0, 1]), see get_random_adjacent_slice
             return slice_id, other, between
         return other, slice_id, between
 
@@ -117,14 +120,25 @@ class TripletAugmenter:
         return oy + top, ox + left, gain, cutoff, k
 
     # ---- device side ------------------------------------------------------------------------------------------------
-    def assemble(self, triplets, transforms=None):
+    def assemble(self, triplets, transforms=None, reuse_output=False):
         """triplets: list of (vol_id, z_from, z_to, z_between); transforms: list of (oy, ox, gain, cutoff, k) or None (drawn
         now, one sample after the other).  Returns {'image': [2B,1,W,W], 'slice_between': [B,1,W,W], 'alpha_from', 'alpha_to'}."""
         B, Wd = len(triplets), self.width
         if transforms is None:
             transforms = [self.draw_transform(t[0]) for t in triplets]
-        image = torch.empty((2 * B, 1, Wd, Wd), device=self.device, dtype=torch.float32)
-        between = torch.empty((B, 1, Wd, Wd), device=self.device, dtype=torch.float32)
+        if reuse_output:
+            # ONE buffer [image | slice_between] per batch size, written again by every batch: the trainer's captured step reads its
+            # inputs from exactly these addresses (AEBaseTrainer._train_graphed adopts "_persistent" batches as its static inputs), so
+            # a training step costs the assemble launch and the graph replay -- no allocation, no fill, no copy of the batch
+            if B not in self._out:
+                both = torch.empty((3 * B, 1, Wd, Wd), device=self.device, dtype=torch.float32)
+                half = torch.full((B, 1), 0.5, device=self.device, dtype=torch.float32)
+                self._out[B] = (both, half, half.clone())
+            both, a_from, a_to = self._out[B]
+            image, between = both[:2 * B], both[2 * B:]
+        else:
+            image = torch.empty((2 * B, 1, Wd, Wd), device=self.device, dtype=torch.float32)
+            between = torch.empty((B, 1, Wd, Wd), device=self.device, dtype=torch.float32)
         _hip.require_gpu_tensor(self.cache, "volume cache")
         for b0 in range(0, B, 64):
             n = min(64, B - b0)
@@ -146,11 +160,14 @@ class TripletAugmenter:
             if B > 64:
                 image[b0:b0 + n] = img_dst[:n]
                 image[B + b0:B + b0 + n] = img_dst[n:]
+        if reuse_output:
+            return {"image": image, "slice_between": between, "alpha_from": a_from, "alpha_to": a_to, "_persistent": True}
         half = torch.full((B, 1), 0.5, device=self.device, dtype=torch.float32)
         return {"image": image, "slice_between": between, "alpha_from": half, "alpha_to": half.clone()}
 
-    def next_batch(self, B, step=2):
-        """A random training batch: B random (volume, slice) pairs, neighbours ``step`` apart."""
+    def next_batch(self, B, step=2, reuse_output=False):
+        """A random training batch: B random (volume, slice) pairs, neighbours ``step`` apart.  ``reuse_output``: the batch is written
+        into this augmenter's persistent output buffer (valid until the next call) -- what the training loop uses."""
         trips = []
         for _ in range(B):
             vid = int(self.rs.randint(0, len(self.shapes)))
@@ -160,4 +177,4 @@ class TripletAugmenter:
             sid = int(self.rs.randint(0, Z))
             zf, zt, zb = self.draw_triplet(vid, sid, step)
             trips.append((vid, zf, zt, zb))
-        return self.assemble(trips)
+        return self.assemble(trips, reuse_output=reuse_output)

@@ -47,6 +47,8 @@ def shard_batch(batch, rank, world):
     lo, hi = (B * rank) // world, (B * (rank + 1)) // world
     out = {}
     for k, v in batch.items():
+        if k == "_persistent":
+            continue              # the shard is made of fresh tensors: not the producer's persistent output buffer
         if k in ("image", "loss_mask") and v.shape[0] == 2 * B:
             out[k] = torch.cat([v[lo:hi], v[B + lo:B + hi]], dim=0)
         elif torch.is_tensor(v) and v.shape[0] == B:

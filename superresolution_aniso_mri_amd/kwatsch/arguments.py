@@ -50,6 +50,7 @@ def build_parser():
     # ---- additive (MI355X build) ----
     a("--synthetic", action="store_true", help="train on synthetic triplets (no dataset on disk needed)")
     a("--synthetic_size", type=int, default=None, help="H=W of the synthetic slices (default: --width)")
+    a("--synthetic_pool", type=int, default=8, help="distinct device-resident synthetic batches that --synthetic cycles through (made before the loop)")
     a("--volumes_dir", type=str, default=None, help="train on the volumes (.npy [Z,H,W] / [T,Z,H,W], .nii(.gz), .mha, .mhd) of this "
                                                   "directory: device-resident cache + on-device triplet assembly / augmentation")
     a("--iters_per_epoch", type=int, default=50, help="iterations per epoch with --synthetic")

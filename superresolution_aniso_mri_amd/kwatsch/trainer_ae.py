@@ -115,8 +115,13 @@ class AEBaseTrainer(BaseTrainer):
         sig = tuple((k, tuple(dev_batch[k].shape)) for k in keys)
         g = self._graphs.get(sig)
         if g is None:
-            static = {k: dev_batch[k].clone() for k in keys}
-            if "image" in static and "slice_between" in static and static["image"].shape[1:] == static["slice_between"].shape[1:]:
+            # a "_persistent" batch (data_device.TripletAugmenter: one output buffer that every batch is written into) IS the static input:
+            # later batches arrive at the same addresses and nothing is copied
+            adopt = bool(dev_batch.get("_persistent"))
+            static = {k: (dev_batch[k] if adopt else dev_batch[k].clone()) for k in keys}
+            from ..networks.acai_vanilla import _joined_view
+            joined = "image" in static and "slice_between" in static and _joined_view([static["image"], static["slice_between"]]) is not None
+            if not joined and "image" in static and "slice_between" in static and static["image"].shape[1:] == static["slice_between"].shape[1:]:
                 # the two image sub-batches back to back in ONE buffer: the encoder pass reads [image | slice_between] as it lies (no
                 # concatenation node, networks/acai_vanilla._joined_view)
                 n1 = static["image"].shape[0]
@@ -148,7 +153,8 @@ class AEBaseTrainer(BaseTrainer):
             g = self._graphs[sig] = (graph, static, sink)
         graph, static, sink = g
         for k in keys:
-            static[k].copy_(dev_batch[k])
+            if static[k].data_ptr() != dev_batch[k].data_ptr():
+                static[k].copy_(dev_batch[k])
         graph.replay()
         self._log_sink(sink)
 

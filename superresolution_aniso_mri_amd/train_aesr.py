@@ -86,9 +86,20 @@ def main(argv=None, brain=False):
                                      rs=np.random.RandomState(args_dict["seed"]), device=args_dict["device"])
         step = max(2, int(args_dict.get("slice_step") or 2))
 
-    def make_batch(seed, n):
+    synth_pool = {}       # --synthetic: a small pool of device-resident batches made BEFORE the loop (rendering one on the host costs tens of ms)
+
+    def make_batch(seed, n, training=True):
         if augmenter is not None:
-            b = augmenter.next_batch(n, step=step)
+            # training batches go into the augmenter's persistent output buffer, which the captured step reads directly; the validation
+            # batch is kept for the whole run and gets tensors of its own
+            b = augmenter.next_batch(n, step=step, reuse_output=training and not dp.active)
+        elif training:
+            key = (n, int(seed) % max(1, int(args_dict.get("synthetic_pool") or 8)))
+            if key not in synth_pool:
+                b = synthetic_batch(n, size, size, seed=args_dict["seed"] + key[1], brain=brain)
+                b = shard_batch(b, dp.rank, dp.world) if dp.active else b
+                synth_pool[key] = {k: (v.to(args_dict["device"]) if torch.is_tensor(v) else v) for k, v in b.items()}
+            return synth_pool[key]
         else:
             b = synthetic_batch(n, size, size, seed=seed, brain=brain)
         return shard_batch(b, dp.rank, dp.world) if dp.active else b
@@ -106,7 +117,7 @@ def main(argv=None, brain=False):
         # single process: one HIP graph per step; data parallel: graph segments between the eager collectives
         trainer.enable_step_graph(dp_segments=dp.active)
     trainer.init_tensorboard(args_dict["output_dir"])
-    validation_batch = make_batch(args_dict["seed"] - 1, args_dict["test_batch_size"])
+    validation_batch = make_batch(args_dict["seed"] - 1, args_dict["test_batch_size"], training=False)
     num_it_per_epoch = args_dict["iters_per_epoch"]
     args.num_it_per_epoch = num_it_per_epoch
     if dp.rank == 0:
