@@ -315,6 +315,27 @@ size_t aesr_ssim_workspace_doubles(int Z, int H, int W);
 int aesr_ssim_mse(const float* a, const float* b, double* workspace, double* ssim, double* mse, int Z, int H, int W, int win,
                   double data_range, double k1, double k2, void* stream);
 
+/* ---- BatchNorm2d (train) [+ AvgPool2d(2)] as ONE launch per direction, for SMALL batches (csrc/bn_fused.hip) -----------------------
+ * The shard of a data-parallel rank (6 images) makes a BatchNorm call three ~5 us launches each way; a layer of that size fits the LDS
+ * of the chip, so one launch of 256 workgroups keeps it there between the statistics and the normalisation, with one grid-wide barrier
+ * in between (bounded waits; a wait that gives up counts in aesr_bn_fused1_timeouts and the host raises).  Same arithmetic per element
+ * as aesr_bn_stats_finalize + aesr_bn_apply / aesr_bn_bwd; the partial sums are formed over other partitions of the pixels, so
+ * statistics agree to fp64 rounding of the sums.  mode: AESR_BN_NONE or AESR_BN_POOL (the folded Upsample runs as NONE).
+ * aesr_bn_fused1_supported: 1 when the layer fits (else take the three-launch entry points; the launchers return AESR_ERR_UNSUPPORTED).
+ * workspace: aesr_bn_fused1_workspace_floats(C, G) floats.  barrier_state: aesr_bn_fused1_barrier_words() 32-bit words, zeroed ONCE by
+ * the caller and then left alone; launches that share one state must be serialised on one stream (one state per network). */
+int aesr_bn_fused1_supported(int N, int H, int W, int C, int mode, int G, int backward);
+size_t aesr_bn_fused1_workspace_floats(int C, int G);
+size_t aesr_bn_fused1_barrier_words(void);
+unsigned int aesr_bn_fused1_timeouts(void);
+int aesr_bn_fused1_fwd(const float* y, float* out, float* workspace, unsigned int* barrier_state, const double* counts_host, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
+                       float* scale, float* shift, int N, int H, int W, int C, int mode, int G, const int* nstart_host, float momentum, float eps,
+                       int update_running, void* stream);
+int aesr_bn_fused1_bwd(const float* gout, const float* y, const float* mean, const float* invstd, const float* scale, float* workspace,
+                       unsigned int* barrier_state, const double* counts_host, float* coef, float* dgamma, float* dbeta, float* dpre, int N, int H,
+                       int W, int C, int mode, int act, float slope, int G, const int* nstart_host, void* stream);
+
 /* ---- VIF of the same protocol (evaluate/metrics.py:65-109 compute_vif_for_batch -> evaluate/vifvec.py:7-63 vifp_mscale, per slice) --
  * ref, dist: [Z][H][W] fp32 in [0, 1].  vif[Z]: fp64 device array, NaN where the denominator is 0 (a black reference slice).  The
  * arithmetic is the reference's on uint8 images (both volumes are converted with uint8(clip(x * 255, 0, 255)) before vifp_mscale is

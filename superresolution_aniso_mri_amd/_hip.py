@@ -84,6 +84,12 @@ SIGNATURES = {
     "aesr_bn_bwd": (c_int, [P] * 6 + [DP] + [P] * 4 + [c_int] * 6 + [c_float, c_int, IP, P]),
     "aesr_bn_fused_supported": (c_int, [c_int, c_int]),
     "aesr_bn_finalize_apply": (c_int, [P] * 13 + [c_int] * 6 + [P, c_float, c_float, c_int, P]),
+    "aesr_bn_fused1_supported": (c_int, [c_int] * 7),
+    "aesr_bn_fused1_workspace_floats": (c_size_t, [c_int, c_int]),
+    "aesr_bn_fused1_barrier_words": (c_size_t, []),
+    "aesr_bn_fused1_timeouts": (ctypes.c_uint, []),
+    "aesr_bn_fused1_fwd": (c_int, [P, P, P, P, DP] + [P] * 9 + [c_int] * 6 + [IP, c_float, c_float, c_int, P]),
+    "aesr_bn_fused1_bwd": (c_int, [P] * 7 + [DP] + [P] * 4 + [c_int] * 6 + [c_float, c_int, IP, P]),
     "aesr_bn_apply": (c_int, [P, P, P, P] + [c_int] * 6 + [IP, P]),
     "aesr_bn_bwd_reduce": (c_int, [P] * 6 + [c_int] * 6 + [IP, P]),
     "aesr_bn_bwd_apply": (c_int, [P] * 6 + [DP] + [P] * 4 + [c_int] * 6 + [c_float, c_int, IP, P]),
@@ -188,6 +194,11 @@ def check_device_watchdogs(where):
     chunk rather than hang the GPU, and counts.  Every place where results LEAVE the process (checkpoints, logged epoch means,
     validation, synthesised volumes, the bench line) calls this, so garbage cannot be trained on or written silently.  Reads a
     device symbol (synchronises the device): never inside the step or a graph capture."""
+    nb = int(lib.aesr_bn_fused1_timeouts())
+    if nb:
+        raise RuntimeError("%s: the one-launch BatchNorm kernel's grid barrier gave up %d time(s) in this process -- its workgroups were not all "
+                           "resident (the device is shared with another grid-barrier kernel: set AESR_BN_FUSED=0); results since are not "
+                           "trustworthy; nothing was written" % (where, nb))
     n = int(lib.aesr_conv2d_wino_ring_timeouts())
     if n:
         raise RuntimeError("%s: the ring convolution kernel's arrival-counter watchdog fired %d time(s) in this process -- activations / "

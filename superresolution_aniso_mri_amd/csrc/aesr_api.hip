@@ -872,6 +872,40 @@ int aesr_bn_apply(const float* y, const float* scale, const float* shift, float*
 
 int aesr_bn_fused_supported(int C, int G) { return aesr_bn_fused_ok(C, G) ? 1 : 0; }
 
+int aesr_bn_fused1_supported(int N, int H, int W, int C, int mode, int G, int backward) {
+    if (mode != AESR_BN_NONE && mode != AESR_BN_POOL) return 0;
+    return aesr_bn_fused1_ok(N, H, W, C, mode == AESR_BN_POOL, G, backward) ? 1 : 0;
+}
+
+size_t aesr_bn_fused1_workspace_floats(int C, int G) { return (size_t)256 * G * 2 * C; }
+size_t aesr_bn_fused1_barrier_words(void) { return 16 * 32; }
+unsigned int aesr_bn_fused1_timeouts(void) { return aesr_bn_fused_timeouts_impl(); }
+
+int aesr_bn_fused1_fwd(const float* y, float* out, float* workspace, unsigned int* barrier_state, const double* counts_host, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
+                       float* scale, float* shift, int N, int H, int W, int C, int mode, int G, const int* nstart_host, float momentum, float eps,
+                       int update_running, void* stream) {
+    BnGroups gr;
+    AESR_CHECK_ARG(y && out && workspace && barrier_state && counts_host && gamma && beta && mean && invstd && scale && shift &&
+                       fill_groups(&gr, G, nstart_host) && gr.nstart[G] == N, "aesr_bn_fused1_fwd: bad arguments");
+    AESR_CHECK_ARG(mode == AESR_BN_NONE || mode == AESR_BN_POOL, "aesr_bn_fused1_fwd: mode %d (the un-folded Upsample takes the three-launch path)", mode);
+    return aesr_bn_fused_run(y, nullptr, out, workspace, barrier_state, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, mean,
+                             invstd, scale, shift, nullptr, nullptr, nullptr, N, H, W, C, mode == AESR_BN_POOL, G, gr.nstart, counts_host, momentum, eps,
+                             update_running && running_mean && running_var, ACT_NONE, 0.f, 0, (hipStream_t)stream);
+}
+
+int aesr_bn_fused1_bwd(const float* gout, const float* y, const float* mean, const float* invstd, const float* scale, float* workspace,
+                       unsigned int* barrier_state, const double* counts_host, float* coef, float* dgamma, float* dbeta, float* dpre, int N, int H,
+                       int W, int C, int mode, int act, float slope, int G, const int* nstart_host, void* stream) {
+    BnGroups gr;
+    AESR_CHECK_ARG(gout && y && mean && invstd && scale && workspace && barrier_state && counts_host && coef && dgamma && dbeta && dpre &&
+                       fill_groups(&gr, G, nstart_host) && gr.nstart[G] == N, "aesr_bn_fused1_bwd: bad arguments");
+    AESR_CHECK_ARG(mode == AESR_BN_NONE || mode == AESR_BN_POOL, "aesr_bn_fused1_bwd: mode %d (the un-folded Upsample takes the three-launch path)", mode);
+    return aesr_bn_fused_run(y, gout, dpre, workspace, barrier_state, nullptr, nullptr, nullptr, nullptr, nullptr, (float*)mean, (float*)invstd,
+                             (float*)scale, nullptr, coef, dgamma, dbeta, N, H, W, C, mode == AESR_BN_POOL, G, gr.nstart, counts_host, 0.f, 0.f, 0, act, slope,
+                             1, (hipStream_t)stream);
+}
+
 int aesr_bn_finalize_apply(const double* sums, const double* counts_host, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
                            const float* y, float* out, int N, int H, int W, int C, int mode, int G, const int* nstart_host, float momentum,

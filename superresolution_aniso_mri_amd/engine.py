@@ -60,6 +60,14 @@ USE_WINO = os.environ.get("AESR_WINO", "1") != "0"
 FOLD_UPSAMPLE = os.environ.get("AESR_FOLD_UPSAMPLE", "1") != "0"
 
 
+def bn_fused_enabled():
+    """Small batches run a BatchNorm call as ONE launch per direction (csrc/bn_fused.hip: activations resident in LDS, one grid-wide
+    barrier) instead of three.  The kernel needs all 256 workgroups resident at once: a process that steps SEVERAL trainers concurrently
+    on different streams of one device must switch it off (AESR_BN_FUSED=0) -- two such grids could each hold half of the chip and wait
+    for the other half until their bounded waits give up (counted; _hip.check_device_watchdogs raises).  Read per call."""
+    return os.environ.get("AESR_BN_FUSED", "1") != "0"
+
+
 def wino_ok(cin, cout, ks, pad, transpose):
     return bool(USE_WINO and lib.aesr_conv2d_wino_supported(int(cin), int(cout), int(ks), int(pad), int(transpose)))
 
@@ -452,6 +460,16 @@ class SequentialRunner:
                 cur, H, W = out, Ho, Wo
         return cur, saved, steps
 
+    def _bn_barrier(self, dev):
+        """Grid-barrier state of this runner's one-launch BatchNorm kernels (csrc/bn_fused.hip): zeroed once, then owned by the kernels.
+        Created by an eager step (a tensor born inside a graph capture would live in the graph's pool and be zeroed by every replay)."""
+        t = self.__dict__.get("_bn_bar")
+        if t is None or t.device != torch.device(dev):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("one-launch BatchNorm: run the pass eagerly once before capturing it into a HIP graph")
+            t = self._bn_bar = torch.zeros((int(lib.aesr_bn_fused1_barrier_words()),), device=dev, dtype=torch.int32)
+        return t
+
     sync_bn = None      # optional callable(sums[G,2,C] double) -> all-reduced in place across ranks (data parallel SyncBN)
     count_scale = 1.0   # data parallel: global / local sub-batch size (B_global / B_local of this rank)
 
@@ -469,6 +487,16 @@ class SequentialRunner:
             partial = torch.empty((G * _hip.BN_NWG * 2 * C,), device=dev, dtype=torch.float32)
             counts = [float((nstart[g + 1] - nstart[g]) * H * W) * self.count_scale for g in range(G)]   # host values
             st["counts"] = counts
+            if (self.sync_bn is None and out is not None and bn_fused_enabled()
+                    and lib.aesr_bn_fused1_supported(N, H, W, C, run_mode, G, 0)):
+                # small batch: statistics, finalize and apply in ONE launch, the layer resident in LDS in between
+                ws = torch.empty((lib.aesr_bn_fused1_workspace_floats(C, G),), device=dev, dtype=torch.float32)
+                check(lib.aesr_bn_fused1_fwd(ptr(y), ptr(out), ptr(ws), ptr(self._bn_barrier(dev)), _hip.double_array(counts), ptr(bn.weight),
+                                             ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
+                                             ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(st["shift"]), N, H, W, C, run_mode, G,
+                                             _hip.int_array(nstart), momentum, float(bn.eps), int(update), stream()), "aesr_bn_fused1_fwd")
+                st["applied"] = True
+                return st
             if self.sync_bn is None:        # single process: statistics -> finalize without the sums round trip
                 check(lib.aesr_bn_stats_finalize(ptr(y), ptr(partial), _hip.double_array(counts), ptr(bn.weight), ptr(bn.bias),
                                                  ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
@@ -675,7 +703,12 @@ class SequentialRunner:
                 coef = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
                 dgamma, dbeta = self._grad_dst(s.mod.weight, grads), self._grad_dst(s.mod.bias, grads)
                 dpre = _empty((N, H, W, C), y)
-                if self.sync_bn is None:
+                if self.sync_bn is None and bn_fused_enabled() and lib.aesr_bn_fused1_supported(N, H, W, C, s.run_mode, G, 1):
+                    ws = torch.empty((lib.aesr_bn_fused1_workspace_floats(C, G),), device=dev, dtype=torch.float32)
+                    check(lib.aesr_bn_fused1_bwd(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(ws),
+                                                 ptr(self._bn_barrier(dev)), _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma), ptr(dbeta),
+                                                 ptr(dpre), N, H, W, C, s.run_mode, prev.act, prev.slope, G, nsa, stream()), "aesr_bn_fused1_bwd")
+                elif self.sync_bn is None:
                     check(lib.aesr_bn_bwd(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(partial),
                                           _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dpre), N, H, W,
                                           C, s.run_mode, prev.act, prev.slope, G, nsa, stream()), "aesr_bn_bwd")
