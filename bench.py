@@ -271,7 +271,29 @@ def small_shards(device):
                 out[config]["%d_triplets_dp_ms" % t] = round(1e3 * timed_steps(trainer, pool, 20, 6, dp) / 20, 3)
                 del trainer, pool
             torch.cuda.empty_cache()
-        out["dp_form"] = "communicator of one, data plane %s, graph form %s" % (dp.data_backend, dp.graph_mode)
+        out["dp_form"] = "communicator of one, data plane %s, graph form %s, SyncBN exchange %s" % (dp.data_backend, dp.graph_mode, dp.syncbn)
+        # the opt-in one-shot SyncBN exchange (AESR_SYNCBN=p2p: inside the one-launch BatchNorm kernels, over a peer group of one): only the
+        # gradient all-reduce is left as a collective
+        dp.shutdown()
+        dp = None
+        saved_sync = os.environ.get("AESR_SYNCBN")
+        os.environ["AESR_SYNCBN"] = "p2p"
+        try:
+            if not dist.is_initialized():
+                dist.init_process_group("gloo", store=dist.HashStore(), rank=0, world_size=1)
+            dp = DataParallelContext(device=device)
+            for config in ("c2", "c3"):
+                for t in (1, 2):
+                    trainer, pool = make_trainer(config, device, t, 160, npool=2, dp=dp)
+                    out[config]["%d_triplets_dp_p2p_ms" % t] = round(1e3 * timed_steps(trainer, pool, 20, 6, dp) / 20, 3)
+                    del trainer, pool
+                torch.cuda.empty_cache()
+            out["dp_p2p_form"] = "communicator of one, data plane %s, graph form %s, SyncBN exchange %s (opt-in)" % (dp.data_backend, dp.graph_mode, dp.syncbn)
+        finally:
+            if saved_sync is None:
+                os.environ.pop("AESR_SYNCBN", None)
+            else:
+                os.environ["AESR_SYNCBN"] = saved_sync
     except Exception as e:       # no RCCL on this box: the projection falls back to the single-process step
         out["dp_note"] = "one-rank data-parallel step not measured (%s)" % (str(e)[:160],)
     finally:
@@ -284,6 +306,8 @@ def small_shards(device):
     for config in ("c2", "c3"):
         step_ms = out[config].get("2_triplets_dp_ms", out[config]["2_triplets_ms"])
         out[config]["projected_8_rank_slices_per_s"] = round(36.0 / step_ms * 1e3, 1)
+        if "2_triplets_dp_p2p_ms" in out[config]:
+            out[config]["projected_8_rank_slices_per_s_p2p"] = round(36.0 / out[config]["2_triplets_dp_p2p_ms"] * 1e3, 1)
     out["projection"] = ("36 slices / the 2-triplet step of one rank with SyncBN and the 9 collectives enqueued on a communicator of one: an UPPER "
                          "bound on the 8-rank rate (wire time and waiting for the slowest peer come on top)")
     return out

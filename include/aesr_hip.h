@@ -336,6 +336,37 @@ int aesr_bn_fused1_bwd(const float* gout, const float* y, const float* mean, con
                        unsigned int* barrier_state, const double* counts_host, float* coef, float* dgamma, float* dbeta, float* dpre, int N, int H,
                        int W, int C, int mode, int act, float slope, int G, const int* nstart_host, void* stream);
 
+/* ---- the same with the SyncBN exchange INSIDE the launch: data parallel over peer-mapped regions (csrc/p2p.hip, csrc/bn_fused.hip) ------
+ * the [G][2][C] partial sums of a BatchNorm call are a few hundred bytes -- a one-shot write into every peer's memory
+ * over xGMI beats a ring all-reduce, and it needs no launch of its own.  Every rank allocates ONE region (aesr_p2p_alloc, fine-grained
+ * device memory of aesr_p2p_region_bytes(world) bytes), publishes its 64-byte IPC handle over any host channel and maps the others'
+ * (aesr_p2p_open).  peers_host[r] = rank r's region as mapped into THIS process (peers_host[rank] = the own allocation).  slot: the
+ * number of the BatchNorm call inside the step (call order, the same on every rank, < AESR_P2P_SLOTS).  gen_dev: a device word that
+ * every rank advances ONCE per step with aesr_p2p_tick before the step's first BatchNorm call (zero-initialised).  Inside the launch
+ * workgroup 0 writes the rank's totals into every region, every workgroup waits (bounded; a wait that gives up counts in
+ * aesr_bn_fused1_timeouts) for all ranks' totals in its own region and adds them in rank order: identical bits on all ranks.
+ * counts_host are the GLOBAL element counts of the groups.  A rank re-uses a slot only after the step's gradient all-reduce, which
+ * every rank enters after its last slot: producers never wait for consumers.  OPT-IN (AESR_SYNCBN=p2p): covered on one device
+ * (a group of one, two ranks through IPC); no multi-GPU box has run it yet.  world <= 8. */
+#define AESR_P2P_HANDLE_BYTES 64
+#define AESR_P2P_SLOTS 32
+#define AESR_P2P_REC_BYTES (512 * 8 + 128)
+int aesr_p2p_alloc(size_t bytes, void** region);
+int aesr_p2p_free(void* region);
+int aesr_p2p_get_handle(void* region, char* handle64);
+int aesr_p2p_open(const char* handle64, void** peer_region);
+int aesr_p2p_close(void* peer_region);
+size_t aesr_p2p_region_bytes(int world);
+int aesr_p2p_tick(unsigned int* gen_dev, void* stream);
+int aesr_bn_fused1_fwd_p2p(const float* y, float* out, float* workspace, unsigned int* barrier_state, const double* counts_host, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
+                           float* scale, float* shift, int N, int H, int W, int C, int mode, int G, const int* nstart_host, float momentum, float eps,
+                           int update_running, void* const* peers_host, int world, int rank, int slot, const unsigned int* gen_dev, void* stream);
+int aesr_bn_fused1_bwd_p2p(const float* gout, const float* y, const float* mean, const float* invstd, const float* scale, float* workspace,
+                           unsigned int* barrier_state, const double* counts_host, float* coef, float* dgamma, float* dbeta, float* dpre, int N, int H,
+                           int W, int C, int mode, int act, float slope, int G, const int* nstart_host, void* const* peers_host, int world, int rank,
+                           int slot, const unsigned int* gen_dev, void* stream);
+
 /* ---- VIF of the same protocol (evaluate/metrics.py:65-109 compute_vif_for_batch -> evaluate/vifvec.py:7-63 vifp_mscale, per slice) --
  * ref, dist: [Z][H][W] fp32 in [0, 1].  vif[Z]: fp64 device array, NaN where the denominator is 0 (a black reference slice).  The
  * arithmetic is the reference's on uint8 images (both volumes are converted with uint8(clip(x * 255, 0, 255)) before vifp_mscale is

@@ -90,6 +90,15 @@ SIGNATURES = {
     "aesr_bn_fused1_timeouts": (ctypes.c_uint, []),
     "aesr_bn_fused1_fwd": (c_int, [P, P, P, P, DP] + [P] * 9 + [c_int] * 6 + [IP, c_float, c_float, c_int, P]),
     "aesr_bn_fused1_bwd": (c_int, [P] * 7 + [DP] + [P] * 4 + [c_int] * 6 + [c_float, c_int, IP, P]),
+    "aesr_p2p_alloc": (c_int, [c_size_t, ctypes.POINTER(c_void_p)]),
+    "aesr_p2p_free": (c_int, [P]),
+    "aesr_p2p_get_handle": (c_int, [P, c_char_p]),
+    "aesr_p2p_open": (c_int, [c_char_p, ctypes.POINTER(c_void_p)]),
+    "aesr_p2p_close": (c_int, [P]),
+    "aesr_p2p_region_bytes": (c_size_t, [c_int]),
+    "aesr_p2p_tick": (c_int, [P, P]),
+    "aesr_bn_fused1_fwd_p2p": (c_int, [P, P, P, P, DP] + [P] * 9 + [c_int] * 6 + [IP, c_float, c_float, c_int, ctypes.POINTER(c_void_p), c_int, c_int, c_int, P, P]),
+    "aesr_bn_fused1_bwd_p2p": (c_int, [P] * 7 + [DP] + [P] * 4 + [c_int] * 6 + [c_float, c_int, IP, ctypes.POINTER(c_void_p), c_int, c_int, c_int, P, P]),
     "aesr_bn_apply": (c_int, [P, P, P, P] + [c_int] * 6 + [IP, P]),
     "aesr_bn_bwd_reduce": (c_int, [P] * 6 + [c_int] * 6 + [IP, P]),
     "aesr_bn_bwd_apply": (c_int, [P] * 6 + [DP] + [P] * 4 + [c_int] * 6 + [c_float, c_int, IP, P]),
@@ -149,6 +158,7 @@ SIGNATURES = {
     "aesr_comm_allreduce_many": (c_int, [P, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), c_int, c_int, c_int, P]),
     "aesr_comm_broadcast": (c_int, [P, P, c_size_t, c_int, c_int, P]),
 }
+P2P_HANDLE_BYTES, P2P_SLOTS = 64, 32
 COMM_ID_BYTES = 128
 COMM_F32, COMM_F64, COMM_SUM, COMM_MAX = 0, 1, 0, 1
 

@@ -891,7 +891,7 @@ int aesr_bn_fused1_fwd(const float* y, float* out, float* workspace, unsigned in
     AESR_CHECK_ARG(mode == AESR_BN_NONE || mode == AESR_BN_POOL, "aesr_bn_fused1_fwd: mode %d (the un-folded Upsample takes the three-launch path)", mode);
     return aesr_bn_fused_run(y, nullptr, out, workspace, barrier_state, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, mean,
                              invstd, scale, shift, nullptr, nullptr, nullptr, N, H, W, C, mode == AESR_BN_POOL, G, gr.nstart, counts_host, momentum, eps,
-                             update_running && running_mean && running_var, ACT_NONE, 0.f, 0, (hipStream_t)stream);
+                             update_running && running_mean && running_var, ACT_NONE, 0.f, 0, nullptr, (hipStream_t)stream);
 }
 
 int aesr_bn_fused1_bwd(const float* gout, const float* y, const float* mean, const float* invstd, const float* scale, float* workspace,
@@ -903,7 +903,60 @@ int aesr_bn_fused1_bwd(const float* gout, const float* y, const float* mean, con
     AESR_CHECK_ARG(mode == AESR_BN_NONE || mode == AESR_BN_POOL, "aesr_bn_fused1_bwd: mode %d (the un-folded Upsample takes the three-launch path)", mode);
     return aesr_bn_fused_run(y, gout, dpre, workspace, barrier_state, nullptr, nullptr, nullptr, nullptr, nullptr, (float*)mean, (float*)invstd,
                              (float*)scale, nullptr, coef, dgamma, dbeta, N, H, W, C, mode == AESR_BN_POOL, G, gr.nstart, counts_host, 0.f, 0.f, 0, act, slope,
-                             1, (hipStream_t)stream);
+                             1, nullptr, (hipStream_t)stream);
+}
+
+/* ---- the same two with the SyncBN exchange inside: data parallel over peer-mapped regions ---- */
+size_t aesr_p2p_region_bytes(int world) { return world > 0 && world <= 8 ? (size_t)AESR_P2P_SLOTS * 2 * world * AESR_P2P_REC_BYTES : 0; }
+
+int aesr_p2p_tick(unsigned int* gen_dev, void* stream) {
+    AESR_CHECK_ARG(gen_dev, "aesr_p2p_tick: null pointer");
+    return aesr_launch_p2p_tick(gen_dev, (hipStream_t)stream);
+}
+
+static int fill_p2p(BnP2P* p, void* const* peers_host, int world, int rank, int slot, const unsigned int* gen_dev, const char* who) {
+    if (!peers_host || !gen_dev || world < 1 || world > 8 || rank < 0 || rank >= world || slot < 0 || slot >= AESR_P2P_SLOTS) {
+        aesr_set_error("%s: bad exchange arguments (world %d, rank %d, slot %d of %d)", who, world, rank, slot, AESR_P2P_SLOTS);
+        return AESR_ERR_ARG;
+    }
+    p->world = world; p->rank = rank; p->slot = slot; p->gen = gen_dev;
+    for (int r = 0; r < 8; ++r) p->peers[r] = r < world ? peers_host[r] : nullptr;
+    for (int r = 0; r < world; ++r)
+        if (!p->peers[r]) {
+            aesr_set_error("%s: the region of rank %d is not mapped", who, r);
+            return AESR_ERR_ARG;
+        }
+    return AESR_OK;
+}
+
+int aesr_bn_fused1_fwd_p2p(const float* y, float* out, float* workspace, unsigned int* barrier_state, const double* counts_host, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
+                           float* scale, float* shift, int N, int H, int W, int C, int mode, int G, const int* nstart_host, float momentum, float eps,
+                           int update_running, void* const* peers_host, int world, int rank, int slot, const unsigned int* gen_dev, void* stream) {
+    BnGroups gr;
+    BnP2P p2p;
+    AESR_CHECK_ARG(y && out && workspace && barrier_state && counts_host && gamma && beta && mean && invstd && scale && shift &&
+                       fill_groups(&gr, G, nstart_host) && gr.nstart[G] == N, "aesr_bn_fused1_fwd_p2p: bad arguments");
+    AESR_CHECK_ARG(mode == AESR_BN_NONE || mode == AESR_BN_POOL, "aesr_bn_fused1_fwd_p2p: mode %d", mode);
+    if (int e = fill_p2p(&p2p, peers_host, world, rank, slot, gen_dev, "aesr_bn_fused1_fwd_p2p")) return e;
+    return aesr_bn_fused_run(y, nullptr, out, workspace, barrier_state, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, mean,
+                             invstd, scale, shift, nullptr, nullptr, nullptr, N, H, W, C, mode == AESR_BN_POOL, G, gr.nstart, counts_host, momentum, eps,
+                             update_running && running_mean && running_var, ACT_NONE, 0.f, 0, &p2p, (hipStream_t)stream);
+}
+
+int aesr_bn_fused1_bwd_p2p(const float* gout, const float* y, const float* mean, const float* invstd, const float* scale, float* workspace,
+                           unsigned int* barrier_state, const double* counts_host, float* coef, float* dgamma, float* dbeta, float* dpre, int N, int H,
+                           int W, int C, int mode, int act, float slope, int G, const int* nstart_host, void* const* peers_host, int world, int rank,
+                           int slot, const unsigned int* gen_dev, void* stream) {
+    BnGroups gr;
+    BnP2P p2p;
+    AESR_CHECK_ARG(gout && y && mean && invstd && scale && workspace && barrier_state && counts_host && coef && dgamma && dbeta && dpre &&
+                       fill_groups(&gr, G, nstart_host) && gr.nstart[G] == N, "aesr_bn_fused1_bwd_p2p: bad arguments");
+    AESR_CHECK_ARG(mode == AESR_BN_NONE || mode == AESR_BN_POOL, "aesr_bn_fused1_bwd_p2p: mode %d", mode);
+    if (int e = fill_p2p(&p2p, peers_host, world, rank, slot, gen_dev, "aesr_bn_fused1_bwd_p2p")) return e;
+    return aesr_bn_fused_run(y, gout, dpre, workspace, barrier_state, nullptr, nullptr, nullptr, nullptr, nullptr, (float*)mean, (float*)invstd,
+                             (float*)scale, nullptr, coef, dgamma, dbeta, N, H, W, C, mode == AESR_BN_POOL, G, gr.nstart, counts_host, 0.f, 0.f, 0, act, slope,
+                             1, &p2p, (hipStream_t)stream);
 }
 
 int aesr_bn_finalize_apply(const double* sums, const double* counts_host, const float* gamma, const float* beta, float* running_mean,

@@ -162,12 +162,14 @@ struct BnBwdArgs {
 };
 // one-launch BatchNorm for small batches (bn_fused.hip): activations resident in LDS, one grid barrier
 struct BnFusedArgs;
+struct BnP2P { int world, rank, slot; const unsigned* gen; void* peers[8]; };     // data parallel: peer-mapped exchange regions (p2p.hip)
+int aesr_launch_p2p_tick(unsigned* gen, hipStream_t st);
 bool aesr_bn_fused1_ok(int N, int H, int W, int C, int pool, int G, int backward);
 unsigned aesr_bn_fused_timeouts_impl();
 int aesr_bn_fused_run(const float* y, const float* gout, float* out, float* rec, unsigned* bar, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, long long* nbt, float* mean, float* invstd, float* scale, float* shift, float* coef,
                       float* dgamma, float* dbeta, int N, int H, int W, int C, int pool, int G, const int* nstart, const double* counts,
-                      float momentum, float eps, int update_running, int act, float slope, int backward, hipStream_t st);
+                      float momentum, float eps, int update_running, int act, float slope, int backward, const BnP2P* p2p, hipStream_t st);
 int aesr_launch_bn_stats(const float* y, float* partial, int HW, int C, const BnGroups& gr, int nwg, hipStream_t st);
 int aesr_launch_bn_reduce(const float* partial, double* sums, int nwg, int C, int G, hipStream_t st);
 int aesr_launch_bn_finalize(const double* sums, const double* counts, const float* gamma, const float* beta, float* rm, float* rv,

@@ -30,9 +30,11 @@
 // records -- no agent-scope fences (the first form of this kernel had both: 3.4 us of its 17-20).  EVERY spin is bounded: a wait that gives up (a workgroup that never became resident: the device is shared with
 // another grid-barrier kernel) counts in g_bn_fused_timeouts and the kernel finishes on garbage; the host raises at the next
 // boundary (_hip.check_device_watchdogs), as for the ring kernel.
+#include <stdlib.h>
+
 #include "aesr_kernels.h"
 
-#define BF_NB 256                 // workgroups of a launch: one per CU
+#define BF_NB_MAX 256             // workgroups of a launch: one per CU (AESR_BN_FUSED_NB = 64 / 128 for rehearsals of several ranks on ONE device)
 #define BF_NT 512
 #define BF_RED_FL (BF_NT * 8)     // floats of the reduction scratch: [512 / C4][2][C] floats = [row-lanes][G 2 C] doubles at most = 16 KB
 #define BF_SPIN_LIMIT (1 << 20)
@@ -63,7 +65,7 @@ __device__ __forceinline__ f32x4 bf_load_sc1(const __amdgpu_buffer_rsrc_t rs, in
 }
 
 // all BF_NB workgroups of the grid; every thread of the workgroup calls it.  Publishes NOTHING but sc1-stored bytes (see above).
-__device__ __forceinline__ void bf_grid_barrier(unsigned* bar) {
+__device__ __forceinline__ void bf_grid_barrier(unsigned* bar, int nb) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's (write-through) stores have been performed
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -71,7 +73,7 @@ __device__ __forceinline__ void bf_grid_barrier(unsigned* bar) {
         const unsigned my_gen = __hip_atomic_load(bar + GB_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool last = false;
         const unsigned a = __hip_atomic_fetch_add(bar + GB_SHARD(blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        if ((a & (BF_NB / 8 - 1)) == 0u) {
+        if ((a & (unsigned)(nb / 8 - 1)) == 0u) {          // nb / 8 is a power of two
             const unsigned t = __hip_atomic_fetch_add(bar + GB_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
             last = (t & 7u) == 0u;
         }
@@ -102,6 +104,11 @@ struct BnFusedArgs {
     int N, H, W, C, Ho, Wo, pool;   // pool: AvgPool2d(2) follows (out / gout are [N][H/2][W/2][C])
     int RU, upi, nunits, unit_fl, gunit_fl;      // rows per unit, units per image, units, floats of a unit of y / of the gathered gradient
     int G, update_running, act;
+    int nb;                         // workgroups of the launch (64, 128 or 256)
+    // data parallel (SyncBN over peer-mapped regions, p2p.hip): world > 0
+    int world, rank, slot, p2p_spins;      // p2p_spins: polls before a wait for a peer gives up (AESR_P2P_SPINS; ~4 us each after the first 4096)
+    const unsigned* gen;            // device word: the step generation (same on every rank; aesr_p2p_tick advances it once per step)
+    unsigned char* peers[8];        // every rank's exchange region as mapped into this process (peers[rank] = this rank's own)
     float momentum, eps, slope;
     double counts[4];
     int nstart[5];
@@ -131,7 +138,7 @@ __device__ __forceinline__ void bf_flush(float* red, float* tot, int g, int C, f
 }
 
 // totd[o] (fp64, LDS) = sum over the BF_NB records of column o, o < GC2 = G * 2 * C (a multiple of 8, <= 512): fixed order
-__device__ __forceinline__ void bf_totals(const float* __restrict__ rec, int GC2, float* red, double* totd) {
+__device__ __forceinline__ void bf_totals(const float* __restrict__ rec, int GC2, float* red, double* totd, int BF_NB) {
     const int nq = GC2 >> 2, RL = BF_NT / nq;                 // column quads, row-lanes per quad (>= 4)
     const int col = threadIdx.x % nq, rl = threadIdx.x / nq;
     double* redd = (double*)red;                              // [RL][GC2] doubles <= 16 KB
@@ -168,10 +175,58 @@ __device__ __forceinline__ void bf_totals(const float* __restrict__ rec, int GC2
     __syncthreads();
 }
 
+// ---- data parallel: one-shot exchange of the totals over peer-mapped regions (p2p.hip) ----------------------------------------------
+// Region layout (bytes): record of rank r for slot k, parity q at ((k * 2 + q) * world + r) * P2P_REC: [512 doubles | flag line of 128 B].
+// A slot is one BatchNorm call of the step (numbered in call order, the same on every rank); the parity is the generation's low bit.
+// Workgroup 0 writes THIS rank's totals into every rank's region (system-scope stores over xGMI), fences, and stores the generation into
+// its flag there; EVERY workgroup then waits until all `world` flags of the slot in ITS OWN region show the generation and adds the
+// records in rank order (fixed order: the same bits on every rank).  Producers never wait for consumers: a rank reaches slot k of step
+// t + 1 only behind the gradient all-reduce of step t, which every rank enters after it has consumed all slots of step t.
+#define P2P_REC (512 * 8 + 128)
+#define P2P_SPIN_LIMIT (1 << 23)
+__device__ __forceinline__ void bf_exchange(const BnFusedArgs& a, int GC2, double* totd) {
+    const int tid = threadIdx.x, W = a.world;
+    const unsigned gen = *a.gen;
+    const size_t base = ((size_t)(a.slot * 2 + (int)(gen & 1u)) * W) * P2P_REC;
+    if (blockIdx.x == 0) {
+        for (int p = 0; p < W; ++p) {
+            double* dst = (double*)(a.peers[p] + base + (size_t)a.rank * P2P_REC);
+            for (int o = tid; o < GC2; o += BF_NT) __hip_atomic_store(dst + o, totd[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's (write-through, system-scope) stores have been performed
+        __syncthreads();
+        if (tid < W) {                                            // ONE wave fences and signals (eight system-scope fences cost eight times one)
+            unsigned* flag = (unsigned*)(a.peers[tid] + base + (size_t)a.rank * P2P_REC + 512 * 8);
+            __hip_atomic_store(flag, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    unsigned char* mine = a.peers[a.rank] + base;
+    if (tid < W) {
+        const unsigned* flag = (const unsigned*)(mine + (size_t)tid * P2P_REC + 512 * 8);
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != gen) {
+            if (spins < 4096) __builtin_amdgcn_s_sleep(4);
+            else __builtin_amdgcn_s_sleep(127);
+            if (++spins > a.p2p_spins) {               // a peer that never arrives: give up (counted; the host raises), never hang
+                atomicAdd(&g_bn_fused_timeouts, 1u);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    __syncthreads();
+    for (int o = tid; o < GC2; o += BF_NT) {
+        double t = 0.0;
+        for (int r = 0; r < W; ++r) t += __hip_atomic_load((const double*)(mine + (size_t)r * P2P_REC) + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        totd[o] = t;
+    }
+    __syncthreads();
+}
+
 // LDS: [data: maxu * (unit_fl + gunit_fl)] [red: BF_RED_FL] [tot: 512 floats] [totd: 512 doubles] [tabA: 512] [tabB: 512]
 __global__ __launch_bounds__(BF_NT, 2) void bn_fused_fwd_kernel(BnFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int C = a.C, C4 = C >> 2, tid = threadIdx.x, b = blockIdx.x;
+    const int C = a.C, C4 = C >> 2, tid = threadIdx.x, b = blockIdx.x, BF_NB = a.nb;
     const int u0 = (int)((long long)b * a.nunits / BF_NB), u1 = (int)((long long)(b + 1) * a.nunits / BF_NB);
     const int maxu = (a.nunits + BF_NB - 1) / BF_NB;
     float* data = lds;
@@ -214,9 +269,10 @@ __global__ __launch_bounds__(BF_NT, 2) void bn_fused_fwd_kernel(BnFusedArgs a) {
     if (cur_g >= 0) bf_flush(red, tot, cur_g, C, s, q);
     else __syncthreads();
     for (int o = tid; o < (GC2 >> 2); o += BF_NT) bf_store_sc1(a.rec, (size_t)BF_NB * GC2 * 4, (b * GC2 + o * 4) * 4, *(const f32x4*)(tot + o * 4));
-    bf_grid_barrier(a.bar);
+    bf_grid_barrier(a.bar, BF_NB);
     // ---- phase 2: totals of all workgroups, finalize (bn.hip: bn_finalize_vals / bn_finalize_apply_kernel) ----
-    bf_totals(a.rec, GC2, red, totd);
+    bf_totals(a.rec, GC2, red, totd, BF_NB);
+    if (a.world > 0) bf_exchange(a, GC2, totd);
     const int GC = a.G * C;
     for (int i = tid; i < GC; i += BF_NT) {
         const int g = i / C, c = i - g * C;
@@ -282,7 +338,7 @@ __global__ __launch_bounds__(BF_NT, 2) void bn_fused_fwd_kernel(BnFusedArgs a) {
 
 __global__ __launch_bounds__(BF_NT, 2) void bn_fused_bwd_kernel(BnFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int C = a.C, C4 = C >> 2, tid = threadIdx.x, b = blockIdx.x;
+    const int C = a.C, C4 = C >> 2, tid = threadIdx.x, b = blockIdx.x, BF_NB = a.nb;
     const int u0 = (int)((long long)b * a.nunits / BF_NB), u1 = (int)((long long)(b + 1) * a.nunits / BF_NB);
     const int maxu = (a.nunits + BF_NB - 1) / BF_NB;
     float* data = lds;                                              // per unit: y [unit_fl] then the gathered gradient [gunit_fl]
@@ -363,9 +419,10 @@ __global__ __launch_bounds__(BF_NT, 2) void bn_fused_bwd_kernel(BnFusedArgs a) {
     if (cur_g >= 0) bf_flush(red, tot, cur_g, C, s1, s2);
     else __syncthreads();
     for (int o = tid; o < (GC2 >> 2); o += BF_NT) bf_store_sc1(a.rec, (size_t)BF_NB * GC2 * 4, (b * GC2 + o * 4) * 4, *(const f32x4*)(tot + o * 4));
-    bf_grid_barrier(a.bar);
+    bf_grid_barrier(a.bar, BF_NB);
     // ---- phase 2: coefficients (bn.hip: bn_bwd_finalize_apply_kernel) ----
-    bf_totals(a.rec, GC2, red, totd);
+    bf_totals(a.rec, GC2, red, totd, BF_NB);
+    if (a.world > 0) bf_exchange(a, GC2, totd);
     for (int i = tid; i < GC2; i += BF_NT) {
         const int g = i / (2 * C);
         const float k = (float)(totd[i] / a.counts[g]);
@@ -415,6 +472,18 @@ __global__ __launch_bounds__(BF_NT, 2) void bn_fused_bwd_kernel(BnFusedArgs a) {
 }
 
 // ---- launcher ----------------------------------------------------------------------------------------------------------------
+// workgroups per launch: 256 = one per CU; AESR_BN_FUSED_NB = 64 / 128 lets several ranks that are REHEARSED on one device be resident
+// together (their kernels wait for each other's records).  Read once: a barrier state must always meet the same number.
+static int bf_nb() {
+    static int nb = 0;
+    if (nb == 0) {
+        const char* e = getenv("AESR_BN_FUSED_NB");
+        const int v = e ? atoi(e) : BF_NB_MAX;
+        nb = (v == 64 || v == 128) ? v : BF_NB_MAX;
+    }
+    return nb;
+}
+
 static bool bf_plan(BnFusedArgs& a, int backward, size_t* shmem) {
     const int C4 = a.C / 4;
     if (a.C % 4 != 0 || C4 <= 0 || BF_NT % C4 != 0 || a.G < 1 || a.G > 4 || a.G * 2 * a.C > 512) return false;
@@ -424,7 +493,8 @@ static bool bf_plan(BnFusedArgs& a, int backward, size_t* shmem) {
     a.nunits = a.N * a.upi;
     a.unit_fl = a.RU * a.W * a.C;
     a.gunit_fl = backward ? (a.pool ? ((a.Wo * a.C + 3) & ~3) : a.unit_fl) : 0;
-    const size_t maxu = (size_t)(a.nunits + BF_NB - 1) / BF_NB;
+    a.nb = bf_nb();
+    const size_t maxu = (size_t)(a.nunits + a.nb - 1) / a.nb;
     *shmem = (maxu * (size_t)(a.unit_fl + a.gunit_fl) + BF_RED_FL + 512 + 1024 + 1024) * sizeof(float);
     return *shmem <= (size_t)150 * 1024;
 }
@@ -435,7 +505,7 @@ static int bf_device_ok() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= AESR_MAX_DEVICES) return 0;
     if (ok[dev] == 0) {
         int cus = 0;
-        ok[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= BF_NB) ? 1 : -1;
+        ok[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= BF_NB_MAX) ? 1 : -1;
         if (ok[dev] == 1) {
             const hipError_t e1 = hipFuncSetAttribute((const void*)bn_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             const hipError_t e2 = hipFuncSetAttribute((const void*)bn_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -458,8 +528,8 @@ int aesr_launch_bn_fused(BnFusedArgs a, int backward, hipStream_t st) {
         aesr_set_error("bn_fused: %d x %d x %d x %d (%d groups) does not fit the one-launch form (aesr_bn_fused1_supported)", a.N, a.H, a.W, a.C, a.G);
         return AESR_ERR_UNSUPPORTED;
     }
-    if (backward) hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3(BF_NB), dim3(BF_NT), shmem, st, a);
-    else hipLaunchKernelGGL(bn_fused_fwd_kernel, dim3(BF_NB), dim3(BF_NT), shmem, st, a);
+    if (backward) hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3(a.nb), dim3(BF_NT), shmem, st, a);
+    else hipLaunchKernelGGL(bn_fused_fwd_kernel, dim3(a.nb), dim3(BF_NT), shmem, st, a);
     AESR_LAUNCH_CHECK(backward ? "bn_fused_bwd" : "bn_fused_fwd");
     return AESR_OK;
 }
@@ -467,8 +537,14 @@ int aesr_launch_bn_fused(BnFusedArgs a, int backward, hipStream_t st) {
 int aesr_bn_fused_run(const float* y, const float* gout, float* out, float* rec, unsigned* bar, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, long long* nbt, float* mean, float* invstd, float* scale, float* shift, float* coef,
                       float* dgamma, float* dbeta, int N, int H, int W, int C, int pool, int G, const int* nstart, const double* counts,
-                      float momentum, float eps, int update_running, int act, float slope, int backward, hipStream_t st) {
+                      float momentum, float eps, int update_running, int act, float slope, int backward, const BnP2P* p2p, hipStream_t st) {
     BnFusedArgs a = {};
+    if (p2p) {
+        const char* e = getenv("AESR_P2P_SPINS");             // tests shorten the wait for a peer that never comes (default ~30 s)
+        a.p2p_spins = e && atoi(e) > 0 ? atoi(e) : P2P_SPIN_LIMIT;
+        a.world = p2p->world; a.rank = p2p->rank; a.slot = p2p->slot; a.gen = p2p->gen;
+        for (int r = 0; r < 8; ++r) a.peers[r] = r < p2p->world ? (unsigned char*)p2p->peers[r] : nullptr;
+    }
     a.y = y; a.gout = gout; a.out = out; a.rec = rec; a.bar = bar; a.gamma = gamma; a.beta = beta; a.running_mean = running_mean;
     a.running_var = running_var; a.nbt = nbt; a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.coef = coef;
     a.dgamma = dgamma; a.dbeta = dbeta; a.N = N; a.H = H; a.W = W; a.C = C; a.pool = pool; a.Ho = pool ? H / 2 : H; a.Wo = pool ? W / 2 : W;
@@ -476,4 +552,19 @@ int aesr_bn_fused_run(const float* y, const float* gout, float* out, float* rec,
     for (int g = 0; g < 4; ++g) a.counts[g] = g < G ? counts[g] : 1.0;
     for (int g = 0; g <= 4; ++g) a.nstart[g] = g <= G ? nstart[g] : nstart[G];
     return aesr_launch_bn_fused(a, backward, st);
+}
+
+// the step generation of the peer exchange: advanced once per step on every rank (a graph node like any other kernel)
+__global__ void p2p_tick_kernel(unsigned* gen) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned g = *gen + 1u;
+        if (g == 0u) g = 1u;          // 0 is the "never written" value of the flags
+        *gen = g;
+    }
+}
+
+int aesr_launch_p2p_tick(unsigned* gen, hipStream_t st) {
+    hipLaunchKernelGGL(p2p_tick_kernel, dim3(1), dim3(64), 0, st, gen);
+    AESR_LAUNCH_CHECK("p2p_tick");
+    return AESR_OK;
 }

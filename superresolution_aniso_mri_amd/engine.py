@@ -470,6 +470,17 @@ class SequentialRunner:
             t = self._bn_bar = torch.zeros((int(lib.aesr_bn_fused1_barrier_words()),), device=dev, dtype=torch.int32)
         return t
 
+    sync_p2p = None     # optional parallel.PeerExchange: the SyncBN exchange inside the one-launch BatchNorm kernels (AESR_SYNCBN=p2p)
+
+    def _p2p_fits(self, N, H, W, C, run_mode, G, backward):
+        """Data parallel with the peer exchange: does this BatchNorm call take the one-launch kernel?  Decided on the LARGEST shard of
+        the step (uneven shards), so that every rank answers the same -- a rank in the kernel would wait for a rank in the all-reduce."""
+        p = self.sync_p2p
+        if p is None or not bn_fused_enabled():
+            return False
+        nmax = int(round(N * p.nscale))
+        return bool(lib.aesr_bn_fused1_supported(max(N, nmax), H, W, C, run_mode, G, backward))
+
     sync_bn = None      # optional callable(sums[G,2,C] double) -> all-reduced in place across ranks (data parallel SyncBN)
     count_scale = 1.0   # data parallel: global / local sub-batch size (B_global / B_local of this rank)
 
@@ -495,6 +506,18 @@ class SequentialRunner:
                                              ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
                                              ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(st["shift"]), N, H, W, C, run_mode, G,
                                              _hip.int_array(nstart), momentum, float(bn.eps), int(update), stream()), "aesr_bn_fused1_fwd")
+                st["applied"] = True
+                return st
+            if self.sync_bn is not None and out is not None and self._p2p_fits(N, H, W, C, run_mode, G, 0):
+                # data parallel, peer exchange: the same ONE launch; workgroup 0 writes this rank's sums into every rank's region and
+                # every workgroup adds all ranks' sums in rank order before it normalises
+                p = self.sync_p2p
+                ws = torch.empty((lib.aesr_bn_fused1_workspace_floats(C, G),), device=dev, dtype=torch.float32)
+                check(lib.aesr_bn_fused1_fwd_p2p(ptr(y), ptr(out), ptr(ws), ptr(self._bn_barrier(dev)), _hip.double_array(counts), ptr(bn.weight),
+                                                 ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
+                                                 ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(st["shift"]), N, H, W, C, run_mode, G,
+                                                 _hip.int_array(nstart), momentum, float(bn.eps), int(update), p.peers, p.world, p.rank,
+                                                 p.next_slot(), ptr(p.gen), stream()), "aesr_bn_fused1_fwd_p2p")
                 st["applied"] = True
                 return st
             if self.sync_bn is None:        # single process: statistics -> finalize without the sums round trip
@@ -708,6 +731,13 @@ class SequentialRunner:
                     check(lib.aesr_bn_fused1_bwd(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(ws),
                                                  ptr(self._bn_barrier(dev)), _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma), ptr(dbeta),
                                                  ptr(dpre), N, H, W, C, s.run_mode, prev.act, prev.slope, G, nsa, stream()), "aesr_bn_fused1_bwd")
+                elif self.sync_bn is not None and self._p2p_fits(N, H, W, C, s.run_mode, G, 1):
+                    p = self.sync_p2p
+                    ws = torch.empty((lib.aesr_bn_fused1_workspace_floats(C, G),), device=dev, dtype=torch.float32)
+                    check(lib.aesr_bn_fused1_bwd_p2p(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(ws),
+                                                     ptr(self._bn_barrier(dev)), _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma),
+                                                     ptr(dbeta), ptr(dpre), N, H, W, C, s.run_mode, prev.act, prev.slope, G, nsa, p.peers, p.world,
+                                                     p.rank, p.next_slot(), ptr(p.gen), stream()), "aesr_bn_fused1_bwd_p2p")
                 elif self.sync_bn is None:
                     check(lib.aesr_bn_bwd(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(partial),
                                           _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dpre), N, H, W,

@@ -18,7 +18,8 @@ from .. import ops
 def _check_watchdogs(trainer, where):
     """Kernel-side protocol watchdogs (``_hip.check_device_watchdogs``), for trainers whose model lives on the GPU (host-logic tests build
     CPU trainers that never launch a kernel)."""
-    p = next(iter(trainer.model.parameters()), None)
+    model = getattr(trainer, "model", None)
+    p = next(iter(model.parameters()), None) if model is not None else None
     if p is not None and p.is_cuda:
         from .._hip import check_device_watchdogs
         check_device_watchdogs(where)

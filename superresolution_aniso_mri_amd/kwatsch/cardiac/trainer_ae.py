@@ -101,6 +101,8 @@ class CombinedStepMixin(object):
         B = x.shape[0] // 2
         if hasattr(self.model, "prepare_weights"):
             self.model.prepare_weights()          # encoder + decoder operands after the last optimizer step: ONE launch
+        if self.dp is not None and self.dp.active:
+            self.dp.begin_step()                  # the peer exchange of the SyncBN sums (AESR_SYNCBN=p2p) advances its generation
         # enc(x[2B]) and the logging-only enc(slice_between[B]): one batched pass, two BatchNorm statistic groups
         z, z_ref = self.model.encode_multi([x, between], needs_grad=[True, False])
         a_from, a_to = self._mix_coefficients(batch_item, B)

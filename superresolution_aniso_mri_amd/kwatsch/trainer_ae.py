@@ -174,6 +174,8 @@ class AEBaseTrainer(BaseTrainer):
         self._note_batch(batch_item, "train")
         if hasattr(self.model, "prepare_weights"):
             self.model.prepare_weights()
+        if self.dp is not None and self.dp.active:
+            self.dp.begin_step()
         z = self.model.encode(x)
         out = self.model.decode(z)
         loss_ae = self.get_loss(x, out, is_test=False)["loss_ae"]

@@ -125,12 +125,13 @@ class HipAE(nn.Module):
         to three per network when their passes start; a no-op when nothing changed since the last call."""
         engine.prepare_weights([(self._runner(n), self._runner(n).train_steps()) for n in names if hasattr(self, n)])
 
-    def set_sync_bn(self, fn, count_scale=1.0):
+    def set_sync_bn(self, fn, count_scale=1.0, p2p=None):
         """Data parallel: ``fn(sums)`` all-reduces BatchNorm partial sums across ranks (SyncBN); ``count_scale`` =
-        B_global / B_local turns local element counts into global ones."""
+        B_global / B_local turns local element counts into global ones.  ``p2p``: a parallel.PeerExchange -- the exchange then happens
+        inside the one-launch BatchNorm kernels wherever the layer fits them (``fn`` stays the way for the others)."""
         for name in ("enc", "dec"):
             r = self._runner(name)
-            r.sync_bn, r.count_scale = fn, float(count_scale)
+            r.sync_bn, r.count_scale, r.sync_p2p = fn, float(count_scale), p2p
 
     # -- multi-group passes (one launch sequence, independent BatchNorm statistics per sub-batch) ---------
     def _pass(self, name, tensors, needs_grad=None):
@@ -239,9 +240,9 @@ class Discriminator(HipAE):
         self.encoder = Encoder(num_scales(args), args["depth"], args["latent"], args["colors"], n_res_block=args["n_res_block"],
                                use_batchnorm=args["use_batchnorm"]).to(args["device"])
 
-    def set_sync_bn(self, fn, count_scale=1.0):
+    def set_sync_bn(self, fn, count_scale=1.0, p2p=None):
         r = self._runner("encoder")
-        r.sync_bn, r.count_scale = fn, float(count_scale)
+        r.sync_bn, r.count_scale, r.sync_p2p = fn, float(count_scale), p2p
 
     def forward_multi(self, images):
         """One critic value per image for several sub-batches with independent BatchNorm statistics: list of [N_i] tensors."""

@@ -80,6 +80,69 @@ class SegmentedStepGraph(object):
                 self.collectives[i]()
 
 
+class PeerExchange(object):
+    """The one-shot SyncBN exchange (``AESR_SYNCBN=p2p``; csrc/p2p.hip, csrc/bn_fused.hip): every rank owns a small region of fine-grained
+    device memory that all ranks map through IPC handles (handed round on the gloo control plane); a BatchNorm call's partial sums are
+    then written straight into every peer's region by the ONE kernel that also computes the statistics and normalises -- no RCCL launch and
+    no graph cut per BatchNorm call (8 per step), only the gradient all-reduce is left.  SURVEY section 5: "one-shot ... direct P2P write
+    over the 7 links, which beats a ring at this size".  OPT-IN until a multi-GPU box has run it."""
+
+    def __init__(self, rank, world, device):
+        import ctypes
+        from ._hip import P2P_HANDLE_BYTES, check, lib
+        if world > 8:
+            raise RuntimeError("the peer exchange is built for one node (<= 8 ranks), got %d" % world)
+        self.rank, self.world = rank, world
+        self.nbytes = int(lib.aesr_p2p_region_bytes(world))
+        own = ctypes.c_void_p()
+        check(lib.aesr_p2p_alloc(self.nbytes, ctypes.byref(own)), "aesr_p2p_alloc")
+        self.own = own
+        self.opened = []
+        regions = [None] * world
+        regions[rank] = own.value
+        if world > 1:
+            h = ctypes.create_string_buffer(P2P_HANDLE_BYTES)
+            check(lib.aesr_p2p_get_handle(own, h), "aesr_p2p_get_handle")
+            handles = [None] * world
+            dist.all_gather_object(handles, h.raw)              # 64 bytes per rank over the gloo/TCP control plane
+            for r in range(world):
+                if r == rank:
+                    continue
+                peer = ctypes.c_void_p()
+                check(lib.aesr_p2p_open(handles[r], ctypes.byref(peer)), "aesr_p2p_open(rank %d)" % r)
+                regions[r] = peer.value
+                self.opened.append(peer)
+            dist.barrier()                                      # nobody writes before everybody has mapped everything
+        self.peers = (ctypes.c_void_p * 8)(*(regions + [None] * (8 - world)))
+        self.gen = torch.zeros(1, dtype=torch.int32, device=device)       # advanced once per step by aesr_p2p_tick
+        self.slot = 0
+        self.nscale = 1.0            # largest shard / this rank's shard (uneven shards): every rank must take the same kernel decision
+
+    def begin_step(self):
+        """Once per training step, before its first BatchNorm call: advance the generation (a kernel: captured like the rest of the step)
+        and start numbering the step's BatchNorm calls again."""
+        from ._hip import check, lib, ptr, stream
+        check(lib.aesr_p2p_tick(ptr(self.gen), stream()), "aesr_p2p_tick")
+        self.slot = 0
+
+    def next_slot(self):
+        from ._hip import P2P_SLOTS
+        s = self.slot
+        if s >= P2P_SLOTS:
+            raise RuntimeError("more than %d BatchNorm exchanges in one step" % P2P_SLOTS)
+        self.slot += 1
+        return s
+
+    def close(self):
+        from ._hip import lib
+        for peer in self.opened:
+            lib.aesr_p2p_close(peer)
+        self.opened = []
+        if self.own is not None:
+            lib.aesr_p2p_free(self.own)
+            self.own = None
+
+
 class DataParallelContext(object):
     """Control plane: a ``torch.distributed`` **gloo** group (rendezvous, barriers, host scalars, the RCCL unique id).
     Data plane on GPUs: an RCCL communicator owned behind the C ABI (``aesr_comm_*``, csrc/comm.hip) whose collectives are
@@ -110,6 +173,12 @@ class DataParallelContext(object):
         self.global_B = None
         self.segments = None            # a SegmentedStepGraph while a step is being captured (gloo data plane only)
         self.n_collectives = 0          # collectives issued so far (tests / DESIGN accounting)
+        # SyncBN exchange: "rccl" (default: an all-reduce per BatchNorm call on the data plane) or "p2p" (opt-in: one-shot writes into
+        # peer-mapped regions inside the BatchNorm kernels, PeerExchange)
+        self.syncbn = os.environ.get("AESR_SYNCBN", "rccl")
+        if self.syncbn not in ("rccl", "p2p"):
+            raise ValueError("AESR_SYNCBN must be 'rccl' or 'p2p', got %r" % (self.syncbn,))
+        self.p2p = None
 
     @property
     def active(self):
@@ -231,10 +300,26 @@ class DataParallelContext(object):
         self._update_model()
         return lo, hi
 
+    def ensure_p2p(self):
+        if self.p2p is None and self.syncbn == "p2p" and self.active and torch.cuda.is_available():
+            torch.cuda.synchronize()
+            self.p2p = PeerExchange(self.rank, self.world, self.device)
+        return self.p2p
+
+    def begin_step(self):
+        """Top of every training step (trainers call it): the peer exchange advances its generation."""
+        if self.p2p is not None:
+            self.p2p.begin_step()
+
     def _update_model(self):
         tr = getattr(self, "trainer", None)
         if tr is not None and hasattr(tr.model, "set_sync_bn"):
-            tr.model.set_sync_bn(self.sync_bn, 1.0 / self.weight if self.weight > 0 else 1.0)
+            p2p = self.ensure_p2p()
+            if p2p is not None and self.global_B:
+                lo, hi = self.shard_range(self.global_B)
+                largest = -(-self.global_B // self.world)
+                p2p.nscale = float(largest) / float(max(1, hi - lo))
+            tr.model.set_sync_bn(self.sync_bn, 1.0 / self.weight if self.weight > 0 else 1.0, p2p=p2p)
 
     # ---- hooks -----------------------------------------------------------------------------------------------
     def sync_bn(self, sums):
@@ -318,6 +403,16 @@ class DataParallelContext(object):
 
     def shutdown(self):
         """Tear the communicator and the process group down (quiet exit under torch.distributed.run)."""
+        if self.p2p is not None:
+            try:
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                if self.world > 1 and dist.is_initialized():
+                    dist.barrier()              # nobody unmaps a region a peer may still write to
+                self.p2p.close()
+            except Exception:              # noqa: BLE001
+                pass
+            self.p2p = None
         if self.comm is not None:
             from ._hip import lib
             try:

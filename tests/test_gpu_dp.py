@@ -31,8 +31,13 @@ def _args(mix):
     return a
 
 
-def _worker(rank, world, port, B, mix, out, graph=False, steps=2):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, world, port, B, mix, out, graph=False, steps=2, syncbn="rccl"):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AESR_SYNCBN=syncbn)
+    if syncbn == "p2p":
+        # several ranks REHEARSED on one device: their one-launch BatchNorm kernels wait for each other's records, so all of them must be
+        # resident together -- 64 workgroups each instead of one per CU
+        os.environ["AESR_BN_FUSED_NB"] = "64"
+        os.environ["AESR_P2P_SPINS"] = str(1 << 18)          # a peer that never arrives costs ~1 s here, not 30
     import warnings
     warnings.simplefilter("ignore")
     from superresolution_aniso_mri_amd.data_synth import shard_batch, synthetic_batch
@@ -48,12 +53,16 @@ def _worker(rank, world, port, B, mix, out, graph=False, steps=2):
         tr.enable_step_graph(eager_steps=1, dp_segments=True)      # step 0 eager, step 1 captured segment by segment, then replays
     for step in range(steps):
         tr.train(shard_batch(synthetic_batch(B, 32, 32, seed=40 + step, brain=True), rank, world), keep_predictions=False)
+    torch.cuda.synchronize()
+    from superresolution_aniso_mri_amd import _hip
+    _hip.check_device_watchdogs("data-parallel worker %d" % rank)
     if rank == 0:
-        torch.save({"sd": {k: v.cpu() for k, v in tr.model.state_dict().items()},
+        torch.save({"sd": {k: v.cpu() for k, v in tr.model.state_dict().items()}, "ncoll": dp.n_collectives,
                     "loss": [dp.reduce_scalar(v) for v in tr.losses["loss_ae"].floats()]}, out)
     else:
         [dp.reduce_scalar(v) for v in tr.losses["loss_ae"].floats()]
     dp.barrier()
+    dp.shutdown()
 
 
 @pytest.mark.parametrize("mix", ["mse", "perceptual"])
@@ -83,6 +92,36 @@ def test_two_ranks_equal_single_process(tmp_path, mix):
         assert float((diff > 1e-4 + 1e-3 * b.abs()).double().mean()) <= 0.03, k
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_ranks_peer_exchange_on_one_device(tmp_path, graph):
+    """AESR_SYNCBN=p2p (parallel.PeerExchange, csrc/p2p.hip): two ranks rehearsed on ONE device map each other's exchange region through IPC
+    handles; the SyncBN sums of the BatchNorm calls that fit the one-launch kernel travel as direct writes into the peer's region inside
+    that kernel (uneven shards: 1 + 2 triplets), the others and the gradients through the host-staged gloo data plane.  Must reproduce
+    the single-process step, host-launched and as graph segments; fewer collectives than the all-reduce form."""
+    import warnings
+    from superresolution_aniso_mri_amd.data_synth import synthetic_batch
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    B, steps = 3, 4
+    out = str(tmp_path / "p2p.pt")
+    mp.spawn(_worker, args=(2, _free_port(), B, "mse", out, graph, steps, "p2p"), nprocs=2, join=True)
+    res = torch.load(out)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(100)
+        ref = get_trainer_dynamic(_args("mse"))
+    for step in range(steps):
+        ref.train(synthetic_batch(B, 32, 32, seed=40 + step, brain=True), keep_predictions=False)
+    np.testing.assert_allclose(res["loss"], ref.losses["loss_ae"].floats(), rtol=2e-5)
+    for k, v in ref.model.state_dict().items():
+        a, b = res["sd"][k].double(), v.cpu().double()
+        if "num_batches" in k:
+            assert int(a) == int(b)
+            continue
+        diff = (a - b).abs()
+        assert float(diff.max()) <= steps * 2 * 1e-3 + 1e-6, k
+        assert float((diff > 1e-4 + 1e-3 * b.abs()).double().mean()) <= 0.03, k
+
+
 def test_segmented_step_graph_equals_host_launched_data_parallel(tmp_path):
     """Data parallel with the step captured as a chain of HIP graphs cut at the (eager) collectives
     (parallel.SegmentedStepGraph) == the host-launched data-parallel step: 5 steps (1 eager, 1 capture, 3 replays), two ranks
@@ -102,12 +141,12 @@ def test_segmented_step_graph_equals_host_launched_data_parallel(tmp_path):
             assert int(seg["sd"][k]) == int(v)
 
 
-def _rccl_worker(rank, port, out, graph_form):
+def _rccl_worker(rank, port, out, graph_form, syncbn="rccl"):
     """A data-parallel group of ONE on the library-owned RCCL communicator (RCCL refuses two ranks on one device, so a one-GPU box
     exercises the call pattern with nranks = 1): raw collectives, then the trainer step host-launched and captured -- as graph
     segments between eager RCCL enqueues (the default form) or as ONE graph with the RCCL calls as nodes (AESR_DP_GRAPH=whole)."""
     os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AESR_FORCE_DP="1",
-                      AESR_DP_GRAPH=graph_form)
+                      AESR_DP_GRAPH=graph_form, AESR_SYNCBN=syncbn)
     os.environ.pop("AESR_DIST_BACKEND", None)
     import ctypes
     import warnings
@@ -148,25 +187,29 @@ def _rccl_worker(rank, port, out, graph_form):
         if step == 0:
             res["collectives_per_step"] = dp.n_collectives - n0
     torch.cuda.synchronize()
+    _hip.check_device_watchdogs("one-rank data-parallel worker")
     res.update(graphs=len(tr._graphs), graph_dp=tr._graph_dp, loss=tr.losses["loss_ae"].floats(),
                sd={k: v.cpu() for k, v in tr.model.state_dict().items()})
     torch.save(res, out)
     dp.shutdown()
 
 
+@pytest.mark.parametrize("syncbn", ["rccl", "p2p"])
 @pytest.mark.parametrize("graph_form", ["segments", "whole"])
-def test_rccl_communicator_and_step_graph_forms(tmp_path, graph_form):
+def test_rccl_communicator_and_step_graph_forms(tmp_path, graph_form, syncbn):
     import warnings
     from superresolution_aniso_mri_amd.data_synth import synthetic_batch
     from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
     out = str(tmp_path / "rccl.pt")
-    mp.spawn(_rccl_worker, args=(_free_port(), out, graph_form), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(_free_port(), out, graph_form, syncbn), nprocs=1, join=True)
     res = torch.load(out)
     assert res["rccl_version"] >= 21800 and res["raw_ok"]
     assert res["bad_dtype"][0] != 0 and "dtype" in res["bad_dtype"][1]
     assert res["graphs"] == 1 and res["graph_dp"] == graph_form
-    # per step: 4 BatchNorm layers x (forward + backward) SyncBN exchanges + ONE flat gradient all-reduce
-    assert res["collectives_per_step"] == 9
+    # per step: 4 BatchNorm layers x (forward + backward) SyncBN exchanges + ONE flat gradient all-reduce; with the peer exchange the two
+    # encoder layers (BatchNorm + AvgPool: the one-launch kernel) exchange inside their kernels -- the decoder's of this small model keep
+    # the un-folded Upsample, which that kernel does not take
+    assert res["collectives_per_step"] == (9 if syncbn == "rccl" else 5)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         torch.manual_seed(100)
@@ -185,9 +228,9 @@ def test_rccl_communicator_and_step_graph_forms(tmp_path, graph_form):
 
 
 # ---- first contact with a real multi-GPU node: TWO ranks on DISTINCT devices over RCCL -----------------------------------------------
-def _rccl2_worker(rank, port, B, out, graph_form, steps):
+def _rccl2_worker(rank, port, B, out, graph_form, steps, syncbn="rccl"):
     os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      AESR_DP_GRAPH=graph_form or "segments", AESR_COMM_INIT_TIMEOUT="90", AESR_STEP_TIMEOUT="120")
+                      AESR_DP_GRAPH=graph_form or "segments", AESR_COMM_INIT_TIMEOUT="90", AESR_STEP_TIMEOUT="120", AESR_SYNCBN=syncbn)
     os.environ.pop("AESR_DIST_BACKEND", None)
     os.environ.pop("AESR_FORCE_DP", None)
     import warnings
@@ -209,6 +252,8 @@ def _rccl2_worker(rank, port, B, out, graph_form, steps):
         for step in range(steps):
             tr.train(shard_batch(synthetic_batch(B, 32, 32, seed=40 + step, brain=True), rank, 2), keep_predictions=False)
         dp.synchronize()
+        from superresolution_aniso_mri_amd import _hip
+        _hip.check_device_watchdogs("rank %d" % rank)
         losses = [dp.reduce_scalar(v) for v in tr.losses["loss_ae"].floats()]
         if rank == 0:
             torch.save({"sd": {k: v.cpu() for k, v in tr.model.state_dict().items()}, "loss": losses,
@@ -218,9 +263,10 @@ def _rccl2_worker(rank, port, B, out, graph_form, steps):
         dp.shutdown()
 
 
+@pytest.mark.parametrize("syncbn", ["rccl", "p2p"])
 @pytest.mark.parametrize("graph_form", [None, "segments", "whole"])
 @pytest.mark.parametrize("B", [4, 3])
-def test_two_gpus_rccl_equal_single_process(tmp_path, graph_form, B):
+def test_two_gpus_rccl_equal_single_process(tmp_path, graph_form, B, syncbn):
     """Needs two GPUs (skipped on the one-GPU build box; the driver's 8-GPU node runs it): two ranks on distinct devices through
     aesr_comm_init, 5 steps host-launched / as graph segments between eager RCCL collectives / as one graph with the collectives as
     nodes, even (2 + 2) and uneven (1 + 2 triplets) shards; every form must reproduce the single-process run."""
@@ -232,7 +278,7 @@ def test_two_gpus_rccl_equal_single_process(tmp_path, graph_form, B):
     out = str(tmp_path / "rccl2.pt")
     steps = 5
     try:
-        mp.spawn(_rccl2_worker, args=(_free_port(), B, out, graph_form, steps), nprocs=2, join=True)
+        mp.spawn(_rccl2_worker, args=(_free_port(), B, out, graph_form, steps, syncbn), nprocs=2, join=True)
     except Exception as e:                                  # noqa: BLE001
         # the opt-in form (multi-rank RCCL collectives captured as graph nodes) has never met two devices before this run.  Only a
         # REFUSAL to capture (RCCL / HIP saying the operation is not permitted or not supported while a stream is capturing) is an
