@@ -196,7 +196,7 @@ def roofline_of(engine, device, nst, config, B, H, gpus, scales3=False):
     # HBM-side bytes per launch of the same kernel: PMC counters cannot be read from inside this process; they come from the
     # committed rocprofv3 --pmc passes of this very command (scripts/profile_all.sh -> profiles/), N=1 and B=12 only, and only
     # while the kernel sources are the ones the passes were measured on
-    tpath = os.path.join(ROOT, "profiles", "r03_%s_hbm_traffic.json" % config)
+    tpath = os.path.join(ROOT, "profiles", "r04_%s_hbm_traffic.json" % config)
     if gpus == 1 and B == 12 and os.path.exists(tpath):
         tj = json.load(open(tpath))
         if tj.get("csrc_sha") == csrc_sha():
@@ -204,10 +204,10 @@ def roofline_of(engine, device, nst, config, B, H, gpus, scales3=False):
             nl = sum(v["launches_per_step"] for v in ig)
             if nl > 0:
                 roofline["traffic"] = round(sum(v["MB_per_step"] for v in ig) / nl * 1e6)
-                roofline["traffic_unit"] = ("bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_%s_hbm_traffic.json, "
+                roofline["traffic_unit"] = ("bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r04_%s_hbm_traffic.json, "
                                             "kernel sources %s)" % (config, tj["csrc_sha"]))
         else:
-            roofline["traffic_note"] = "profiles/r03_%s_hbm_traffic.json was measured on other kernel sources (%s, now %s): not quoted" % (
+            roofline["traffic_note"] = "profiles/r04_%s_hbm_traffic.json was measured on other kernel sources (%s, now %s): not quoted" % (
                 config, tj.get("csrc_sha"), csrc_sha())
     return roofline
 

@@ -56,7 +56,7 @@ for name, h, cin, cout, nf, nb in LAYERS:
         fl, mf = floor_us(n, h, kin, nout)
         kind = KIND.get(L.aesr_conv2d_wino_kernel(n, h, h, cin, cout, 3, 1, tr), "?") + (" +split" if nws else "")
         gf = mf * 2 * 16 * 16 * 4 / 1e9
-        print("%-26s %-9s %-20s %8.1f %8.1f %8.3f %7.1f" % (name, direction, kind, t, fl, gf, gf / t * 1e-3 * 1e6 / 1e3))
+        print("%-26s %-9s %-20s %8.1f %8.1f %8.3f %7.1f" % (name, direction, kind, t, fl, gf, gf / t * 1e3))
         d = tot.setdefault(direction, [0.0, 0.0, 0.0])
         d[0] += t; d[1] += fl; d[2] += gf
     # weight gradient (Winograd form where both channel counts are multiples of 32)
@@ -69,8 +69,8 @@ for name, h, cin, cout, nf, nb in LAYERS:
     t = timeit(fn) * 1e6
     fl, mf = floor_us(n, h, cin, cout)
     gf = mf * 2 * 16 * 16 * 4 / 1e9
-    print("%-26s %-9s %-20s %8.1f %8.1f %8.3f %7.1f   (slabs %.1f MB)" % (name, "wgrad", "conv_wgrad_wino_f32", t, fl, gf, gf / t, wsz * 4 / 1e6))
+    print("%-26s %-9s %-20s %8.1f %8.1f %8.3f %7.1f   (slabs %.1f MB)" % (name, "wgrad", "conv_wgrad_wino_f32", t, fl, gf, gf / t * 1e3, wsz * 4 / 1e6))
     d = tot.setdefault("wgrad", [0.0, 0.0, 0.0])
     d[0] += t; d[1] += fl; d[2] += gf
 for k, (t, fl, gf) in tot.items():
-    print("TOTAL %-6s %8.1f us measured, %7.1f us at the MFMA rate evenly spread (%.0f %%), %.2f GF executed = %.1f TF" % (k, t, fl, 100 * fl / t, gf, gf / t))
+    print("TOTAL %-6s %8.1f us measured, %7.1f us at the MFMA rate evenly spread (%.0f %%), %.2f GF executed = %.1f TF" % (k, t, fl, 100 * fl / t, gf, gf / t * 1e3))
