@@ -72,6 +72,8 @@ class AEBaseTrainer(BaseTrainer):
             if self.dp is not None and self.dp.active:
                 self.dp.allreduce_gradients(self.opt_ae)
             self.opt_ae.step()
+        elif self.dp is not None and self.dp.active:
+            self.dp.step_fence()                 # no gradient all-reduce in this step: keep the ranks in step for the peer exchange
         if self.opt_sched_ae is not None:
             self.opt_sched_ae.step()
 
@@ -115,6 +117,8 @@ class AEBaseTrainer(BaseTrainer):
         sig = tuple((k, tuple(dev_batch[k].shape)) for k in keys)
         g = self._graphs.get(sig)
         if g is None:
+            if hasattr(self.model, "ensure_bn_barriers"):
+                self.model.ensure_bn_barriers()         # state the captured kernels own: born outside the graph's memory pool
             # a "_persistent" batch (data_device.TripletAugmenter: one output buffer that every batch is written into) IS the static input:
             # later batches arrive at the same addresses and nothing is copied
             adopt = bool(dev_batch.get("_persistent"))

@@ -125,6 +125,15 @@ class HipAE(nn.Module):
         to three per network when their passes start; a no-op when nothing changed since the last call."""
         engine.prepare_weights([(self._runner(n), self._runner(n).train_steps()) for n in names if hasattr(self, n)])
 
+    def ensure_bn_barriers(self, names=("enc", "dec")):
+        """Create the grid-barrier state of the one-launch BatchNorm kernels now (outside any graph capture): a step that is captured at a
+        batch size the eager steps never saw would otherwise meet ``SequentialRunner._bn_barrier`` for the first time inside the capture."""
+        for n in names:
+            if hasattr(self, n):
+                p = next(getattr(self, n).parameters(), None)
+                if p is not None and p.is_cuda:
+                    self._runner(n)._bn_barrier(p.device)
+
     def set_sync_bn(self, fn, count_scale=1.0, p2p=None):
         """Data parallel: ``fn(sums)`` all-reduces BatchNorm partial sums across ranks (SyncBN); ``count_scale`` =
         B_global / B_local turns local element counts into global ones.  ``p2p``: a parallel.PeerExchange -- the exchange then happens

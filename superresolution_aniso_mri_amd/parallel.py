@@ -311,6 +311,16 @@ class DataParallelContext(object):
         if self.p2p is not None:
             self.p2p.begin_step()
 
+    def step_fence(self):
+        """A step WITHOUT a gradient all-reduce (``train(..., eval_mode=True)``) under the peer exchange: the exchange re-uses its slots
+        on the promise that every rank has consumed step t before any rank writes step t + 1, which the gradient all-reduce keeps -- here a
+        4-byte all-reduce stands in for it."""
+        if self.p2p is not None:
+            buf = self.__dict__.get("_fence_buf")
+            if buf is None:
+                buf = self._fence_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._all_reduce(buf)
+
     def _update_model(self):
         tr = getattr(self, "trainer", None)
         if tr is not None and hasattr(tr.model, "set_sync_bn"):

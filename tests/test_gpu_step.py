@@ -262,6 +262,29 @@ def test_two_captured_trainers_on_two_streams_keep_their_loss_workspaces_apart(m
         assert b1.losses[key].floats() == b0.losses[key].floats(), key
 
 
+def test_step_captured_with_kernels_the_eager_steps_never_ran(monkeypatch):
+    """The one-launch BatchNorm kernels own a grid-barrier state that must be born OUTSIDE a graph capture.  A step whose eager warm-up ran the
+    three-launch form (a larger batch; here: the switch) and whose capture meets the one-launch form first must still capture and replay
+    (AEBaseTrainer._train_graphed creates the state before it opens the capture)."""
+    rec = dict(np.load(os.path.join(GOLDEN, "step_k3_cardiac_mse.npz")))
+    ref, tr = make_trainer("cardiac_mse", rec), make_trainer("cardiac_mse", rec)
+    tr.enable_step_graph(eager_steps=1)
+    monkeypatch.setenv("AESR_BN_FUSED", "0")
+    tr.train(_batch(rec, 0), keep_predictions=False)                  # eager, three-launch BatchNorm: no barrier state exists yet
+    assert "_bn_bar" not in tr.model._runner("enc").__dict__
+    monkeypatch.setenv("AESR_BN_FUSED", "1")
+    for k in (1, 2, 1, 2):
+        tr.train(_batch(rec, k), keep_predictions=False)              # capture (one-launch BatchNorm inside), then replays
+    assert len(tr._graphs) == 1 and "_bn_bar" in tr.model._runner("enc").__dict__
+    for k in (0, 1, 2, 1, 2):
+        ref.train(_batch(rec, k), keep_predictions=False)
+    torch.cuda.synchronize()
+    from superresolution_aniso_mri_amd import _hip
+    _hip.check_device_watchdogs("test")
+    np.testing.assert_allclose(tr.losses["loss_ae"].floats(), ref.losses["loss_ae"].floats(), rtol=2e-3)
+    np.testing.assert_allclose(tr.losses["loss_ae"].floats()[:1], ref.losses["loss_ae"].floats()[:1], rtol=1e-6)
+
+
 @pytest.mark.parametrize("loss", ["mse", "perceptual"])
 def test_twenty_steps_track_the_oracle(loss):
     """20 consecutive training steps (lr 1e-4, distinct batches) on the HIP trainer and on the CPU oracle from the same start:
