@@ -501,8 +501,10 @@ def main():
         from superresolution_aniso_mri_amd._hip import lib as _lib
         line["csrc_sha"] = csrc_sha()
         line["ring_watchdog_timeouts"] = int(_lib.aesr_conv2d_wino_ring_timeouts())
-        if line["ring_watchdog_timeouts"]:          # a number measured on garbage is not a number: no line, non-zero exit
-            raise SystemExit("bench: the ring kernel's arrival-counter watchdog fired %d time(s); no result line is printed" % line["ring_watchdog_timeouts"])
+        line["bn_barrier_timeouts"] = int(_lib.aesr_bn_fused1_timeouts())
+        if line["ring_watchdog_timeouts"] or line["bn_barrier_timeouts"]:          # a number measured on garbage is not a number: no line, non-zero exit
+            raise SystemExit("bench: kernel-side watchdogs fired (ring arrival counters %d, BatchNorm grid barrier / peer exchange %d); no result line "
+                             "is printed" % (line["ring_watchdog_timeouts"], line["bn_barrier_timeouts"]))
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     finally:
         dp.shutdown()
