@@ -65,7 +65,8 @@ def main(argv=None, brain=False):
             "same batch layout) or feed trainer.train() from your own loader (dataset '{}')".format(args_dict["dataset"]))
     dp = DataParallelContext()
     if str(args_dict["device"]).startswith("cuda") and dp.world > 1:
-        args_dict["device"] = "cuda:%d" % dp.local_rank
+        # AESR_SINGLE_DEVICE=1 (with AESR_DIST_BACKEND=gloo): several ranks REHEARSED on one device, as bench.py does
+        args_dict["device"] = "cuda:%d" % (0 if os.environ.get("AESR_SINGLE_DEVICE") == "1" else dp.local_rank)
     if str(args_dict["device"]).startswith("cuda"):
         dev = torch.device(args_dict["device"])
         torch.cuda.set_device(dev.index if dev.index is not None else 0)

@@ -91,3 +91,35 @@ def test_config1_mnist_shaped_step_vs_oracle():
         assert abs(trainer.losses[key][-1] - want) <= 3e-5 * abs(want), key
     rel = float((trainer.train_predictions["reconstruction"].double() - ref["out"].double()).norm() / ref["out"].double().norm())
     assert rel < 1e-5
+
+
+@pytest.mark.parametrize("syncbn", ["rccl", "p2p"])
+def test_two_rank_training_cli_on_one_device(tmp_path, syncbn):
+    """train_cardiac_aesr.py under torch.distributed.run with TWO ranks rehearsed on the one device of the test box (gloo data plane; with
+    AESR_SYNCBN=p2p the SyncBN sums travel through IPC-mapped peer regions inside the one-launch BatchNorm kernels): the loop, its deadline
+    syncs, the cross-rank epoch means and the rank-0 checkpoints; both exchange forms print the same epoch losses."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AESR_SINGLE_DEVICE="1", AESR_DIST_BACKEND="gloo", AESR_SYNCBN=syncbn, AESR_BN_FUSED_NB="64", AESR_P2P_SPINS=str(1 << 18))
+    out = str(tmp_path / "expers")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "train_cardiac_aesr.py"), "--dataset=ACDC", "--model=ae_combined", "--batch_size=4", "--test_batch_size=4", "--latent=16",
+           "--latent_width=8", "--width=32", "--depth=8", "--downsample_steps=2", "--epochs=2", "--lr=0.001", "--ex_loss_weight1=0.05", "--exper_id=dp",
+           "--output_dir=" + out, "--synthetic", "--iters_per_epoch=4", "--image_mix_loss_func=mse", "--epoch_threshold=0", "--use_step_graph"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("epoch")]
+    assert len(lines) == 2 and all("nan" not in ln for ln in lines), r.stdout[-1500:]
+    assert os.path.isfile(os.path.join(out, "dp", "models", "2.models")) and os.path.isfile(os.path.join(out, "dp", "settings.yaml"))
+    # both exchange forms compute the same global batch statistics: the printed epoch means agree to the printed digits
+    ref = tmp_path.parent / "two_rank_cli_lines.txt"
+    if ref.exists():
+        assert ref.read_text() == "\n".join(lines)
+    else:
+        ref.write_text("\n".join(lines))
