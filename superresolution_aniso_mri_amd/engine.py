@@ -493,6 +493,17 @@ class SequentialRunner:
         use_batch = train or bn.running_mean is None
         momentum = 0.1 if bn.momentum is None else float(bn.momentum)
         update = bool(train and bn.track_running_stats and bn.running_mean is not None)
+        if update:
+            self._bn_updates = getattr(self, "_bn_updates", 0) + 1       # the kernels write the running statistics through raw pointers
+        if not use_batch:
+            # eval mode: scale / shift follow from the running statistics alone -- computed once per state of the layer, not once per call
+            # (slice synthesis runs 6 BatchNorm calls per volume: 6 launches of a few hundred threads each)
+            key = (self.weights_epoch, getattr(self, "_bn_updates", 0), bn.weight._version, bn.bias._version, bn.running_mean._version,
+                   bn.running_var._version, bn.weight.data_ptr(), bn.running_mean.data_ptr(), G, str(dev))
+            cache = self.__dict__.setdefault("_eval_bn", {})
+            hit = cache.get(id(bn))
+            if hit is not None and hit[0] == key and not torch.cuda.is_current_stream_capturing():
+                return dict(hit[1])
         sums = counts = None
         if use_batch:
             partial = torch.empty((G * _hip.BN_NWG * 2 * C,), device=dev, dtype=torch.float32)
@@ -545,6 +556,8 @@ class SequentialRunner:
                                    ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(st["mean"]), ptr(st["invstd"]),
                                    ptr(st["scale"]), ptr(st["shift"]), C, G, momentum, float(bn.eps), int(use_batch),
                                    int(update), stream()), "aesr_bn_finalize")
+        if not use_batch and not torch.cuda.is_current_stream_capturing():
+            self.__dict__.setdefault("_eval_bn", {})[id(bn)] = (key, dict(st))
         return st
 
     # ---- backward --------------------------------------------------------------------------------------------
