@@ -402,6 +402,14 @@ int aesr_conv2d_wino_fwd(const float* in, const float* upacked, const float* bia
                          int Cout, int act, float slope, void* stream);
 int aesr_conv2d_wino_dgrad(const float* dy, const float* upacked_t, const float* x_saved, float* dx, int N, int H, int W, int Cin,
                            int Cout, int mask_act, float slope, void* stream);
+/* Inference: conv + activation + EVAL-mode BatchNorm [+ AvgPool2d(2)] in one launch (networks/acai_vanilla.py:55-59,68-70,87-92 under
+ * model.eval()): out = bn_scale[co] * [mean of each 2x2 window of] act(conv(in) + bias) + bn_shift[co]; pool: out is [N][H/2][W/2][Cout].
+ * bn_scale / bn_shift: [Cout] device arrays (gamma / sqrt(running_var + eps), beta - running_mean * scale: aesr_bn_finalize with train = 0).
+ * Bitwise what aesr_conv2d_wino_fwd followed by aesr_bn_apply gives.  Layers the resident-filter kernel serves only
+ * (aesr_conv2d_wino_fwd_bn_supported; the others keep the two launches). */
+int aesr_conv2d_wino_fwd_bn_supported(int N, int H, int W, int Cin, int Cout);
+int aesr_conv2d_wino_fwd_bn(const float* in, const float* upacked, const float* bias, const float* bn_scale, const float* bn_shift, float* out, int N,
+                            int H, int W, int Cin, int Cout, int act, float slope, int pool, void* stream);
 /* The same two with a caller-owned workspace for the CHANNEL SPLIT of small layers with many K-side channels (a small shard of a
  * data-parallel step; the deep VGG layers of lpips/pretrained_networks.py:107-116 at any batch): a layer with fewer work items than
  * the chip has SIMDs streams its K side serially per item (512 channels = 32 chunks of ~3 us), so conv_wino_ring_f32 splits the

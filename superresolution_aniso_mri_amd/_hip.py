@@ -141,6 +141,8 @@ SIGNATURES = {
     "aesr_conv2d_wino_fwd": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),
     "aesr_conv2d_wino_dgrad": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),
     "aesr_conv2d_wino_workspace_floats": (c_size_t, [c_int] * 6),
+    "aesr_conv2d_wino_fwd_bn_supported": (c_int, [c_int] * 5),
+    "aesr_conv2d_wino_fwd_bn": (c_int, [P, P, P, P, P, P] + [c_int] * 6 + [c_float, c_int, P]),
     "aesr_conv2d_wino_fwd_ws": (c_int, [P, P, P, P, P, c_size_t] + [c_int] * 6 + [c_float, P]),
     "aesr_conv2d_wino_dgrad_ws": (c_int, [P, P, P, P, P, c_size_t] + [c_int] * 6 + [c_float, P]),
     "aesr_conv2d_wino_fwd_up2": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),

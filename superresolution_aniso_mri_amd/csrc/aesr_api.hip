@@ -564,6 +564,36 @@ int aesr_conv2d_wino_dgrad_ws(const float* dy, const float* upacked_t, const flo
     return run_wino(dy, upacked_t, nullptr, x_saved, dx, N, H, W, Cout, Cin, ACT_NONE, mask_act, slope, (hipStream_t)stream, 0, 0, workspace, workspace_floats);
 }
 
+/* conv + activation + eval-mode BatchNorm (per-channel scale / shift) [+ AvgPool2d(2)] as one launch: the resident-filter kernel, and the
+   ring kernel where it takes the layer WITHOUT a workspace (no channel split: the epilogue has to see the finished sums) */
+int aesr_conv2d_wino_fwd_bn_supported(int N, int H, int W, int Cin, int Cout) {
+    if (!aesr_conv2d_wino_supported(Cin, Cout, 3, 1, 0) || N < 1 || H < 1 || W < 1) return 0;
+    const WinoPlan p = plan_wino(N, H, W, Cin, Cout);
+    WinoArgs a = {};
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.CinP = p.CinP; a.CoutP = p.CoutP;
+    a.plan_cost = p.cost;
+    if (aesr_wino_res_ok(a)) return 1;
+    return aesr_wino_ring_takes(a) ? 1 : 0;          /* a.ws_floats = 0: as the call below runs it */
+}
+
+int aesr_conv2d_wino_fwd_bn(const float* in, const float* upacked, const float* bias, const float* bn_scale, const float* bn_shift, float* out, int N,
+                            int H, int W, int Cin, int Cout, int act, float slope, int pool, void* stream) {
+    AESR_CHECK_ARG(in && upacked && bn_scale && bn_shift && out && N > 0 && H > 0 && W > 0, "aesr_conv2d_wino_fwd_bn: null pointer or empty shape");
+    AESR_CHECK_ARG(!pool || (H >= 2 && W >= 2), "aesr_conv2d_wino_fwd_bn: pooling needs H, W >= 2");
+    AESR_CHECK_ARG(aesr_conv2d_wino_fwd_bn_supported(N, H, W, Cin, Cout), "aesr_conv2d_wino_fwd_bn: %d -> %d at %d x %d x %d is not a resident-filter or ring-kernel layer "
+                   "(aesr_conv2d_wino_fwd_bn_supported)", Cin, Cout, N, H, W);
+    const WinoPlan p = plan_wino(N, H, W, Cin, Cout);
+    WinoArgs a = {};
+    a.in = in; a.upk = upacked; a.bias = bias; a.ysave = nullptr; a.out = out;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = p.CinP; a.Cout = Cout; a.CoutP = p.CoutP;
+    a.TI = p.TI; a.THt = p.THt; a.TWt = p.TWt;
+    a.plan_cost = p.cost;
+    a.act = act; a.mask_act = ACT_NONE; a.slope = slope; a.ksplit = 1;
+    a.post_scale = bn_scale; a.post_shift = bn_shift; a.post_pool = pool ? 1 : 0;
+    return aesr_launch_conv_wino(a, (hipStream_t)stream);
+}
+
 /* nearest Upsample(x2) in front of the convolution folded into the kernels (H, W = the convolution's = upsampled size, even) */
 int aesr_conv2d_wino_fwd_up2(const float* in_half, const float* upacked, const float* bias, float* out, int N, int H, int W, int Cin,
                              int Cout, int act, float slope, void* stream) {

@@ -45,6 +45,10 @@ struct WinoArgs {
     unsigned m_ksplit;           // ceil(2^32 / ksplit) (0: ksplit == 1)
     float* ws;                   // caller's workspace for the slabs (nullptr: no channel split)
     size_t ws_floats;
+    // eval-mode BatchNorm (+ AvgPool2d(2)) behind the activation, folded into the epilogue (resident-filter kernel, forward only):
+    // out = post_scale[co] * [mean of the 2x2 tile of] act(conv + bias) + post_shift[co]; post_pool: the output is [N][H/2][W/2][Cout]
+    const float* post_scale; const float* post_shift;
+    int post_pool;
 };
 int aesr_launch_conv_wino(const WinoArgs& a, hipStream_t st);
 bool aesr_wino_res_ok(const WinoArgs& a);                        // few input channels: the filter stays resident, waves run on their own

@@ -500,6 +500,10 @@ int aesr_launch_conv_wino(const WinoArgs& a_in, hipStream_t st) {
     }
     if (aesr_wino_res_ok(a)) return aesr_launch_conv_wino_res(a, st);      // Cin <= 32: resident filter, independent waves (conv_wino_res.hip)
     if (aesr_wino_ring_takes(a)) return aesr_launch_conv_wino_ring(a, st);      // filter chunks through an LDS ring (conv_wino_ring.hip)
+    if (a.post_scale) {
+        aesr_set_error("conv_wino: the folded eval-mode BatchNorm epilogue exists in the resident-filter and ring kernels only (aesr_conv2d_wino_fwd_bn_supported)");
+        return AESR_ERR_UNSUPPORTED;
+    }
     a.regs_y = ceil_div(ceil_div(a.H, 2), a.THt);
     a.regs_x = ceil_div(ceil_div(a.W, 2), a.TWt);
     a.nitems = ceil_div(a.N, a.TI) * a.regs_y * a.regs_x * (a.CoutP / WN_TN);

@@ -47,7 +47,9 @@ __device__ __forceinline__ void wr_st(__amdgpu_buffer_rsrc_t rs, int byte_off, f
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), rs, byte_off, 0, 0);
 }
 
-template <int WR_TN, bool MASK>
+// POST: eval-mode BatchNorm (a per-channel affine behind the activation) and the AvgPool2d(2) that follows it, in the epilogue -- a lane
+// holds one 2 x 2 output tile, which IS one pooling window; an instantiation of its own, so that the training kernels' code is untouched
+template <int WR_TN, bool MASK, bool POST = false>
 __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
     constexpr int WR_NB = WR_TN / 16;
     constexpr int WR_WFL = 16 * 4 * WR_TN * 4;      // floats of one U chunk (16 positions x 16 ci x TN co)
@@ -72,7 +74,8 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
 
     const int sh = a.in_up2 ? 1 : 0;
     const int inH = a.H >> sh, inW = a.W >> sh;                                              // stored size of the input tensor
-    const int outH = a.out_sum2 ? a.H >> 1 : a.H, outW = a.out_sum2 ? a.W >> 1 : a.W;        // stored size of the output tensor
+    const bool halfout = a.out_sum2 || (POST && a.post_pool);
+    const int outH = halfout ? a.H >> 1 : a.H, outW = halfout ? a.W >> 1 : a.W;              // stored size of the output tensor
     const int inimg = inH * inW * a.Cin * 4, inrow = inW * a.Cin * 4;                        // bytes of an input image / row
     // (sizes through readfirstlane: a 64-bit product lands in vector registers, and a resource there costs a waterfall loop per access)
     const int wbytes = __builtin_amdgcn_readfirstlane(16 * a.CinP * a.CoutP * 4);
@@ -254,6 +257,11 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
                     wr_st(rs_out, obs + cob, s);
                     continue;
                 }
+                f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f}, prow = psh, pm = psh;      // pooled: row sums as they come (8 registers, not 16)
+                if (POST && co < a.Cout) {
+                    psc = *(const f32x4*)(a.post_scale + co);
+                    psh = *(const f32x4*)(a.post_shift + co);
+                }
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     f32x4 Y[2];
@@ -274,12 +282,25 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] *= (ys[p][q][e] > 0.f ? 1.f : mslope);
                         }
-                        wr_st(rs_out, ob[p][q] + cob, o);
+                        if (POST) {
+                            if (a.post_pool) prow = q == 0 ? o : prow + o;
+                            else wr_st(rs_out, ob[p][q] + cob, o * psc + psh);              // bn.hip bn_apply: v * scale + shift
+                        } else {
+                            wr_st(rs_out, ob[p][q] + cob, o);
+                        }
                     }
+                    if (POST && a.post_pool) pm = p == 0 ? prow : pm + prow;
+                }
+                if (POST && a.post_pool) {
+                    // AvgPool2d(2) of the activated tile, then the affine: the arithmetic and order of bn.hip's bn_apply (pooling mode);
+                    // a window that sticks out of an odd image has no output (floor)
+                    const f32x4 m = pm * 0.25f;                     // ((o00 + o01) + (o10 + o11)) * 0.25
+                    const int obs = (y0 + 1 < a.H && x0 + 1 < a.W) ? ((cur_n * outH + (y0 >> 1)) * outW + (x0 >> 1)) * a.Cout * 4 : WR_OOB;
+                    wr_st(rs_out, obs + cob, m * psc + psh);
                 }
             }
         }
-        after_stores = !MASK && !a.out_sum2;        // exactly 4 NB stores follow the next patch's DMAs
+        after_stores = !MASK && !halfout;           // exactly 4 NB stores follow the next patch's DMAs
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no DMA may still be writing this workgroup's LDS when it is released
 #undef WR_DIV
@@ -309,14 +330,14 @@ bool aesr_wino_res_ok(const WinoArgs& a) {
     return level >= 2 && a.CinP <= 64 && waste <= 1.10;
 }
 
-template <int WR_TN, bool MASK>
+template <int WR_TN, bool MASK, bool POST = false>
 static int wino_res_launch_one(const WinoArgs& a, hipStream_t st) {
     const size_t shmem = wino_res_lds_bytes(a.CinP, WR_TN);
     static bool attr_set[AESR_MAX_DEVICES] = {};
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= AESR_MAX_DEVICES) dev_ = 0;
     if (!attr_set[dev_]) {
-        const hipError_t e_ = hipFuncSetAttribute((const void*)conv_wino_res_f32<WR_TN, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t e_ = hipFuncSetAttribute((const void*)conv_wino_res_f32<WR_TN, MASK, POST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e_ != hipSuccess) {
             aesr_set_error("conv_wino_res_f32: hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KB) failed: %s", hipGetErrorString(e_));
             return AESR_ERR_HIP;
@@ -332,7 +353,7 @@ static int wino_res_launch_one(const WinoArgs& a, hipStream_t st) {
     WinoArgs b = a;
     static const int xmap_on = getenv("AESR_WINO_XCD") ? atoi(getenv("AESR_WINO_XCD")) : 1;
     b.xcd_map = (xmap_on && grid % (8 * ncot) == 0) ? 1 : 0;
-    hipLaunchKernelGGL((conv_wino_res_f32<WR_TN, MASK>), dim3(grid), dim3(WR_NT), shmem, st, b);
+    hipLaunchKernelGGL((conv_wino_res_f32<WR_TN, MASK, POST>), dim3(grid), dim3(WR_NT), shmem, st, b);
     AESR_LAUNCH_CHECK("conv_wino_res_f32");
     return AESR_OK;
 }
@@ -357,6 +378,13 @@ int aesr_launch_conv_wino_res(const WinoArgs& a_in, hipStream_t st) {
     if (wino_res_lds_bytes(a.CinP, TN) > (size_t)160 * 1024) {
         aesr_set_error("conv_wino_res: %d input channels do not fit the resident filter", a.CinP);
         return AESR_ERR_ARG;
+    }
+    if (a.post_scale) {
+        if (a.ysave || a.out_sum2 || !a.post_shift) {
+            aesr_set_error("conv_wino_res: the folded eval-mode BatchNorm is a forward epilogue (no derivative mask, no 2x2-summing output)");
+            return AESR_ERR_ARG;
+        }
+        return TN == 32 ? wino_res_launch_one<32, false, true>(a, st) : wino_res_launch_one<16, false, true>(a, st);
     }
     if (TN == 32) return a.ysave ? wino_res_launch_one<32, true>(a, st) : wino_res_launch_one<32, false>(a, st);
     return a.ysave ? wino_res_launch_one<16, true>(a, st) : wino_res_launch_one<16, false>(a, st);

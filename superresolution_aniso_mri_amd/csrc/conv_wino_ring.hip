@@ -83,7 +83,8 @@ __device__ __forceinline__ void rg_st(__amdgpu_buffer_rsrc_t rs, int byte_off, f
 
 // PWT: pixel slots of a patch row (>= 2 TWt + 2) at compile time; rows are pitched PWT * 16 + 4 floats, so the 16 patch reads of a
 // chunk share 4 address registers (a run-time pitch cost 11 spilled registers, reloaded behind s_waitcnt vmcnt(0))
-template <int PWT, bool MASK>
+// POST: the folded eval-mode BatchNorm (+ AvgPool2d(2)) epilogue of conv_wino_res.hip, for the forward of slice synthesis
+template <int PWT, bool MASK, bool POST = false>
 __global__ __launch_bounds__(512, 2) void conv_wino_ring_f32(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -98,7 +99,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_ring_f32(WinoArgs a) {
 
     const int sh = a.in_up2 ? 1 : 0;
     const int inH = a.H >> sh, inW = a.W >> sh;                                              // stored size of the input tensor
-    const int outH = a.out_sum2 ? a.H >> 1 : a.H, outW = a.out_sum2 ? a.W >> 1 : a.W;        // stored size of the output tensor
+    const bool halfout = a.out_sum2 || (POST && a.post_pool);
+    const int outH = halfout ? a.H >> 1 : a.H, outW = halfout ? a.W >> 1 : a.W;              // stored size of the output tensor
     const int inimg = inH * inW * a.Cin * 4, inrow = inW * a.Cin * 4;                        // bytes of an input image / row
     const int ibytes = __builtin_amdgcn_readfirstlane(a.N * inimg);
     const int wbytes = __builtin_amdgcn_readfirstlane(16 * a.CinP * a.CoutP * 4);
@@ -379,6 +381,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_ring_f32(WinoArgs a) {
                     rg_st(rs_out, obs + cob + cur_so, s);
                     continue;
                 }
+                f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f}, prow = psh, pm = psh;      // pooled: row sums as they come (8 registers, not 16)
+                if (POST && co < a.Cout) {
+                    psc = *(const f32x4*)(a.post_scale + co);
+                    psh = *(const f32x4*)(a.post_shift + co);
+                }
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     f32x4 Y[2];
@@ -399,13 +406,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino_ring_f32(WinoArgs a) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] *= (ys[p][q][e] > 0.f ? 1.f : mslope);
                         }
-                        rg_st(rs_out, ob[p][q] + cob + cur_so, o);
+                        if (POST) {
+                            if (a.post_pool) prow = q == 0 ? o : prow + o;
+                            else rg_st(rs_out, ob[p][q] + cob, o * psc + psh);              // bn.hip bn_apply: v * scale + shift
+                        } else {
+                            rg_st(rs_out, ob[p][q] + cob + cur_so, o);
+                        }
                     }
+                    if (POST && a.post_pool) pm = p == 0 ? prow : pm + prow;
+                }
+                if (POST && a.post_pool) {
+                    // AvgPool2d(2) of the activated tile, then the affine, in bn_apply's order; an odd image's last row / column has no window
+                    const f32x4 m = pm * 0.25f;                     // ((o00 + o01) + (o10 + o11)) * 0.25
+                    const int obs = (okn && y0 + 1 < a.H && x0 + 1 < a.W) ? ((n * outH + (y0 >> 1)) * outW + (x0 >> 1)) * a.Cout * 4 : RG_OOB;
+                    rg_st(rs_out, obs + cob, m * psc + psh);
                 }
             }
         }
         if (!has_next) break;
-        after_stores = active && !MASK && !a.out_sum2;
+        after_stores = active && !MASK && !halfout;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no DMA may still be writing this workgroup's LDS when it is released
 #undef RG_DIV
@@ -594,20 +613,20 @@ unsigned aesr_wino_ring_timeouts() {
     return v;
 }
 
-template <int PWT, bool MASK>
+template <int PWT, bool MASK, bool POST = false>
 static int ring_launch_one(const WinoArgs& a, int grid, size_t shmem, hipStream_t st) {
     static bool attr_set[AESR_MAX_DEVICES] = {};
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= AESR_MAX_DEVICES) dev_ = 0;
     if (!attr_set[dev_]) {
-        const hipError_t e_ = hipFuncSetAttribute((const void*)conv_wino_ring_f32<PWT, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_MAX);
+        const hipError_t e_ = hipFuncSetAttribute((const void*)conv_wino_ring_f32<PWT, MASK, POST>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_MAX);
         if (e_ != hipSuccess) {
             aesr_set_error("conv_wino_ring_f32: hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KB - 256 B) failed: %s", hipGetErrorString(e_));
             return AESR_ERR_HIP;
         }
         attr_set[dev_] = true;
     }
-    hipLaunchKernelGGL((conv_wino_ring_f32<PWT, MASK>), dim3(grid), dim3(512), shmem, st, a);
+    hipLaunchKernelGGL((conv_wino_ring_f32<PWT, MASK, POST>), dim3(grid), dim3(512), shmem, st, a);
     AESR_LAUNCH_CHECK("conv_wino_ring_f32");
     return AESR_OK;
 }
@@ -655,8 +674,13 @@ int aesr_launch_conv_wino_ring(const WinoArgs& a_in, hipStream_t st) {
         aesr_set_error("conv_wino_ring: a channel split of %d was planned without a workspace", a.ksplit);
         return AESR_ERR_ARG;
     }
+    if (a.post_scale && (a.ksplit > 1 || a.ysave || a.out_sum2 || !a.post_shift)) {
+        aesr_set_error("conv_wino_ring: the folded eval-mode BatchNorm is a forward epilogue without a channel split (pass no workspace)");
+        return AESR_ERR_ARG;
+    }
     a.kchunks = ceil_div(a.CinP / 16, p.ksplit);
-    const size_t out_floats = (size_t)a.N * (a.out_sum2 ? a.H / 2 : a.H) * (a.out_sum2 ? a.W / 2 : a.W) * a.Cout;
+    const bool halfout = a.out_sum2 || (a.post_scale && a.post_pool);
+    const size_t out_floats = (size_t)a.N * (halfout ? a.H / 2 : a.H) * (halfout ? a.W / 2 : a.W) * a.Cout;
     if (out_floats * 4 * (size_t)a.ksplit >= (size_t)(a.ksplit > 1 ? 0x20000000 : RG_OOB)) {      // split: see ring_smax
         aesr_set_error("conv_wino_ring: %zu output bytes x %d channel splits exceed the kernel's 32-bit offsets", out_floats * 4, a.ksplit);
         return AESR_ERR_UNSUPPORTED;
@@ -686,7 +710,10 @@ int aesr_launch_conv_wino_ring(const WinoArgs& a_in, hipStream_t st) {
     if (const char* e = getenv("AESR_WINO_GRID")) grid = atoi(e);
     if (grid > a.nitems) grid = a.nitems;
     int rc = AESR_ERR_UNSUPPORTED;
-#define RG_CASE(pw) if (p.PWT == pw) rc = a.ysave ? ring_launch_one<pw, true>(a, grid, shmem, st) : ring_launch_one<pw, false>(a, grid, shmem, st);
+#define RG_CASE(pw)                                                                                                              \
+    if (p.PWT == pw)                                                                                                             \
+        rc = a.post_scale ? ring_launch_one<pw, false, true>(a, grid, shmem, st)                                                 \
+                          : (a.ysave ? ring_launch_one<pw, true>(a, grid, shmem, st) : ring_launch_one<pw, false>(a, grid, shmem, st));
     RG_CASE(8) RG_CASE(10) RG_CASE(12) RG_CASE(16)
 #undef RG_CASE
     if (rc == AESR_ERR_UNSUPPORTED) aesr_set_error("conv_wino_ring: no instantiation for a patch of %d pixel slots", p.PWT);

@@ -58,6 +58,8 @@ FUSE_STEM = os.environ.get("AESR_FUSE_STEM", "1") != "0"      # fold the encoder
 # results equal to the implicit GEMM within 2-4e-7); AESR_WINO=0 keeps every layer on the exact-fp32 fma-chain implicit GEMM
 USE_WINO = os.environ.get("AESR_WINO", "1") != "0"
 FOLD_UPSAMPLE = os.environ.get("AESR_FOLD_UPSAMPLE", "1") != "0"
+# inference: conv + activation + eval-mode BatchNorm (+ AvgPool2d(2)) as ONE launch where the resident-filter kernel serves the layer
+FUSE_EVAL_BN = os.environ.get("AESR_FUSE_EVAL_BN", "1") != "0"
 
 
 def bn_fused_enabled():
@@ -381,7 +383,11 @@ class SequentialRunner:
             steps = steps[first:last]
             if raw_last and (not steps or steps[-1].kind != "conv"):
                 raise RuntimeError("raw_last needs a convolution as the last step of the range")
-        for s in steps:
+        skip = False
+        for idx, s in enumerate(steps):
+            if skip:                # a BatchNorm that went into the epilogue of the convolution in front of it (eval mode)
+                skip = False
+                continue
             if s.kind == "stemconv":
                 if C != 1:
                     raise RuntimeError("channel mismatch: tensor has %d channels, the stem expects 1" % C)
@@ -416,6 +422,22 @@ class SequentialRunner:
                 elif s.cout == 1 and s.ks == 3 and s.pad == 1 and s.cin % 4 == 0:
                     check(lib.aesr_conv2d_cout1_fwd(ptr(cur), ptr(s.mod.weight), ptr(bias), ptr(out), N, H, W, s.cin, act_k,
                                                     s.slope, stream()), "aesr_conv2d_cout1_fwd")
+                elif (s.wino_fwd and FUSE_EVAL_BN and not train and not save and G == 1 and idx + 1 < len(steps) and steps[idx + 1].kind == "bn"
+                      and steps[idx + 1].run_mode in (_hip.BN_NONE, _hip.BN_POOL) and steps[idx + 1].mod.running_mean is not None
+                      and not (raw_last and s is steps[-1]) and (steps[idx + 1].run_mode == _hip.BN_NONE or (H >= 2 and W >= 2))
+                      and lib.aesr_conv2d_wino_fwd_bn_supported(N, H, W, s.cin, s.cout)):
+                    # eval mode: BatchNorm is a per-channel affine of the running statistics (cached per layer state) -- it and the pooling
+                    # behind it go into this convolution's epilogue; the activation tensor in between is never written
+                    nxt = steps[idx + 1]
+                    st = self._bn_forward_stats(nxt.mod, cur, N, Ho, Wo, s.cout, nstart, False)
+                    Hb, Wb = nxt.out_hw(Ho, Wo)
+                    out = _empty((N, Hb, Wb, s.cout), x)
+                    _pb(("wino", N, Ho, Wo, s.cin, s.cout, 0), 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
+                    check(lib.aesr_conv2d_wino_fwd_bn(ptr(cur), ptr(s.packed_w), ptr(bias), ptr(st["scale"]), ptr(st["shift"]), ptr(out), N, H, W,
+                                                      s.cin, s.cout, act_k, s.slope, int(nxt.run_mode == _hip.BN_POOL), stream()),
+                          "aesr_conv2d_wino_fwd_bn")
+                    _pe()
+                    Ho, Wo, skip = Hb, Wb, True
                 elif s.wino_fwd:
                     _pb(("wino", N, Ho, Wo, s.cin, s.cout, 0), 2.0 * N * Ho * Wo * s.cout * 9 * s.cin)
                     ws, nws = wino_workspace(cur, N, H, W, s.cin, s.cout, 0)
@@ -864,6 +886,8 @@ def run_pass_groups(runner, x_nhwc, splits, nstart=None, ngrad=None, train=True)
     n = x_nhwc.shape[0]
     nstart = tuple(nstart) if nstart is not None else (0, n)
     ngrad = n if ngrad is None else int(ngrad)
+    if not torch.is_grad_enabled():
+        ngrad = 0       # torch.no_grad(): ctx.needs_input_grad still reports the parameters, but no backward pass will come -- keep nothing
     splits = tuple(int(v) for v in splits)
     if sum(splits) != n:
         raise ValueError("splits %s do not add up to the batch size %d" % (splits, n))

@@ -872,6 +872,66 @@ def test_conv_wino_baseline_size_repeatable(hip, case, streamed_kernel):
         assert float((douts[0].double() - dref.permute(0, 2, 3, 1)).norm() / dref.norm()) < 2e-6
 
 
+@pytest.mark.parametrize("case", [(3, 160, 160, 32, 32), (2, 81, 81, 32, 64), (2, 37, 41, 32, 32), (1, 6, 6, 32, 64), (36, 160, 160, 32, 64),
+                                  (30, 112, 112, 64, 64), (30, 56, 56, 128, 128), (30, 57, 55, 64, 128), (30, 28, 28, 128, 256), (30, 112, 112, 64, 32)])
+@pytest.mark.parametrize("pool", [0, 1])
+def test_conv_wino_eval_bn_epilogue(hip, case, pool):
+    """Slice synthesis: convolution + LeakyReLU + eval-mode BatchNorm (+ AvgPool2d(2)) in one launch == the convolution followed by
+    aesr_bn_apply, bit for bit (same per-element arithmetic and order), odd sizes included (the pooled output floors).  The
+    resident-filter kernel (Cin = 32 here) and the ring kernel (the dHCP-size layers above it) carry the epilogue."""
+    N, H, W, Cin, Cout = case
+    L = hip.lib
+    kind = L.aesr_conv2d_wino_kernel(N, H, W, Cin, Cout, 3, 1, 0)
+    if Cin == 32:
+        assert kind == 2 and L.aesr_conv2d_wino_fwd_bn_supported(N, H, W, Cin, Cout)
+    elif not L.aesr_conv2d_wino_fwd_bn_supported(N, H, W, Cin, Cout):
+        assert kind in (1, 3)       # 3: the ring kernel takes it only WITH a channel split, whose partial sums the epilogue cannot see
+        pytest.skip("the planner gives this layer to the first streamed kernel (or a channel split), which has no such epilogue")
+    g = torch.Generator(device="cuda").manual_seed(17 + pool)
+    x = _common_mode((N, H, W, Cin), g, False)
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / np.sqrt(Cin * 9) + 0.02
+    b = torch.randn(Cout, device="cuda", generator=g)
+    sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
+    sh = torch.randn(Cout, device="cuda", generator=g)
+    uf = D(_pack_wino(hip, w, 0))
+    mid = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    hip.check(L.aesr_conv2d_wino_fwd(hip.ptr(x), hip.ptr(uf), hip.ptr(b), hip.ptr(mid), N, H, W, Cin, Cout, 1, 0.01, hip.stream()), "wino_fwd")
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    want = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda")
+    ns = hip.int_array([0, N])
+    hip.check(L.aesr_bn_apply(hip.ptr(mid), hip.ptr(sc), hip.ptr(sh), hip.ptr(want), N, H, W, Cout, hip.BN_POOL if pool else hip.BN_NONE, 1, ns,
+                              hip.stream()), "apply")
+    got = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda")
+    for _ in range(2):
+        got.fill_(float("nan"))
+        hip.check(L.aesr_conv2d_wino_fwd_bn(hip.ptr(x), hip.ptr(uf), hip.ptr(b), hip.ptr(sc), hip.ptr(sh), hip.ptr(got), N, H, W, Cin, Cout, 1, 0.01,
+                                            pool, hip.stream()), "wino_fwd_bn")
+        torch.cuda.synchronize()
+        assert not torch.isnan(got).any()
+        assert torch.equal(got, want)
+    ref = F.leaky_relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1), 0.01)
+    if pool:
+        ref = F.avg_pool2d(ref, 2)
+    ref = (ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).permute(0, 2, 3, 1)
+    assert float((got.double() - ref).norm() / ref.norm()) < 2e-6
+
+
+def test_conv_wino_eval_bn_epilogue_refuses_other_kernels(hip):
+    """The first streamed kernel and a channel-split layer have no such epilogue: the query says so and the call refuses instead of dropping the BatchNorm."""
+    L = hip.lib
+    cases = [c for c in [(2, 40, 40, 128, 128), (1, 81, 81, 64, 64), (3, 81, 81, 64, 64), (6, 40, 40, 128, 128), (1, 20, 20, 256, 256)]
+             if not L.aesr_conv2d_wino_fwd_bn_supported(*c)]
+    if not cases:
+        pytest.skip("every candidate layer goes to a kernel with the epilogue under this planner setting")
+    N, H, W, Cin, Cout = cases[0]
+    assert L.aesr_conv2d_wino_kernel(N, H, W, Cin, Cout, 3, 1, 0) in (1, 3)     # 3: only with a channel split (workspace)
+    x = torch.zeros(N * H * W * max(Cin, Cout), device="cuda")
+    u = torch.zeros(16 * Cin * Cout, device="cuda")
+    rc = L.aesr_conv2d_wino_fwd_bn(hip.ptr(x), hip.ptr(u), None, hip.ptr(x), hip.ptr(x), hip.ptr(x), N, H, W, Cin, Cout, 0, 0.0, 0, hip.stream())
+    assert rc != 0
+    assert not L.aesr_conv2d_wino_fwd_bn_supported(4, 16, 16, 24, 32)        # not a Winograd layer at all
+
+
 @pytest.mark.parametrize("sizes", [(24 * 160 * 160, 12 * 160 * 160, 12 * 128 * 20 * 20), (1003, 517, 0), (5, 3, 2)])
 def test_combined_mse_loss_block(hip, sizes):
     """aesr_mse3_fwd / _bwd (the loss block of the ae_combined step with MSE losses, one launch each) against torch in fp64;
