@@ -114,6 +114,7 @@ SIGNATURES = {
     "aesr_lerp_cat_fwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
     "aesr_lerp_multi": (c_int, [P, P, c_int, c_size_t, FP, c_int, c_int, c_float, P]),
     "aesr_lerp_cat_bwd": (c_int, [P, P, P, P, c_int, c_size_t, P]),
+    "aesr_interleave_clamp": (c_int, [P, P, P, c_int, c_int, c_size_t, c_float, c_float, P]),
     "aesr_mse_fwd": (c_int, [P, P, P, P, c_size_t, P]),
     "aesr_mse_bwd": (c_int, [P, P, P, P, c_size_t, P]),
     "aesr_mse3_fwd": (c_int, [P, P, c_size_t, P, P, c_size_t, P, P, c_size_t, P, P, P, P]),

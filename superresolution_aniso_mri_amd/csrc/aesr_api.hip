@@ -1121,6 +1121,13 @@ int aesr_lerp_multi(const float* z, float* out, int Z, size_t per_slice, const f
     return aesr_launch_lerp_multi(z, out, Z, per_slice, alphas_host, n, nslope, (hipStream_t)stream);
 }
 
+int aesr_interleave_clamp(const float* orig, const float* synth, float* out, int Z, int n, size_t per_slice, float lo, float hi, void* stream) {
+    AESR_CHECK_ARG(orig && out && Z >= 1 && n >= 0 && per_slice > 0 && per_slice % 4 == 0 && (synth || n == 0 || Z == 1) && orig != out && synth != out,
+                   "aesr_interleave_clamp: bad arguments (per_slice %% 4 == 0, out apart from its inputs)");
+    AESR_CHECK_ARG(lo <= hi, "aesr_interleave_clamp: empty range [%g, %g]", (double)lo, (double)hi);
+    return aesr_launch_interleave_clamp(orig, synth, out, Z, Z > 1 ? n : 0, per_slice, lo, hi, (hipStream_t)stream);
+}
+
 int aesr_lerp_cat_bwd(const float* g, const float* a_from, const float* a_to, float* dz, int B, size_t per, void* stream) {
     AESR_CHECK_ARG(g && a_from && a_to && dz && g != dz && B > 0 && per % 4 == 0, "aesr_lerp_cat_bwd: bad arguments (per %% 4 == 0)");
     return aesr_launch_lerp_cat_bwd(g, a_from, a_to, dz, B, per, (hipStream_t)stream);

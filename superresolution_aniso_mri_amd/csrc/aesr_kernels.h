@@ -200,6 +200,7 @@ int aesr_launch_bn_bwd_finalize_apply(const double* sums, const double* counts, 
 int aesr_launch_lerp_fwd(const float* z, const float* af, const float* at, float* zmix, int B, size_t per, hipStream_t st);
 int aesr_launch_lerp_bwd(const float* dmix, const float* af, const float* at, float* dz, int B, size_t per, hipStream_t st);
 int aesr_launch_lerp_cat_fwd(const float* z, const float* af, const float* at, float* zcat, int B, size_t per, hipStream_t st);
+int aesr_launch_interleave_clamp(const float* orig, const float* synth, float* out, int Z, int n, size_t per, float lo, float hi, hipStream_t st);
 int aesr_launch_lerp_multi(const float* z, float* out, int Z, size_t per, const float* alphas, int n, float nslope, hipStream_t st);
 int aesr_launch_lerp_cat_bwd(const float* g, const float* af, const float* at, float* dz, int B, size_t per, hipStream_t st);
 int aesr_launch_mse_fwd(const float* a, const float* b, double* partial, int np, float* out, size_t n, hipStream_t st);

@@ -67,6 +67,22 @@ __global__ __launch_bounds__(256) void lerp_multi_kernel(const float* __restrict
     }
 }
 
+// the super-resolved volume (generate_hr_volumes.py:102-118): slot i * (n + 1) = slice i of `orig`, slot i * (n + 1) + k + 1 = synthesised slice
+// synth[k][i], everything clamped to [lo, hi] -- one pass instead of n + 1 strided copies and a clamp over the result
+__global__ __launch_bounds__(256) void interleave_clamp_kernel(const float* __restrict__ orig, const float* __restrict__ synth, float* __restrict__ out,
+                                                               int Z, int n, size_t per4, float lo, float hi) {
+    const size_t total = ((size_t)(Z - 1) * (n + 1) + 1) * per4;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t slot = idx / per4, e = idx - slot * per4;
+        const size_t i = slot / (n + 1);
+        const int k = (int)(slot - i * (n + 1));
+        f32x4 v = k == 0 ? ((const f32x4*)orig)[i * per4 + e] : ((const f32x4*)synth)[((size_t)(k - 1) * (Z - 1) + i) * per4 + e];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = fminf(fmaxf(v[c], lo), hi);
+        ((f32x4*)out)[idx] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void lerp_cat_bwd_kernel(const float* __restrict__ g, const float* __restrict__ af,
                                                            const float* __restrict__ at, float* __restrict__ dz, int B, size_t per4) {
     const size_t total = (size_t)B * per4;
@@ -314,6 +330,13 @@ int aesr_launch_lerp_multi(const float* z, float* out, int Z, size_t per, const 
     for (int k = 0; k < 16; ++k) al.a[k] = k < n ? alphas[k] : 0.f;
     hipLaunchKernelGGL(lerp_multi_kernel, dim3(grid_for((size_t)(Z - 1) * per / 4, 4096)), dim3(256), 0, st, z, out, Z - 1, per / 4, al, nslope);
     AESR_LAUNCH_CHECK("lerp_multi");
+    return AESR_OK;
+}
+
+int aesr_launch_interleave_clamp(const float* orig, const float* synth, float* out, int Z, int n, size_t per, float lo, float hi, hipStream_t st) {
+    const size_t total4 = ((size_t)(Z - 1) * (n + 1) + 1) * (per / 4);
+    hipLaunchKernelGGL(interleave_clamp_kernel, dim3(grid_for(total4, 4096)), dim3(256), 0, st, orig, synth, out, Z, n, per / 4, lo, hi);
+    AESR_LAUNCH_CHECK("interleave_clamp");
     return AESR_OK;
 }
 

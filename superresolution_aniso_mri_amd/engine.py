@@ -482,6 +482,28 @@ class SequentialRunner:
                 cur, H, W = out, Ho, Wo
         return cur, saved, steps
 
+    def max_elems_per_image(self, H, W, C, first=0, last=None):
+        """Largest activation tensor (elements per image) a pass over ``steps[first:last]`` touches for an H x W x C input: what decides
+        how many images fit one pass under the kernels' 32-bit offsets (aesr_launch_conv_wino refuses tensors of 469 M elements)."""
+        best = H * W * C
+        for s in self.steps[first:last]:
+            if s.kind == "conv":
+                if s.s2d:
+                    H, W = H // 2, W // 2
+                elif s.in_up2:
+                    H, W = 2 * H, 2 * W
+                    H, W = s.out_hw(H, W)
+                else:
+                    H, W = s.out_hw(H, W)
+                C = s.cout
+            elif s.kind == "stemconv":
+                H, W = s.out_hw(H, W)
+                C = s.cout
+            else:
+                H, W = s.out_hw(H, W)
+            best = max(best, H * W * C)
+        return best
+
     def _bn_barrier(self, dev):
         """Grid-barrier state of this runner's one-launch BatchNorm kernels (csrc/bn_fused.hip): zeroed once, then owned by the kernels.
         Created by an eager step (a tensor born inside a graph capture would live in the graph's pool and be zeroed by every replay)."""

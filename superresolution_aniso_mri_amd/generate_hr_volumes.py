@@ -47,8 +47,7 @@ def create_super_volume(trainer, images, alpha_range, use_original=False, labels
     with torch.no_grad():
         lat = _encode(trainer, vol)                                   # every slice encoded exactly once
         recon = vol if use_original else trainer.decode(lat, use_sr_model=True)
-        out = torch.empty(((Z - 1) * (n + 1) + 1, H, W), device=vol.device, dtype=torch.float32)
-        out[::n + 1] = recon[:, 0]
+        dec = None
         if Z > 1 and n > 0:
             model = trainer._use_sr_model(True)
             model.eval()
@@ -57,10 +56,16 @@ def create_super_volume(trainer, images, alpha_range, use_original=False, labels
                 zpair = torch.cat([lat[1:], lat[:-1]], dim=0)         # rows i / i+(Z-1): later slice / earlier slice
                 mixes = torch.cat([ops.lerp_mix(zpair, float(a), float(1 - a)) for a in alpha_range], dim=0)
                 dec = trainer.decode(mixes, use_sr_model=True)        # ONE decoder pass over all (Z-1)*n latents
-            dec = dec.reshape(n, Z - 1, H, W)
-            for k in range(n):
-                out[k + 1::n + 1] = dec[k]
-        out.clamp_(0, 1.)
+        if vol.is_cuda and (H * W) % 4 == 0:
+            out = ops.interleave_clamp(recon[:, 0], dec, n, 0.0, 1.0)        # interleave + clamp: one pass over the volume
+        else:
+            out = torch.empty(((Z - 1) * (n + 1) + 1, H, W), device=vol.device, dtype=torch.float32)
+            out[::n + 1] = recon[:, 0]
+            if dec is not None:
+                dec = dec.reshape(n, Z - 1, H, W)
+                for k in range(n):
+                    out[k + 1::n + 1] = dec[k]
+            out.clamp_(0, 1.)
     if to_cpu:
         out = out.cpu()
         if vol.is_cuda:

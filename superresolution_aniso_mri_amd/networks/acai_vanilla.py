@@ -198,12 +198,10 @@ class HipAE(nn.Module):
         with torch.no_grad():
             pre, _, _ = r.forward(zn, (0, N), False, save=False, first=0, last=1, raw_last=True)
             mixed = ops.lerp_multi(pre, alphas, s0.act, s0.slope)
-            # big volumes in pieces: no activation tensor of a pass may exceed the kernels' 32-bit offset range (as BaseTrainer._run_eval)
-            up = 1
-            for st in r.steps[1:]:
-                if st.kind == "bn" and st.mode == _hip.BN_UP or (st.kind == "resample" and st.mode != _hip.RS_POOL):
-                    up *= 2
-            n_max = max(1, (1 << 28) // (mixed.shape[1] * up * mixed.shape[2] * up * 64))
+            # big volumes in pieces: no activation tensor of a pass may exceed the kernels' 32-bit offset range -- 2^28 elements (1 GB) per
+            # tensor, against the largest one the rest of the decoder really makes (a dHCP volume of 30 slices x 3 mixes goes in ONE pass;
+            # the 64-channels-at-full-size guess of BaseTrainer._run_eval cut it into 83 + 4 images: seven launches for the 4)
+            n_max = max(1, (1 << 28) // r.max_elems_per_image(mixed.shape[1], mixed.shape[2], mixed.shape[3], first=1))
             outs = [r.forward(mixed[i:i + n_max], (0, min(n_max, mixed.shape[0] - i)), False, save=False, first=1)[0]
                     for i in range(0, mixed.shape[0], n_max)]
             out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)

@@ -124,6 +124,24 @@ def lerp_multi(z_nhwc, alphas, act=_hip.ACT_NONE, slope=0.0):
     return out
 
 
+def interleave_clamp(orig, synth, n, lo=0.0, hi=1.0):
+    """The super-resolved volume in one pass: orig [Z, H, W], synth [n * (Z - 1), H, W] (row k * (Z - 1) + i, as ``lerp_multi`` orders them)
+    -> [(Z - 1)(n + 1) + 1, H, W] with slice i at slot i (n + 1) and its n synthesised successors behind it, clamped to [lo, hi]."""
+    _hip.require_gpu_tensor(orig, "orig")
+    Z, per = orig.shape[0], orig[0].numel()
+    orig = orig.contiguous()
+    if Z > 1 and n > 0:
+        _hip.require_gpu_tensor(synth, "synth")
+        synth = synth.contiguous()
+        if synth.numel() != n * (Z - 1) * per:
+            raise ValueError("synth holds %d elements, %d x %d slices of %d expected" % (synth.numel(), n, Z - 1, per))
+    else:
+        synth, n = None, 0
+    out = torch.empty(((Z - 1) * (n + 1) + 1,) + tuple(orig.shape[1:]), device=orig.device, dtype=torch.float32)
+    check(lib.aesr_interleave_clamp(ptr(orig), ptr(synth), ptr(out), Z, n, per, float(lo), float(hi), stream()), "aesr_interleave_clamp")
+    return out
+
+
 def lerp_cat(z, alpha_from, alpha_to):
     """[z | lerp_mix(z)] as ONE [3B,...] tensor written by one kernel: the decoder input of the ae_combined step (its rows 2B.. are
     z_mix).  Saves the separate concatenation pass and, in backward, the accumulation of the two gradient paths into z."""

@@ -60,6 +60,34 @@ def test_super_volume_properties_at_dhcp_size():
     np.testing.assert_allclose(lim[2::3][:Z - 1].numpy(), rec[0:-1:n + 1].numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_super_volume_in_pieces_equals_one_pass(monkeypatch):
+    """A volume too big for one decoder pass is decoded in pieces (eval-mode BatchNorm: results do not depend on the batch): same
+    volume as the single pass up to the rounding of the kernels the planner picks per batch size; and the bound that decides the
+    pieces is the largest tensor the rest of the decoder really makes (one pass for a dHCP volume of 30 slices x 3 mixes)."""
+    from superresolution_aniso_mri_amd import engine
+    from superresolution_aniso_mri_amd.generate_hr_volumes import create_super_volume
+    torch.manual_seed(5)
+    tr = _trainer(dict(width=64, latent_width=16, depth=32, latent=128))
+    vol = torch.rand(7, 1, 64, 64)
+    alphas = np.linspace(0, 1, 5)[1:-1]
+    r = tr.model._runner("dec")
+    assert r.max_elems_per_image(56, 56, 64, first=1) == 224 * 224 * 32          # dHCP decoder behind its first convolution
+    assert (1 << 28) // (224 * 224 * 32) >= 29 * 3
+    one = create_super_volume(tr, vol, alphas, use_original=False)["upsampled_image"]
+    calls = []
+    real = engine.SequentialRunner.forward
+
+    def counting(self, x, *a, **kw):
+        calls.append(int(x.shape[0]))
+        return real(self, x, *a, **kw)
+
+    monkeypatch.setattr(engine.SequentialRunner, "forward", counting)
+    monkeypatch.setattr(engine.SequentialRunner, "max_elems_per_image", lambda self, H, W, C, first=0, last=None: (1 << 28) // 5)
+    pieces = create_super_volume(tr, vol, alphas, use_original=False)["upsampled_image"]
+    assert [n for n in calls if n == 5] and 18 not in calls                      # 18 mixes went through in pieces of 5
+    np.testing.assert_allclose(pieces.numpy(), one.numpy(), rtol=1e-5, atol=2e-6)
+
+
 def test_fused_lerp_decode_at_eval_patch_size(monkeypatch):
     """BASELINE configs[4] inference leg: a dHCP-shaped volume cropped to the 224 x 224 evaluation patch (README.md:97), 3 interpolations.
     The fused path (decoder's first convolution once per slice, all mixes formed on its pre-activations by aesr_lerp_multi, the rest of

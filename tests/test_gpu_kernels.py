@@ -916,6 +916,27 @@ def test_conv_wino_eval_bn_epilogue(hip, case, pool):
     assert float((got.double() - ref).norm() / ref.norm()) < 2e-6
 
 
+@pytest.mark.parametrize("case", [(30, 3, 224, 224), (2, 1, 6, 6), (1, 4, 8, 8), (5, 0, 4, 4), (7, 16, 10, 6)])
+def test_interleave_clamp(hip, case):
+    """The super-resolved volume in one pass == n + 1 strided copies and a clamp (generate_hr_volumes.py:102-118), bit for bit."""
+    from superresolution_aniso_mri_amd import ops
+    Z, n, H, W = case
+    g = torch.Generator(device="cuda").manual_seed(Z * 100 + n)
+    orig = torch.rand(Z, H, W, device="cuda", generator=g) * 1.4 - 0.2
+    synth = torch.rand(max(n * (Z - 1), 1), H, W, device="cuda", generator=g) * 1.4 - 0.2
+    got = ops.interleave_clamp(orig, synth if n and Z > 1 else None, n)
+    nn_ = n if Z > 1 else 0
+    want = torch.full(((Z - 1) * (nn_ + 1) + 1, H, W), float("nan"), device="cuda")
+    want[::nn_ + 1] = orig
+    for k in range(nn_):
+        want[k + 1::nn_ + 1] = synth.reshape(n, Z - 1, H, W)[k]
+    want.clamp_(0, 1)
+    assert got.shape == want.shape and torch.equal(got, want)
+    with pytest.raises(ValueError):
+        ops.interleave_clamp(torch.rand(3, 4, 4, device="cuda"), torch.rand(5, 4, 4, device="cuda"), 2)
+    assert hip.lib.aesr_interleave_clamp(hip.ptr(orig), hip.ptr(synth), hip.ptr(orig), Z, n, H * W, 0.0, 1.0, hip.stream()) != 0     # in place: refused
+
+
 def test_conv_wino_eval_bn_epilogue_refuses_other_kernels(hip):
     """The first streamed kernel and a channel-split layer have no such epilogue: the query says so and the call refuses instead of dropping the BatchNorm."""
     L = hip.lib
