@@ -247,7 +247,7 @@ int aesr_lerp_cat_fwd(const float* z, const float* a_from, const float* a_to, fl
 int aesr_lerp_multi(const float* z, float* out, int Z, size_t per_slice, const float* alphas_host, int n, int act, float slope,
                     void* stream);
 int aesr_lerp_cat_bwd(const float* g, const float* a_from, const float* a_to, float* dz, int B, size_t per, void* stream);
-/* generate_hr_volumes.py:102-118 (the volume is assembled slice by slice on the host there): out[(Z-1)(n+1)+1][per_slice], slot i (n+1) = orig[i],
+/* generate_hr_volumes.py:57-67 (the volume is assembled slice by slice on the host there): out[(Z-1)(n+1)+1][per_slice], slot i (n+1) = orig[i],
  * slot i (n+1) + k + 1 = synth[k][i] (synth: [n][Z-1][per_slice], the order aesr_lerp_multi mixes in), every element clamped to [lo, hi]. */
 int aesr_interleave_clamp(const float* orig, const float* synth, float* out, int Z, int n, size_t per_slice, float lo, float hi, void* stream);
 

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void lerp_multi_kernel(const float* __restrict
     }
 }
 
-// the super-resolved volume (generate_hr_volumes.py:102-118): slot i * (n + 1) = slice i of `orig`, slot i * (n + 1) + k + 1 = synthesised slice
+// the super-resolved volume (generate_hr_volumes.py:57-67): slot i * (n + 1) = slice i of `orig`, slot i * (n + 1) + k + 1 = synthesised slice
 // synth[k][i], everything clamped to [lo, hi] -- one pass instead of n + 1 strided copies and a clamp over the result
 __global__ __launch_bounds__(256) void interleave_clamp_kernel(const float* __restrict__ orig, const float* __restrict__ synth, float* __restrict__ out,
                                                                int Z, int n, size_t per4, float lo, float hi) {

@@ -918,7 +918,7 @@ def test_conv_wino_eval_bn_epilogue(hip, case, pool):
 
 @pytest.mark.parametrize("case", [(30, 3, 224, 224), (2, 1, 6, 6), (1, 4, 8, 8), (5, 0, 4, 4), (7, 16, 10, 6)])
 def test_interleave_clamp(hip, case):
-    """The super-resolved volume in one pass == n + 1 strided copies and a clamp (generate_hr_volumes.py:102-118), bit for bit."""
+    """The super-resolved volume in one pass == n + 1 strided copies and a clamp (generate_hr_volumes.py:57-67), bit for bit."""
     from superresolution_aniso_mri_amd import ops
     Z, n, H, W = case
     g = torch.Generator(device="cuda").manual_seed(Z * 100 + n)
