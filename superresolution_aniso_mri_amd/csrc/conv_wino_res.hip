@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <vector>
 
 #include "aesr_kernels.h"
 
@@ -49,13 +50,23 @@ __device__ __forceinline__ void wr_st(__amdgpu_buffer_rsrc_t rs, int byte_off, f
 
 // POST: eval-mode BatchNorm (a per-channel affine behind the activation) and the AvgPool2d(2) that follows it, in the epilogue -- a lane
 // holds one 2 x 2 output tile, which IS one pooling window; an instantiation of its own, so that the training kernels' code is untouched
-template <int WR_TN, bool MASK, bool POST = false>
+// STAMP (debug, AESR_WINO_RES_DBG=1): wall-clock stamps (s_memrealtime, 10 ns) of the phases of every wave's FIRST item -> a.dbgbuf as
+// [workgroup][wave][16] 64-bit ticks: 0 entry, 1 DMAs of the prologue issued, 2 behind the prologue barrier, 3 + 2 c patch of chunk c landed,
+// 4 + 2 c MFMAs of chunk c issued (c < 4), 11 stores of the item issued, 12 exit, 13 items of the wave
+template <int WR_TN, bool MASK, bool POST = false, bool STAMP = false>
 __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
     constexpr int WR_NB = WR_TN / 16;
     constexpr int WR_WFL = 16 * 4 * WR_TN * 4;      // floats of one U chunk (16 positions x 16 ci x TN co)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long stamp[14] = {};
+    int stamped_items = 0;
+#define WR_STAMP(k)                                                          \
+    if constexpr (STAMP) {                                                   \
+        if (stamped_items == 0) stamp[k] = __builtin_amdgcn_s_memrealtime(); \
+    }
+    WR_STAMP(0)
     const int l15 = lane & 15, g = lane >> 4;
     const int ncot = a.CoutP / WR_TN, nchunks = a.CinP >> 4;
     // Workgroup -> (cout tile, spatial worker).  Workgroups b and b + 8 share an XCD (round-robin placement: speed only, never
@@ -85,7 +96,10 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
     const __amdgpu_buffer_rsrc_t rs_ys = __builtin_amdgcn_make_buffer_rsrc((void*)(MASK ? a.ysave : a.out), 0, ybytes, 0x00020000);
 
     // ---- prologue: the workgroup's U block(s) and bias, once ----
-    if (tid < WR_TN) ldsBias[tid] = (a.bias && co0 + tid < a.Cout) ? a.bias[co0 + tid] : 0.f;
+    // (the bias is only REQUESTED here: parked in LDS behind the DMA issue below -- written first, its global round trip (~1 us on a cold
+    // line) stood in front of every DMA of the launch: stamps of profiles/r04_small_shard_budget.txt, section 11)
+    float bias_v = 0.f;
+    if (tid < WR_TN && a.bias && co0 + tid < a.Cout) bias_v = a.bias[co0 + tid];
     // packed layout [chunk][32-cout tile][position][ci / 4][32 couts][4]: a 16-cout workgroup takes one half of every 32-cout row
     for (int cc = 0; cc < nchunks; ++cc) {
         const int wbase = (int)(((size_t)cc * (a.CoutP / 32) + (co0 >> 5)) * (8192 * 4)) + ((co0 >> 4) & 1) * (WR_TN == 16 ? 256 : 0);
@@ -139,8 +153,11 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
         locate(item);
         fetch(item, 0);
     }
+    WR_STAMP(1)
+    if (tid < WR_TN) ldsBias[tid] = bias_v;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // explicit: this wave's share of the filter DMAs has landed before it arrives
     __syncthreads();            // U and bias are in LDS (every wave waited for its own part); the only barrier of the kernel
+    WR_STAMP(2)
 
     f32x4 acc[16][WR_NB];
     int cc = 0;
@@ -150,6 +167,9 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
         // the DMAs of this patch are the oldest outstanding memory operations; the previous item's stores may still be in flight
         if (after_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * WR_NB) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (STAMP) {
+            if (stamped_items == 0 && cc < 4) stamp[3 + 2 * cc] = __builtin_amdgcn_s_memrealtime();
+        }
         f32x4 t[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -218,6 +238,9 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
         if (cc == 0) positions(std::true_type{});
         else positions(std::false_type{});
 #undef WR_V
+        if constexpr (STAMP) {
+            if (stamped_items == 0 && cc < 4) stamp[4 + 2 * cc] = __builtin_amdgcn_s_memrealtime();
+        }
         after_stores = false;
         if (!last) {
             ++cc;
@@ -301,8 +324,20 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
             }
         }
         after_stores = !MASK && !halfout;           // exactly 4 NB stores follow the next patch's DMAs
+        WR_STAMP(11)
+        if constexpr (STAMP) ++stamped_items;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no DMA may still be writing this workgroup's LDS when it is released
+    if constexpr (STAMP) {
+        stamp[12] = __builtin_amdgcn_s_memrealtime();
+        stamp[13] = (unsigned long long)stamped_items;
+        if (lane == 0) {
+            unsigned long long* dst = (unsigned long long*)a.dbgbuf + ((size_t)blockIdx.x * 8 + wave) * 16;
+#pragma unroll
+            for (int k = 0; k < 14; ++k) dst[k] = stamp[k];
+        }
+    }
+#undef WR_STAMP
 #undef WR_DIV
 }
 
@@ -330,6 +365,61 @@ bool aesr_wino_res_ok(const WinoArgs& a) {
     return level >= 2 && a.CinP <= 64 && waste <= 1.10;
 }
 
+// debug launch (AESR_WINO_RES_DBG=1, forward without mask): the stamped instantiation, then a host sync and ONE line on stderr -- where the
+// time of a launch goes for the waves that had work (profiles/r04_small_shard_budget.txt, section 11)
+template <int WR_TN>
+static int wino_res_stamped(const WinoArgs& b_in, int grid, size_t shmem, hipStream_t st) {
+    static unsigned long long* dbuf = nullptr;
+    static std::vector<unsigned long long> host;
+    const size_t n = (size_t)grid * 8 * 16;
+    if (grid > 1024) return AESR_ERR_ARG;
+    if (!dbuf && hipMalloc(&dbuf, (size_t)1024 * 8 * 16 * sizeof(unsigned long long)) != hipSuccess) return AESR_ERR_HIP;
+    (void)hipFuncSetAttribute((const void*)conv_wino_res_f32<WR_TN, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    WinoArgs b = b_in;
+    b.dbgbuf = (float*)dbuf;
+    (void)hipMemsetAsync(dbuf, 0, n * sizeof(unsigned long long), st);
+    hipLaunchKernelGGL((conv_wino_res_f32<WR_TN, false, false, true>), dim3(grid), dim3(WR_NT), shmem, st, b);
+    AESR_LAUNCH_CHECK("conv_wino_res_f32 (stamped)");
+    (void)hipStreamSynchronize(st);
+    host.resize(n);
+    (void)hipMemcpy(host.data(), dbuf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    unsigned long long t_first = ~0ull, t_last = 0;
+    for (size_t w = 0; w < (size_t)grid * 8; ++w) {
+        const unsigned long long* s_ = &host[w * 16];
+        if (s_[0] && s_[0] < t_first) t_first = s_[0];
+        if (s_[12] > t_last) t_last = s_[12];
+    }
+    const int nch = b.CinP / 16 < 4 ? b.CinP / 16 : 4;
+    double sum[16] = {}, ramp_max = 0;
+    int busy = 0, items = 0;
+    for (size_t w = 0; w < (size_t)grid * 8; ++w) {
+        const unsigned long long* s_ = &host[w * 16];
+        if (!s_[13]) continue;
+        ++busy;
+        items += (int)s_[13];
+        const double ramp = (double)(s_[0] - t_first);
+        if (ramp > ramp_max) ramp_max = ramp;
+        sum[0] += ramp;                                     // entry behind the first wave of the grid
+        sum[1] += (double)(s_[1] - s_[0]);                  // address work + issue of the filter and first-patch DMAs
+        sum[2] += (double)(s_[2] - s_[1]);                  // wait for them + the barrier
+        unsigned long long prev = s_[2];
+        for (int c = 0; c < nch; ++c) {
+            sum[3 + 2 * c] += (double)(s_[3 + 2 * c] - prev);               // wait for the patch of chunk c
+            sum[4 + 2 * c] += (double)(s_[4 + 2 * c] - s_[3 + 2 * c]);      // LDS reads, next DMAs, transform, MFMAs of chunk c
+            prev = s_[4 + 2 * c];
+        }
+        sum[11] += (double)(s_[11] - prev);                 // output transform, activation, stores issued
+        sum[12] += (double)(s_[12] - s_[11]);               // further items of the wave + drain of the stores
+    }
+    const double q = busy ? 0.01 / busy : 0.0;              // ticks of 10 ns -> us per busy wave
+    fprintf(stderr, "[wino-res stamps] %d->%d N=%d %dx%d TN=%d grid=%d: %d of %d waves busy, %d items | span %.2f us | per busy wave (first item), us: "
+            "entry behind first wave %.2f (max %.2f) | DMA issue %.2f | prologue wait+barrier %.2f |", b.Cin, b.Cout, b.N, b.H, b.W, WR_TN, grid, busy,
+            grid * 8, items, (double)(t_last - t_first) * 0.01, sum[0] * q, ramp_max * 0.01, sum[1] * q, sum[2] * q);
+    for (int c = 0; c < nch; ++c) fprintf(stderr, " chunk %d: wait %.2f work %.2f |", c, sum[3 + 2 * c] * q, sum[4 + 2 * c] * q);
+    fprintf(stderr, " epilogue %.2f | rest of the wave %.2f\n", sum[11] * q, sum[12] * q);
+    return AESR_OK;
+}
+
 template <int WR_TN, bool MASK, bool POST = false>
 static int wino_res_launch_one(const WinoArgs& a, hipStream_t st) {
     const size_t shmem = wino_res_lds_bytes(a.CinP, WR_TN);
@@ -347,12 +437,21 @@ static int wino_res_launch_one(const WinoArgs& a, hipStream_t st) {
     const int ncot = a.CoutP / WR_TN;
     int grid = 256 / ncot * ncot;                          // one workgroup per CU, a whole number of them per cout tile
     if (const char* e = getenv("AESR_WINO_GRID")) grid = atoi(e) / ncot * ncot;
-    const int per_cot = ceil_div(a.nblk, 8);               // more workgroups than 8-wave rounds of blocks would idle
+    // Few blocks (a small data-parallel shard, the deep layers): at most FOUR per workgroup.  Waves 0..3 of a workgroup sit on the four
+    // SIMDs of its CU (wave i -> SIMD i % 4: measured, scripts/r04_stamps.py), so four one-item waves each have a matrix pipe to themselves;
+    // the round-2 rule packed eight per workgroup and two one-item waves shared every SIMD (2.2 -> 1.5 us per 16-channel chunk at 6 images).
+    static const int wpw = getenv("AESR_WINO_RES_WPW") ? atoi(getenv("AESR_WINO_RES_WPW")) : 4;
+    const int per_cot = ceil_div(a.nblk, wpw >= 1 && wpw <= 8 ? wpw : 4);
     if (grid / ncot > per_cot) grid = per_cot * ncot;
     if (grid < ncot) grid = ncot;
     WinoArgs b = a;
     static const int xmap_on = getenv("AESR_WINO_XCD") ? atoi(getenv("AESR_WINO_XCD")) : 1;
-    b.xcd_map = (xmap_on && grid % (8 * ncot) == 0) ? 1 : 0;
+    // (the XCD map hands every XCD a contiguous run of 8 x its workers blocks per round: with fewer blocks than waves it would fill the first
+    // XCDs' workgroups with eight blocks each and leave the others idle)
+    b.xcd_map = (xmap_on && grid % (8 * ncot) == 0 && a.nblk >= 8 * (grid / ncot)) ? 1 : 0;
+    if constexpr (!MASK && !POST) {
+        if (getenv("AESR_WINO_RES_DBG")) return wino_res_stamped<WR_TN>(b, grid, shmem, st);
+    }
     hipLaunchKernelGGL((conv_wino_res_f32<WR_TN, MASK, POST>), dim3(grid), dim3(WR_NT), shmem, st, b);
     AESR_LAUNCH_CHECK("conv_wino_res_f32");
     return AESR_OK;
