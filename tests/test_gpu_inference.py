@@ -88,6 +88,37 @@ def test_super_volume_in_pieces_equals_one_pass(monkeypatch):
     np.testing.assert_allclose(pieces.numpy(), one.numpy(), rtol=1e-5, atol=2e-6)
 
 
+def test_no_grad_passes_keep_nothing_and_use_the_eval_epilogue(monkeypatch):
+    """Under torch.no_grad() a pass keeps no activation for a backward pass that will not come (ctx.needs_input_grad reports the
+    parameters regardless), and -- eval mode -- the BatchNorm behind a Winograd layer runs in that layer's epilogue: no aesr_bn_apply call,
+    the same output as with the epilogue switched off (bit for bit: same arithmetic, same order)."""
+    from superresolution_aniso_mri_amd import _hip, engine
+    torch.manual_seed(11)
+    tr = _trainer(dict(width=64, latent_width=16, depth=32, latent=128))
+    tr.model.eval()
+    x = torch.rand(5, 1, 64, 64, device="cuda")
+    seen = []
+    real = engine.SequentialRunner.forward
+
+    def spy(self, xx, nstart, train, save, *a, **kw):
+        seen.append(bool(save))
+        return real(self, xx, nstart, train, save, *a, **kw)
+
+    monkeypatch.setattr(engine.SequentialRunner, "forward", spy)
+    with torch.no_grad():
+        lat = tr.model.encode(x)
+        fused = tr.model.decode(lat)
+    assert seen and not any(seen)
+    seen.clear()
+    lat_g = tr.model.encode(x)                      # grad mode: the parameters need gradients, the pass keeps its activations
+    assert seen == [True] and lat_g.requires_grad
+    monkeypatch.setattr(engine, "FUSE_EVAL_BN", False)
+    with torch.no_grad():
+        plain = tr.model.decode(tr.model.encode(x))
+    assert torch.equal(fused, plain)
+    assert torch.equal(lat, lat_g.detach())
+
+
 def test_fused_lerp_decode_at_eval_patch_size(monkeypatch):
     """BASELINE configs[4] inference leg: a dHCP-shaped volume cropped to the 224 x 224 evaluation patch (README.md:97), 3 interpolations.
     The fused path (decoder's first convolution once per slice, all mixes formed on its pre-activations by aesr_lerp_multi, the rest of

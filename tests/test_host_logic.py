@@ -239,3 +239,28 @@ def test_evaluation_crop_and_masks_vs_reference_transforms():
     assert r_mask.tolist() == [True, False, False, True, False, False, True] and (r_mask ^ s_mask).all()
     top = store_top_scores("3", {}, [0.5, 0.7], [20.0, 30.0], [float("nan")] * 2)
     assert top["3"][0] == pytest.approx(0.6) and top["3"][1] == 25.0 and np.isnan(top["3"][2])
+
+
+def test_largest_activation_of_a_pass_and_planner_queries():
+    """Host logic of the inference path: the bound that decides how many images one decoder pass takes is the largest tensor the compiled
+    steps really make (folded upsampling, pooling, stem), and the eval-mode epilogue query follows the planner without touching a device."""
+    from superresolution_aniso_mri_amd import _hip, engine
+    from superresolution_aniso_mri_amd.networks import acai_vanilla as av
+    dec = engine.SequentialRunner(av.Decoder(2, 32, 128, 1, use_batchnorm=True))
+    assert [s.kind for s in dec.steps] == ["conv", "conv", "bn", "conv", "conv", "bn", "conv", "conv"]
+    assert dec.max_elems_per_image(56, 56, 128) == 224 * 224 * 32                  # the 32-channel tensors at full resolution
+    assert dec.max_elems_per_image(56, 56, 64, first=1) == 224 * 224 * 32         # ... also behind the decoder's first convolution
+    assert dec.max_elems_per_image(56, 56, 128, last=2) == 56 * 56 * 128           # the input itself where nothing bigger follows
+    enc = engine.SequentialRunner(av.Encoder(2, 32, 128, 1, use_batchnorm=True))
+    assert enc.max_elems_per_image(224, 224, 1) == 226 * 226 * 32                  # the 1x1 / padding-1 stem grows the image by 2
+    assert (1 << 28) // dec.max_elems_per_image(56, 56, 64, first=1) >= 29 * 3     # a dHCP volume (30 slices, 3 mixes per pair): one pass
+    L = _hip.lib
+    assert L.aesr_conv2d_wino_fwd_bn_supported(30, 226, 226, 32, 32) == 1          # resident-filter layer
+    assert L.aesr_conv2d_wino_fwd_bn_supported(4, 16, 16, 24, 32) == 0             # not a Winograd layer
+    assert L.aesr_conv2d_wino_fwd_bn_supported(0, 16, 16, 32, 32) == 0
+    for shape in [(30, 113, 113, 64, 64), (2, 40, 40, 128, 128), (1, 20, 20, 256, 256)]:
+        kind = L.aesr_conv2d_wino_kernel(*shape, 3, 1, 0)
+        if L.aesr_conv2d_wino_fwd_bn_supported(*shape):
+            assert kind in (2, 3)
+        else:
+            assert kind in (1, 3)        # the first streamed kernel, or the ring kernel only WITH a channel split
