@@ -485,6 +485,10 @@ class SequentialRunner:
     def max_elems_per_image(self, H, W, C, first=0, last=None):
         """Largest activation tensor (elements per image) a pass over ``steps[first:last]`` touches for an H x W x C input: what decides
         how many images fit one pass under the kernels' 32-bit offsets (aesr_launch_conv_wino refuses tensors of 469 M elements)."""
+        return self.trace_shapes(H, W, C, first, last)[0]
+
+    def trace_shapes(self, H, W, C, first=0, last=None):
+        """(largest activation tensor in elements per image, (H, W, C) of the output) of a pass over ``steps[first:last]``."""
         best = H * W * C
         for s in self.steps[first:last]:
             if s.kind == "conv":
@@ -502,7 +506,7 @@ class SequentialRunner:
             else:
                 H, W = s.out_hw(H, W)
             best = max(best, H * W * C)
-        return best
+        return best, (H, W, C)
 
     def _bn_barrier(self, dev):
         """Grid-barrier state of this runner's one-launch BatchNorm kernels (csrc/bn_fused.hip): zeroed once, then owned by the kernels.

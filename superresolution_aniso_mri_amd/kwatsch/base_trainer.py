@@ -233,13 +233,18 @@ class BaseTrainer(object):
     def _to_device(self, t):
         return t.to(self.args["device"]).float()
 
-    def _run_eval(self, model, fn, x, eval, upscale=1):
+    def _run_eval(self, model, fn, x, eval, upscale=1, what=None):
         model.train(not eval)
         if eval:
             # eval-mode BatchNorm makes results independent of the batch composition: big batches are cut so that no
-            # activation tensor of a pass exceeds the kernels' 32-bit offset range (reference: chunk_size=16 host loop)
-            full = x.shape[-2] * upscale * x.shape[-1] * upscale
-            n_max = max(1, (1 << 28) // (full * 64))
+            # activation tensor of a pass exceeds the kernels' 32-bit offset range (reference: chunk_size=16 host loop) -- 2^28
+            # elements per tensor, against the largest one the compiled stacks really make where the network can say it
+            # (HipAE.max_elems_per_image), else against 64 channels at the full output size
+            probe = getattr(model, "max_elems_per_image", None)
+            per = probe(what, tuple(x.shape[1:])) if (probe is not None and what is not None and x.dim() == 4) else None
+            if not per:
+                per = x.shape[-2] * upscale * x.shape[-1] * upscale * 64
+            n_max = max(1, (1 << 28) // int(per))
             with torch.no_grad():
                 if x.shape[0] <= n_max:
                     return fn(x)
@@ -247,11 +252,11 @@ class BaseTrainer(object):
         return fn(x)
 
     def predict(self, x, eval=True, chunk_size=16, clear_cache=False, **kwargs):
-        return self._run_eval(self.model, self.model, self._to_device(x), eval)
+        return self._run_eval(self.model, self.model, self._to_device(x), eval, what="forward")
 
     def encode(self, x, eval=True, clear_cache=False, chunk_size=16, **kwargs):
         model = self._use_sr_model(kwargs.get("use_sr_model", False))
-        return self._run_eval(model, model.encode, self._to_device(x), eval)
+        return self._run_eval(model, model.encode, self._to_device(x), eval, what="encode")
 
     def decode(self, z, eval=True, clear_cache=False, chunk_size=16, **kwargs):
         model = self._use_sr_model(kwargs.get("use_sr_model", False))
@@ -259,7 +264,7 @@ class BaseTrainer(object):
         if scales is None:
             from ..networks.acai_vanilla import num_scales
             scales = num_scales(self.args)
-        return self._run_eval(model, model.decode, self._to_device(z), eval, upscale=1 << int(scales))
+        return self._run_eval(model, model.decode, self._to_device(z), eval, upscale=1 << int(scales), what="decode")
 
     # ---- validation (reference :67-99) -----------------------------------------------------------------------------
     def _bounded_sync(self):

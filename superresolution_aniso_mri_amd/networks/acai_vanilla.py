@@ -207,6 +207,21 @@ class HipAE(nn.Module):
             out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
         return engine.to_nchw_view(out)
 
+    def max_elems_per_image(self, what, chw):
+        """Largest activation tensor (elements per image) of ``encode`` / ``decode`` / ``forward`` for one C x H x W input image, or None
+        when this network is not an ``enc`` / ``dec`` pair of compiled stacks (BaseTrainer._run_eval then keeps its conservative guess)."""
+        if not (hasattr(self, "enc") and hasattr(self, "dec")):
+            return None
+        C, H, W = (int(v) for v in chw)
+        if what == "encode":
+            return self._runner("enc").trace_shapes(H, W, C)[0]
+        if what == "decode":
+            return self._runner("dec").trace_shapes(H, W, C)[0]
+        if what == "forward":
+            e, (h, w, c) = self._runner("enc").trace_shapes(H, W, C)
+            return max(e, self._runner("dec").trace_shapes(h, w, c)[0])
+        return None
+
     def encode(self, img):
         return self._pass("enc", [img])[0]
 

@@ -119,6 +119,38 @@ def test_no_grad_passes_keep_nothing_and_use_the_eval_epilogue(monkeypatch):
     assert torch.equal(lat, lat_g.detach())
 
 
+def test_eval_wrappers_cut_big_batches_by_the_real_activation_size(monkeypatch):
+    """BaseTrainer.predict / encode / decode (eval): a batch goes through in ONE pass while its largest activation tensor stays under 2^28
+    elements -- measured on the compiled stacks, not guessed as 64 channels at full size -- and in pieces beyond, with the same result."""
+    from superresolution_aniso_mri_amd import engine
+    torch.manual_seed(13)
+    tr = _trainer(dict(width=64, latent_width=16, depth=32, latent=128))
+    m = tr.model
+    assert m.max_elems_per_image("encode", (1, 64, 64)) == 66 * 66 * 32
+    assert m.max_elems_per_image("decode", (128, 16, 16)) == 64 * 64 * 32
+    assert m.max_elems_per_image("forward", (1, 64, 64)) == 66 * 66 * 32
+    x = torch.rand(11, 1, 64, 64)
+    one = tr.predict(x).cpu()
+    z = tr.encode(x)
+    calls = []
+    real = engine.SequentialRunner.forward
+
+    def counting(self, xx, *a, **kw):
+        calls.append(int(xx.shape[0]))
+        return real(self, xx, *a, **kw)
+
+    monkeypatch.setattr(engine.SequentialRunner, "forward", counting)
+    tr.predict(x)
+    assert calls == [11, 11]                                    # encoder and decoder: one pass each
+    calls.clear()
+    monkeypatch.setattr(type(m), "max_elems_per_image", lambda self, what, chw: (1 << 28) // 4)
+    pieces = tr.predict(x).cpu()
+    assert sorted(set(calls)) == [3, 4] and 11 not in calls      # pieces of 4 (and the rest of 3), encoder and decoder
+    np.testing.assert_allclose(pieces.numpy(), one.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(tr.decode(z).cpu().numpy(), one.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(tr.encode(x).cpu().numpy(), z.cpu().numpy(), rtol=1e-5, atol=2e-6)
+
+
 def test_fused_lerp_decode_at_eval_patch_size(monkeypatch):
     """BASELINE configs[4] inference leg: a dHCP-shaped volume cropped to the 224 x 224 evaluation patch (README.md:97), 3 interpolations.
     The fused path (decoder's first convolution once per slice, all mixes formed on its pre-activations by aesr_lerp_multi, the rest of
