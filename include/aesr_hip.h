@@ -392,8 +392,8 @@ int aesr_conv2d_wino_supported(int Cin, int Cout, int KS, int pad, int transpose
  * transformed filter stays resident in LDS, independent waves, csrc/conv_wino_res.hip: K-side channels <= 32, or <= 64 where
  * 8 x 8-output blocks tile the image with <= 10 % padding; AESR_WINO_RES=0 disables it, =1 keeps it to <= 32 channels),
  * 3 = conv_wino_ring_f32 (filter chunks through a three-slot LDS ring, independent waves with per-wave patches,
- * csrc/conv_wino_ring.hip: the other layers where the launcher's cost estimate for it is below kernel 1's -- layers whose image
- * 8 x 8-output blocks tile well and that fill at least a round of work items; AESR_WINO_RING=0: never, =2: always).  The
+ * csrc/conv_wino_ring.hip: all the other layers; AESR_WINO_RING=1: only where the launcher's cost estimate for it is below kernel 1's
+ * -- layers whose image 8 x 8-output blocks tile well and that fill at least a round of work items -- =0: never).  The
  * LeakyReLU fused into these kernels is max(x, slope * x): slope must lie in [0, 1] (AESR_ERR_UNSUPPORTED otherwise). */
 int aesr_conv2d_wino_kernel(int N, int H, int W, int Cin, int Cout, int KS, int pad, int transpose);
 /* Watchdog of conv_wino_ring_f32's LDS arrival counters: how many waits gave up since the library was loaded (a wait that long

@@ -53,7 +53,7 @@ struct WinoArgs {
 int aesr_launch_conv_wino(const WinoArgs& a, hipStream_t st);
 bool aesr_wino_res_ok(const WinoArgs& a);                        // few input channels: the filter stays resident, waves run on their own
 int aesr_launch_conv_wino_res(const WinoArgs& a, hipStream_t st);
-int aesr_wino_ring_mode();                                       // AESR_WINO_RING: 0 never, 1 (default) where its cost estimate is lower, 2 always
+int aesr_wino_ring_mode();                                       // AESR_WINO_RING: 0 never, 1 where its cost estimate is lower, 2 (default) always
 bool aesr_wino_ring_takes(const WinoArgs& a);                    // many K-side channels: filter chunks through an LDS ring, independent waves
 int aesr_launch_conv_wino_ring(const WinoArgs& a, hipStream_t st);
 size_t aesr_wino_ring_workspace_floats(const WinoArgs& a);      // floats of workspace the ring kernel's channel split wants for this layer (0: none)

@@ -572,8 +572,11 @@ static RingPlan plan_ring(const WinoArgs& a, int smax) {
 }
 
 int aesr_wino_ring_mode() {
+    // 2 (default since round 4): every streamed layer; 1: only where the cost estimate below is lower than the first streamed kernel's (the
+    // default of round 3 -- it kept 81 x 81 and a few 40 x 40 layers on conv_wino_f32, measured 0.7-0.8 % slower per step at C2 / C4 / C5
+    // than "always": profiles/r04_ring_always.txt); 0: never
     const char* e = getenv("AESR_WINO_RING");          // read per call: tests and A/B scripts switch it inside one process
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 2;
 }
 
 // Which streamed kernel serves a layer: both planners estimate the cycles of the busiest SIMD with the same unit costs (fitted to

@@ -91,7 +91,7 @@ def test_super_volume_in_pieces_equals_one_pass(monkeypatch):
 def test_no_grad_passes_keep_nothing_and_use_the_eval_epilogue(monkeypatch):
     """Under torch.no_grad() a pass keeps no activation for a backward pass that will not come (ctx.needs_input_grad reports the
     parameters regardless), and -- eval mode -- the BatchNorm behind a Winograd layer runs in that layer's epilogue: no aesr_bn_apply call,
-    the same output as with the epilogue switched off (bit for bit: same arithmetic, same order)."""
+    the same output as with the epilogue switched off (the kernel test holds the epilogue to bit equality)."""
     from superresolution_aniso_mri_amd import _hip, engine
     torch.manual_seed(11)
     tr = _trainer(dict(width=64, latent_width=16, depth=32, latent=128))
@@ -115,8 +115,10 @@ def test_no_grad_passes_keep_nothing_and_use_the_eval_epilogue(monkeypatch):
     monkeypatch.setattr(engine, "FUSE_EVAL_BN", False)
     with torch.no_grad():
         plain = tr.model.decode(tr.model.encode(x))
-    assert torch.equal(fused, plain)
-    assert torch.equal(lat, lat_g.detach())
+    # same arithmetic and order as the two launches -- unless the unfused layer takes a channel split (small batches on the ring kernel: its
+    # partial sums add up in another order), hence a rounding-level bound instead of bit equality
+    assert float((fused - plain).norm() / plain.norm()) < 2e-6
+    assert float((lat - lat_g.detach()).norm() / lat_g.detach().norm()) < 2e-6
 
 
 def test_eval_wrappers_cut_big_batches_by_the_real_activation_size(monkeypatch):

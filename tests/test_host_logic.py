@@ -39,11 +39,18 @@ def test_cabi_exports_every_declared_symbol():
         assert k(36, 80, 80, 64, 32, 3, 1, 0) == 2
         assert k(36, 80, 80, 32, 64, 3, 1, 1) == 2          # data gradient: the K side is Cout
         if os.environ.get("AESR_WINO_RING") is None:
-            # streamed layers: the ring kernel where its cost estimate is lower (blocks tile the image, a round of items or more) ...
+            # streamed layers: all on the ring kernel (the default) ...
             assert k(36, 40, 40, 128, 128, 3, 1, 0) == 3 and k(24, 80, 80, 128, 128, 3, 1, 0) == 3 and k(24, 20, 20, 512, 512, 3, 1, 0) == 3
-            # ... the first streamed kernel on 81 x 81 (18 % block padding); VGG conv5 (less than a round of ring items) goes to the ring
-            # kernel with its 32 chunks split over 4 items per block group, for which the library asks for 4 output-sized slabs
-            assert k(36, 81, 81, 64, 64, 3, 1, 0) == 1 and k(24, 10, 10, 512, 512, 3, 1, 0) == 3
+            assert k(36, 81, 81, 64, 64, 3, 1, 0) == 3
+            # ... with AESR_WINO_RING=1 only where its cost estimate is lower: the first streamed kernel on 81 x 81 (18 % block padding);
+            # VGG conv5 (less than a round of ring items) goes to the ring kernel with its 32 chunks split over 4 items per block group,
+            # for which the library asks for 4 output-sized slabs
+            os.environ["AESR_WINO_RING"] = "1"
+            try:
+                assert k(36, 81, 81, 64, 64, 3, 1, 0) == 1 and k(36, 40, 40, 128, 128, 3, 1, 0) == 3
+            finally:
+                del os.environ["AESR_WINO_RING"]
+            assert k(24, 10, 10, 512, 512, 3, 1, 0) == 3
             wsf = _hip.lib.aesr_conv2d_wino_workspace_floats
             assert wsf(24, 10, 10, 512, 512, 0) == 4 * 24 * 10 * 10 * 512 and wsf(36, 40, 40, 128, 128, 0) == 0
             assert wsf(2, 10, 10, 512, 512, 1) == 16 * 2 * 10 * 10 * 512          # a 1-triplet shard: 16 splits of 2 chunks
