@@ -546,8 +546,9 @@ class SequentialRunner:
         if not use_batch:
             # eval mode: scale / shift follow from the running statistics alone -- computed once per state of the layer, not once per call
             # (slice synthesis runs 6 BatchNorm calls per volume: 6 launches of a few hundred threads each)
-            key = (self.weights_epoch, getattr(self, "_bn_updates", 0), bn.weight._version, bn.bias._version, bn.running_mean._version,
-                   bn.running_var._version, bn.weight.data_ptr(), bn.running_mean.data_ptr(), G, str(dev))
+            ver = lambda t: (-1, 0) if t is None else (t._version, t.data_ptr())         # affine=False: no weight / bias
+            key = (self.weights_epoch, getattr(self, "_bn_updates", 0), ver(bn.weight), ver(bn.bias), ver(bn.running_mean), ver(bn.running_var),
+                   G, str(dev))
             cache = self.__dict__.setdefault("_eval_bn", {})
             hit = cache.get(id(bn))
             if hit is not None and hit[0] == key and not torch.cuda.is_current_stream_capturing():

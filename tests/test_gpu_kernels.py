@@ -874,8 +874,8 @@ def test_conv_wino_baseline_size_repeatable(hip, case, streamed_kernel):
 
 @pytest.mark.parametrize("case", [(3, 160, 160, 32, 32), (2, 81, 81, 32, 64), (2, 37, 41, 32, 32), (1, 6, 6, 32, 64), (36, 160, 160, 32, 64),
                                   (30, 112, 112, 64, 64), (30, 56, 56, 128, 128), (30, 57, 55, 64, 128), (30, 28, 28, 128, 256), (30, 112, 112, 64, 32)])
-@pytest.mark.parametrize("pool", [0, 1])
-def test_conv_wino_eval_bn_epilogue(hip, case, pool):
+@pytest.mark.parametrize("pool,act", [(0, 1), (1, 1), (1, 0), (0, 2)])
+def test_conv_wino_eval_bn_epilogue(hip, case, pool, act):
     """Slice synthesis: convolution + LeakyReLU + eval-mode BatchNorm (+ AvgPool2d(2)) in one launch == the convolution followed by
     aesr_bn_apply, bit for bit (same per-element arithmetic and order), odd sizes included (the pooled output floors).  The
     resident-filter kernel (Cin = 32 here) and the ring kernel (the dHCP-size layers above it) carry the epilogue."""
@@ -895,7 +895,7 @@ def test_conv_wino_eval_bn_epilogue(hip, case, pool):
     sh = torch.randn(Cout, device="cuda", generator=g)
     uf = D(_pack_wino(hip, w, 0))
     mid = torch.full((N, H, W, Cout), float("nan"), device="cuda")
-    hip.check(L.aesr_conv2d_wino_fwd(hip.ptr(x), hip.ptr(uf), hip.ptr(b), hip.ptr(mid), N, H, W, Cin, Cout, 1, 0.01, hip.stream()), "wino_fwd")
+    hip.check(L.aesr_conv2d_wino_fwd(hip.ptr(x), hip.ptr(uf), hip.ptr(b), hip.ptr(mid), N, H, W, Cin, Cout, act, 0.01, hip.stream()), "wino_fwd")
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     want = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda")
     ns = hip.int_array([0, N])
@@ -904,12 +904,13 @@ def test_conv_wino_eval_bn_epilogue(hip, case, pool):
     got = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda")
     for _ in range(2):
         got.fill_(float("nan"))
-        hip.check(L.aesr_conv2d_wino_fwd_bn(hip.ptr(x), hip.ptr(uf), hip.ptr(b), hip.ptr(sc), hip.ptr(sh), hip.ptr(got), N, H, W, Cin, Cout, 1, 0.01,
+        hip.check(L.aesr_conv2d_wino_fwd_bn(hip.ptr(x), hip.ptr(uf), hip.ptr(b), hip.ptr(sc), hip.ptr(sh), hip.ptr(got), N, H, W, Cin, Cout, act, 0.01,
                                             pool, hip.stream()), "wino_fwd_bn")
         torch.cuda.synchronize()
         assert not torch.isnan(got).any()
         assert torch.equal(got, want)
-    ref = F.leaky_relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1), 0.01)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1)
+    ref = F.leaky_relu(ref, 0.01) if act == 1 else (F.relu(ref) if act == 2 else ref)
     if pool:
         ref = F.avg_pool2d(ref, 2)
     ref = (ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).permute(0, 2, 3, 1)
