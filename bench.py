@@ -19,6 +19,37 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+def self_launch(argv):
+    """``python bench.py --gpus N`` (N > 1) without an outer launcher: start the N ranks as FRESH child processes under
+    ``torch.distributed.run`` -- before this process imports torch or touches a GPU, never by exec -- let rank 0's JSON line through on the
+    inherited stdout and return the launcher's exit code.  Returns None when there is nothing to launch (N = 1, or the ranks' environment
+    is already there: the driver's own ``python -m torch.distributed.run ... bench.py`` form)."""
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    gpus = ap.parse_known_args(argv)[0].gpus
+    if gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:        # a free rendezvous port on the loop-back interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL across processes needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write("bench: launching %d ranks: %s\n" % (gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
+if __name__ == "__main__":
+    _rc = self_launch(sys.argv[1:])
+    if _rc is not None:
+        sys.exit(_rc)
+
 import torch  # noqa: E402
 
 # algorithmic conv FLOPs per training step (SURVEY.md section 8a / BASELINE.md section 2)
@@ -242,74 +273,72 @@ def secondary_config(engine, config, device, scales3=False, steps=10, warmup=4, 
     return out
 
 
-def small_shards(device):
-    """What strong scaling over 12 triplets runs on, measured on ONE GPU: the replayed single-process step at 1 / 2 / 3 / 6 triplets (c2 and
-    c3), and -- what a RANK of a data-parallel run executes -- the same step at 1 / 2 triplets with the data-parallel machinery switched
-    on over a communicator of one (``*_dp_ms``: SyncBN partial-sum kernels, the 8 SyncBN + 1 gradient collectives as RCCL enqueues, the
-    default graph form; no wire time, no waiting for peers).  8 ranks on 12 triplets are bounded by 36 slices per step of the slowest
-    rank (2 triplets: 2,2,2,2,1,1,1,1)."""
+# what ONE rank of the 8-rank run of each BASELINE configuration executes: config -> (H, single-process shard sizes, rank-step shard sizes,
+# slices of the global batch, triplets on the slowest of 8 ranks).  c2 / c3: 12 triplets -> 2,2,2,2,1,1,1,1; c4 (configs[3]): 16 -> 2 each;
+# c5 (configs[4]): 8 -> 1 each (SyncBN is what keeps its statistics those of the global batch)
+SHARD_CASES = {"c2": (160, (1, 2, 3, 6), (1, 2), 36, 2), "c3": (160, (1, 2, 3, 6), (1, 2), 36, 2),
+               "c4": (220, (2,), (2,), 48, 2), "c5": (256, (1,), (1,), 24, 1)}
+
+
+def small_shards(device, configs=("c2", "c3", "c4", "c5")):
+    """What strong scaling runs on, measured on ONE GPU: the replayed single-process step at the shard sizes of SHARD_CASES and -- what a
+    RANK of a data-parallel run executes -- the same step with the data-parallel machinery switched on over a communicator of one
+    (``*_dp_ms``: SyncBN partial-sum kernels, the 8 SyncBN + 1 gradient collectives as RCCL enqueues, the default graph form; no wire
+    time, no waiting for peers).  The 8-rank rate is bounded by the global batch per step of the slowest rank."""
     import torch.distributed as dist
     from superresolution_aniso_mri_amd.parallel import DataParallelContext
     out = {}
-    for config in ("c2", "c3"):
+    for config in configs:
+        H, singles, _, _, _ = SHARD_CASES[config]
         row = {}
-        for t in (1, 2, 3, 6):
-            trainer, pool = make_trainer(config, device, t, 160, npool=2)
+        for t in singles:
+            trainer, pool = make_trainer(config, device, t, H, npool=2)
             row["%d_triplets_ms" % t] = round(1e3 * timed_steps(trainer, pool, 20, 6) / 20, 3)
             del trainer, pool
         torch.cuda.empty_cache()
         out[config] = row
-    dp, saved = None, os.environ.get("AESR_FORCE_DP")
-    try:
-        os.environ["AESR_FORCE_DP"] = "1"
+
+    def rank_steps(suffix):
         if not dist.is_initialized():          # a group of one without a network port
             dist.init_process_group("gloo", store=dist.HashStore(), rank=0, world_size=1)
         dp = DataParallelContext(device=device)
-        for config in ("c2", "c3"):
-            for t in (1, 2):
-                trainer, pool = make_trainer(config, device, t, 160, npool=2, dp=dp)
-                out[config]["%d_triplets_dp_ms" % t] = round(1e3 * timed_steps(trainer, pool, 20, 6, dp) / 20, 3)
-                del trainer, pool
-            torch.cuda.empty_cache()
-        out["dp_form"] = "communicator of one, data plane %s, graph form %s, SyncBN exchange %s" % (dp.data_backend, dp.graph_mode, dp.syncbn)
-        # the opt-in one-shot SyncBN exchange (AESR_SYNCBN=p2p: inside the one-launch BatchNorm kernels, over a peer group of one): only the
-        # gradient all-reduce is left as a collective
-        dp.shutdown()
-        dp = None
-        saved_sync = os.environ.get("AESR_SYNCBN")
-        os.environ["AESR_SYNCBN"] = "p2p"
         try:
-            if not dist.is_initialized():
-                dist.init_process_group("gloo", store=dist.HashStore(), rank=0, world_size=1)
-            dp = DataParallelContext(device=device)
-            for config in ("c2", "c3"):
-                for t in (1, 2):
-                    trainer, pool = make_trainer(config, device, t, 160, npool=2, dp=dp)
-                    out[config]["%d_triplets_dp_p2p_ms" % t] = round(1e3 * timed_steps(trainer, pool, 20, 6, dp) / 20, 3)
+            for config in configs:
+                H, _, ranks, _, _ = SHARD_CASES[config]
+                for t in ranks:
+                    trainer, pool = make_trainer(config, device, t, H, npool=2, dp=dp)
+                    out[config]["%d_triplets_%s_ms" % (t, suffix)] = round(1e3 * timed_steps(trainer, pool, 20, 6, dp) / 20, 3)
                     del trainer, pool
                 torch.cuda.empty_cache()
-            out["dp_p2p_form"] = "communicator of one, data plane %s, graph form %s, SyncBN exchange %s (opt-in)" % (dp.data_backend, dp.graph_mode, dp.syncbn)
+            return "communicator of one, data plane %s, graph form %s, SyncBN exchange %s" % (dp.data_backend, dp.graph_mode, dp.syncbn)
         finally:
-            if saved_sync is None:
-                os.environ.pop("AESR_SYNCBN", None)
-            else:
-                os.environ["AESR_SYNCBN"] = saved_sync
+            dp.shutdown()
+
+    saved = {k: os.environ.get(k) for k in ("AESR_FORCE_DP", "AESR_SYNCBN")}
+    try:
+        os.environ["AESR_FORCE_DP"] = "1"
+        out["dp_form"] = rank_steps("dp")
+        # the opt-in one-shot SyncBN exchange (AESR_SYNCBN=p2p: inside the one-launch BatchNorm kernels, over a peer group of one): only the
+        # gradient all-reduce is left as a collective
+        os.environ["AESR_SYNCBN"] = "p2p"
+        out["dp_p2p_form"] = rank_steps("dp_p2p") + " (opt-in)"
     except Exception as e:       # no RCCL on this box: the projection falls back to the single-process step
         out["dp_note"] = "one-rank data-parallel step not measured (%s)" % (str(e)[:160],)
     finally:
-        if dp is not None:
-            dp.shutdown()
-        if saved is None:
-            os.environ.pop("AESR_FORCE_DP", None)
-        else:
-            os.environ["AESR_FORCE_DP"] = saved
-    for config in ("c2", "c3"):
-        step_ms = out[config].get("2_triplets_dp_ms", out[config]["2_triplets_ms"])
-        out[config]["projected_8_rank_slices_per_s"] = round(36.0 / step_ms * 1e3, 1)
-        if "2_triplets_dp_p2p_ms" in out[config]:
-            out[config]["projected_8_rank_slices_per_s_p2p"] = round(36.0 / out[config]["2_triplets_dp_p2p_ms"] * 1e3, 1)
-    out["projection"] = ("36 slices / the 2-triplet step of one rank with SyncBN and the 9 collectives enqueued on a communicator of one: an UPPER "
-                         "bound on the 8-rank rate (wire time and waiting for the slowest peer come on top)")
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for config in configs:
+        _, _, _, slices, t = SHARD_CASES[config]
+        step_ms = out[config].get("%d_triplets_dp_ms" % t, out[config]["%d_triplets_ms" % t])
+        out[config]["projected_8_rank_slices_per_s"] = round(slices / step_ms * 1e3, 1)
+        if "%d_triplets_dp_p2p_ms" % t in out[config]:
+            out[config]["projected_8_rank_slices_per_s_p2p"] = round(slices / out[config]["%d_triplets_dp_p2p_ms" % t] * 1e3, 1)
+    out["projection"] = ("global batch (36 / 36 / 48 / 24 slices) / the step of the slowest of 8 ranks (2 / 2 / 2 / 1 triplets) with SyncBN and the 9 "
+                         "collectives enqueued on a communicator of one: an UPPER bound on the 8-rank rate (wire time and waiting for the slowest "
+                         "peer come on top)")
     return out
 
 
@@ -429,9 +458,10 @@ def main():
     ap.add_argument("--triplets", type=int, default=0, help="global batch in triplets (default: the BASELINE workload; other values are for experiments only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured step")
     ap.add_argument("--dp-graph", choices=("on", "off"), default="on",
-                    help="N > 1: 'on' (default) replays the step from the captured graph (RCCL data plane: ONE graph with the collectives "
-                    "as nodes; gloo rehearsal: graph segments between eager collectives); 'off' launches every kernel from the host. "
-                    "A failure in either form ends the run with a non-zero exit code: no other form is substituted")
+                    help="N > 1: 'on' (default) replays the step from captured graphs -- by default as graph SEGMENTS cut at the 9 collectives, "
+                    "which stay eager enqueues on the same stream (RCCL, or host-staged gloo for rehearsals); AESR_DP_GRAPH=whole makes the "
+                    "collectives nodes of ONE graph (RCCL only). 'off' launches every kernel from the host. A failure in either form ends the "
+                    "run with a non-zero exit code: no other form is substituted")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary single-GPU measurements (c3, c3 with scales 3, c4, c5, "
                     "small shards, inference)")
     opt = ap.parse_args()
@@ -459,6 +489,9 @@ def main():
                       "one HIP graph per step, RCCL collectives (library-owned communicator) as graph nodes" if dp.graph_mode == "whole" else
                       ("HIP graph segments between eager RCCL collectives (library-owned communicator)" if dp.data_backend == "rccl" else
                        "HIP graph segments between eager host-staged (gloo) collectives"))
+        if dp.active:
+            launch += "; graph form %s, data plane %s, SyncBN exchange %s" % (dp.graph_mode if use_graph else "none", dp.data_backend, dp.syncbn)
+        if use_graph:
             if not getattr(trainer, "_graphs", None):
                 raise SystemExit("bench: the step graph was requested but never captured")
         loss = trainer.losses["loss_ae"][-1]

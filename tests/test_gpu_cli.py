@@ -123,3 +123,27 @@ def test_two_rank_training_cli_on_one_device(tmp_path, syncbn):
         assert ref.read_text() == "\n".join(lines)
     else:
         ref.write_text("\n".join(lines))
+
+
+def test_bench_launches_its_own_ranks():
+    """``python bench.py --gpus 2`` with NO outer launcher (WORLD_SIZE unset): the ranks start as fresh child processes under
+    torch.distributed.run before the parent touches torch or the GPU; rank 0's single JSON line and the exit code come through.  Two
+    ranks rehearsed on the one device of the test box (gloo data plane)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(AESR_SINGLE_DEVICE="1", AESR_DIST_BACKEND="gloo", AESR_BN_FUSED_NB="64")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-secondary"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-1500:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["value"] > 0 and line["scaling"] == "strong"
+    assert "graph form segments" in line["config"]["launch"] and "SyncBN exchange" in line["config"]["launch"]
+    # a rank that fails takes the launcher's exit code with it and no line is printed
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-secondary",
+                          "--config", "nope"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and bad.stdout.strip() == ""
