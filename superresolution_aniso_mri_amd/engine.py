@@ -307,7 +307,11 @@ class SequentialRunner:
         self.params = [p for p in seq.parameters()]
 
     def mark_weights_dirty(self):
+        """Host counters only (no launch).  Every state a kernel may have written through raw pointers counts as changed: the parameters
+        (packed operands, folded stem) and the BatchNorm running statistics (eval-mode scale / shift cache) -- a replayed step graph
+        updates both without any tensor version or Python-side counter moving, so the trainer calls this after every replay."""
         self.weights_epoch += 1
+        self._bn_updates = getattr(self, "_bn_updates", 0) + 1
 
     # ---- weight preparation ---------------------------------------------------------------------------------
     def _prep_jobs(self, steps):

@@ -144,6 +144,7 @@ class AEBaseTrainer(BaseTrainer):
                     self._capture_sink = None
                     self.dp.segments = None
                 self._graphs[sig] = (graph, static, sink)
+                self._replayed()
                 self._log_sink(sink)
                 return
             graph = torch.cuda.CUDAGraph()
@@ -160,7 +161,15 @@ class AEBaseTrainer(BaseTrainer):
             if static[k].data_ptr() != dev_batch[k].data_ptr():
                 static[k].copy_(dev_batch[k])
         graph.replay()
+        self._replayed()
         self._log_sink(sink)
+
+    def _replayed(self):
+        """A replay rewrote the parameters, the BatchNorm running statistics and (one step behind) the packed operands through raw
+        pointers: no tensor version moved and no Python ran, so every host-side cache keyed on them is stale -- the eval-mode BatchNorm
+        scale / shift, the packed filters an eager validate() / encode() / decode() would reuse.  Host counters only."""
+        if hasattr(self.model, "mark_weights_dirty"):
+            self.model.mark_weights_dirty()
 
     def _log_sink(self, sink):
         """Log the scalars a replayed step left in its static buffers: ONE gather kernel for all of them (the buffers are
