@@ -415,6 +415,82 @@ def gen_trainer_steps(av):
         print("  step_probe_%s: losses %s" % (tag, rec["losses"]))
 
 
+def gen_val_volumes(av):
+    """kwatsch/base_trainer.py:67-99,149-162: ``validate(validation_batch, image_dict=...)`` of the reference's OWN ``AETrainerEndToEnd`` on the
+    CPU -- ``_generate_val_volumes`` -> ``evaluate.evaluate_image.evaluate_image`` (:37-80: AdjustToPatchSize + CenterCrop, every 2nd slice
+    kept, the held-out ones synthesised at alpha 0.5, all slices reconstructed) -> ``create_compare_image`` (:83-106) per in-memory 4-D
+    patient.  Placement shims only: ``Tensor.to('cuda')`` (evaluate/common.py:185, kwatsch/base_trainer.py:317) is the identity here and
+    ``latent_space_interp``'s default device is bound to 'cpu'.  torchvision is absent: ``transforms.Compose`` is its published definition
+    (apply in order) and ``make_grid`` RECORDS its argument -- the fixture stores the tensor the reference hands to ``make_grid`` with its
+    nrow / padding / pad_value, so the grid layout itself stays pinned by the layout tests of the build's own ``make_grid``."""
+    import functools
+    tae, cta, bta = import_reference_trainers()
+    import evaluate.common as ec
+    import evaluate.evaluate_image as ei
+    ec.latent_space_interp = functools.partial(ec.latent_space_interp, device="cpu")
+
+    class Compose(object):
+        def __init__(self, ts):
+            self.transforms = ts
+
+        def __call__(self, x):
+            for t in self.transforms:
+                x = t(x)
+            return x
+
+    ei.transforms.Compose = Compose
+    seen = []
+
+    def recording_make_grid(t, nrow=8, padding=2, normalize=False, pad_value=0):
+        seen.append((t.detach().clone(), int(nrow), int(padding), float(pad_value), bool(normalize)))
+        return t
+
+    ei.make_grid = recording_make_grid
+    if not hasattr(np, "bool"):
+        np.bool = bool                              # create_compare_image uses the alias numpy removed in 1.24 (evaluate_image.py:93-94)
+    to0 = torch.Tensor.to
+
+    def to_cpu_if_cuda(self, *a, **k):
+        if a and isinstance(a[0], str) and a[0].startswith("cuda"):
+            return self
+        return to0(self, *a, **k)
+
+    args = trainer_args("mse", lr=1e-3)
+    rec, trainer = _run_reference_trainer(av, cta.AETrainerEndToEnd, args, _triplet_batches(2, 3, 32, 32, 900))
+    rec = {"p/" + k: v for k, v in np_state(trainer.model.state_dict()).items()}
+    g = np.random.RandomState(31)
+
+    def patient(t, z, h, w):
+        low = g.rand(t, z, (h + 7) // 8, (w + 7) // 8)
+        return np.clip(np.kron(low, np.ones((1, 1, 8, 8)))[:, :, :h, :w] * 0.8 + 0.15 * g.rand(t, z, h, w), 0, 1).astype(np.float32)
+
+    image_dict = {3: {"image": patient(3, 7, 40, 36), "patient_id": "patient003", "spacing": np.array([8.0, 1.4, 1.4])},
+                  17: {"image": patient(2, 8, 30, 44), "patient_id": "patient017", "spacing": np.array([10.0, 1.25, 1.25])}}
+    val = _triplet_batches(1, 4, 32, 32, 950)[0]
+    frame_id = 1
+    torch.Tensor.to = to_cpu_if_cuda
+    try:
+        out = trainer.validate(dict(val), image_dict=image_dict, frame_id=frame_id, generate_images=False)
+        ev = {p: ei.evaluate_image(trainer, image_dict[p], frame_id=frame_id, downsample_steps=2, eval_patch_size=args["width"]) for p in image_dict}
+    finally:
+        torch.Tensor.to = to0
+    assert sorted(out["synthesized_vols"].keys()) == [3, 17] and len(seen) >= 2
+    rec["val/image"], rec["val/slice_between"] = val["image"].numpy(), val["slice_between"].numpy()
+    rec["val/loss_ae"] = np.float64(out["loss_ae"])
+    rec["frame_id"], rec["patients"] = np.array(frame_id), np.array([3, 17])
+    for i, p in enumerate((3, 17)):
+        t, nrow, padding, pad_value, normalize = seen[i]
+        assert not normalize and np.array_equal(out["synthesized_vols"][p], t.numpy())      # the recorder returned its argument
+        rec["p%d/image4d" % p] = image_dict[p]["image"]
+        rec["p%d/grid_input" % p] = t.numpy()
+        rec["p%d/grid_args" % p] = np.array([nrow, padding, pad_value])
+        rec["p%d/alphas" % p] = np.asarray(out["alphas"][p], dtype=np.float32)
+        rec["p%d/orig" % p] = ev[p]["orig_images"][frame_id]
+        rec["p%d/synth" % p] = ev[p]["synth_images"][frame_id]
+    np.savez_compressed(os.path.join(OUT, "val_volumes.npz"), **rec)
+    print("  val_volumes: loss_ae %.6f, grid inputs %s" % (out["loss_ae"], [tuple(seen[i][0].shape) for i in range(2)]))
+
+
 def gen_supervolume(av):
     """generate_hr_volumes.py:12-101 arithmetic (z=5, n=3) around the reference model in eval mode; the
     reference function itself hard-codes .to('cuda') so its loop is restated here verbatim in meaning:
@@ -751,6 +827,9 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "trainer_steps":
         gen_trainer_steps(import_reference()[0])
         return
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "val_volumes":
+        gen_val_volumes(import_reference()[0])
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "supervolume_eval":
         gen_supervolume_eval(import_reference()[0])
         return
@@ -768,6 +847,7 @@ def main():
     gen_lpips(nb)
     gen_trainer_steps(av)          # step_k3_*: the reference's own trainer classes (supersedes the restated gen_steps)
     gen_supervolume(av)
+    gen_val_volumes(av)            # last: it rebinds names inside the reference's evaluate.* modules
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote %d fixtures, %.1f KiB" % (len(os.listdir(OUT)), tot / 1024))
 

@@ -196,6 +196,29 @@ def create_super_volume_eval(ae, images, alpha_range=None, use_original=True, do
     return hr, alphas
 
 
+def val_volume_compare(ae, image4d, frame_id, eval_patch_size, downsample_steps=2):
+    """kwatsch/base_trainer.py:149-162 -> evaluate/evaluate_image.py:37-80,83-106 for ONE patient: frame ``frame_id`` of a [t,z,y,x]
+    image is padded / centre-cropped to the evaluation patch (datasets/shared_transforms.py AdjustToPatchSize + CenterCrop), every 2nd
+    slice kept and reconstructed, the held-out ones synthesised at alpha 0.5 (evaluate/common.py:134-235 with use_original=False,
+    generate_inbetween_slices=True); returns (orig [z,y,x], synth [z',y,x], the [7k,1,y,x] stack handed to make_grid, k)."""
+    from . import augment_oracle
+    f = min(int(frame_id), image4d.shape[0] - 1)
+    orig = torch.from_numpy(np.ascontiguousarray(augment_oracle.adjust_and_center_crop(np.asarray(image4d[f], dtype=np.float32), int(eval_patch_size))))
+    synth, _ = create_super_volume_eval(ae, orig, [0.5], use_original=False, downsample_steps=downsample_steps, generate_inbetween_slices=True)
+    real, syn = orig.numpy(), synth.numpy()
+    if real.shape[0] % downsample_steps == 0:                     # evaluate_image.py:88-92
+        real, syn = real[:-1], syn[:-1]
+    n = real.shape[0]
+    s_mask = np.ones(n, dtype=bool)
+    s_mask[::downsample_steps] = False
+    r_mask = ~s_mask
+    s1, s3 = real[r_mask][:-1], real[r_mask][1:]
+    r1, r3 = syn[r_mask][:-1], syn[r_mask][1:]
+    held, made = real[s_mask], syn[s_mask]
+    stack = np.concatenate([s1[:, None], r1[:, None], held[:, None], made[:, None], (held - made)[:, None], r3[:, None], s3[:, None]], axis=0)
+    return orig.numpy(), synth.numpy(), stack, s1.shape[0]
+
+
 def synthetic_triplets(B, H, W, seed, device="cpu"):
     """Smooth, correlated (from, to, between) triplets in [0,1]: sum of 8 Gaussian blobs
     + low-pass noise; between = 0.5(from+to) + N(0, 0.02)."""

@@ -63,6 +63,39 @@ def load_volume_dir(path):
     return vols
 
 
+def load_image_dict(path, max_patients=2):
+    """The in-memory validation images ``validate(image_dict=...)`` previews (train_cardiac_aesr.py:49-53 of the reference: two 4-D
+    patients): {p_id: {'image': [t,z,y,x] float32 in [0,1], 'patient_id': 'patientNNN', 'spacing': (z,y,x)}} from the first
+    ``max_patients`` volumes of a directory (a 3-D volume counts as one frame).  p_id: the digits in the file name, else its rank."""
+    import os
+    import re
+    from . import volume_io
+    out = {}
+    for rank, name in enumerate(sorted(os.listdir(path))):
+        f, low = os.path.join(path, name), name.lower()
+        if low.endswith(".npy"):
+            arr, spacing = np.load(f), (1.0, 1.0, 1.0)
+        elif low.endswith((".nii", ".nii.gz", ".mha", ".mhd")):
+            v = volume_io.read_volume(f)
+            arr, spacing = v.array, tuple(v.spacing[:3][::-1])
+        else:
+            continue
+        arr = np.asarray(arr, dtype=np.float32)
+        arr = arr[None] if arr.ndim == 3 else arr
+        if arr.ndim != 4:
+            raise ValueError("%s: expected a 3-D or 4-D image, got shape %s" % (f, arr.shape))
+        if not (arr.min() >= 0 and arr.max() <= 1):
+            arr = np.stack([rescale_intensities(a) for a in arr])
+        digits = re.findall(r"\d+", name)
+        p_id = int(digits[0]) if digits and int(digits[0]) not in out else 1000 + rank
+        out[p_id] = {"image": arr, "patient_id": "patient{:03d}".format(p_id), "spacing": np.asarray(spacing, dtype=np.float64)}
+        if len(out) >= int(max_patients):
+            break
+    if not out:
+        raise FileNotFoundError("no .npy / .nii / .mha / .mhd images in %s" % path)
+    return out
+
+
 class TripletAugmenter:
     """``volumes``: list of float32 arrays [Z,H,W] already intensity-normalised to [0,1] (one per patient / frame)."""
 

@@ -53,6 +53,9 @@ def build_parser():
     a("--synthetic_pool", type=int, default=8, help="distinct device-resident synthetic batches that --synthetic cycles through (made before the loop)")
     a("--volumes_dir", type=str, default=None, help="train on the volumes (.npy [Z,H,W] / [T,Z,H,W], .nii(.gz), .mha, .mhd) of this "
                                                   "directory: device-resident cache + on-device triplet assembly / augmentation")
+    a("--val_volumes_dir", type=str, default=None, help="4-D (or 3-D) validation images of this directory become the in-memory image_dict "
+                                                      "that validate() previews as val_image_e###_p###.png (at most --val_patients of them)")
+    a("--val_patients", type=int, default=2, help="validation patients kept for the whole-volume previews (the reference loads 2)")
     a("--iters_per_epoch", type=int, default=50, help="iterations per epoch with --synthetic")
     a("--vgg_weights", type=str, default=None, help="local torchvision vgg16 state_dict for LPIPS (offline)")
     a("--use_step_graph", action="store_true", help="capture the training step in a HIP graph")

@@ -300,8 +300,26 @@ class BaseTrainer(object):
         result = {"img_grid_recons": grid, "loss_ae": self.losses_test["loss_ae"][-1]}
         _check_watchdogs(self, "validate")
         if image_dict is not None:
-            result.update(synthesized_vols=None, alphas=None)   # whole-volume previews need the dataset readers
+            vols, alphas = self._generate_val_volumes(image_dict, frame_id=frame_id)
+            result.update(synthesized_vols=vols, alphas=alphas)
         return result
+
+    def _generate_val_volumes(self, image_dict, frame_id):
+        """Whole-volume validation previews (reference :149-162): for every in-memory 4-D patient ``image_dict[p_id]`` (keys ``image``
+        [t,z,y,x], ``patient_id``, ``spacing``) frame ``frame_id`` is cropped to ``eval_patch_size`` (default: ``width``), every 2nd slice
+        kept, the held-out slices synthesised at alpha 0.5 and all kept ones reconstructed (``evaluate.evaluate_image.evaluate_image``: one
+        encoder pass, one decoder pass per volume); returns ({p_id: comparison grid}, {p_id: alphas}).  A ``frame_id`` beyond the
+        patient's last frame means the last frame (``evaluate_image`` clips it, :50-51; the reference then fails on its own dict key)."""
+        from collections import defaultdict
+        from ..evaluate.evaluate_image import create_compare_image, evaluate_image
+        vols, alphas = defaultdict(dict), defaultdict(dict)
+        eval_patch_size = self.args.get("eval_patch_size", self.args["width"])
+        for p_id, data in image_dict.items():
+            f_id = min(int(frame_id), int(data["image"].shape[0]) - 1)
+            res = evaluate_image(self, data, frame_id=f_id, downsample_steps=2, eval_patch_size=eval_patch_size)
+            vols[p_id] = create_compare_image(res["orig_images"][f_id], res["synth_images"][f_id])
+            alphas[p_id] = res["pred_alphas"][f_id]
+        return vols, alphas
 
     def _best_now(self, key):
         hist = self.mean_losses_test[key]
@@ -369,7 +387,11 @@ class BaseTrainer(object):
         if self.epoch > self.args["epoch_threshold"]:
             self.save_models(os.path.join(self.args["dir_models"], "{:0d}.models".format(epoch)), epoch)
         self.save_losses()
-        if self._is_writer() and val.get("img_grid_recons") is not None:
+        if self._is_writer():
             from .acai_utils import save_image_grid
-            save_image_grid(val["img_grid_recons"], os.path.join(self.args["dir_images"], "val_recons_e{:03d}.png".format(epoch)))
+            # example validation volumes, one PNG per patient (reference :416-418)
+            for p_id, grid in (val.get("synthesized_vols") or {}).items():
+                save_image_grid(grid, os.path.join(self.args["dir_images"], "val_image_e{:03d}_p{:03d}.png".format(epoch, int(p_id))))
+            if val.get("img_grid_recons") is not None:
+                save_image_grid(val["img_grid_recons"], os.path.join(self.args["dir_images"], "val_recons_e{:03d}.png".format(epoch)))
         self.epoch += 1      # initialised with 0 in AEBaseTrainer.__init__

@@ -119,6 +119,10 @@ def main(argv=None, brain=False):
         trainer.enable_step_graph(dp_segments=dp.active)
     trainer.init_tensorboard(args_dict["output_dir"])
     validation_batch = make_batch(args_dict["seed"] - 1, args_dict["test_batch_size"], training=False)
+    image_dict_val = None       # train_cardiac_aesr.py:49-53,183: a few in-memory 4-D patients, previewed as whole volumes at every validation
+    if args_dict.get("val_volumes_dir"):
+        from .data_device import load_image_dict
+        image_dict_val = load_image_dict(args_dict["val_volumes_dir"], args_dict.get("val_patients") or 2)
     num_it_per_epoch = args_dict["iters_per_epoch"]
     args.num_it_per_epoch = num_it_per_epoch
     if dp.rank == 0:
@@ -132,7 +136,7 @@ def main(argv=None, brain=False):
                 do_validate = (trainer.iters + 1) % num_it_per_epoch == 0
                 trainer.train(batch_item, keep_predictions=do_validate)
                 if do_validate:
-                    val_result = trainer.validate(validation_batch, image_dict=None)
+                    val_result = trainer.validate(validation_batch, image_dict=image_dict_val)
                     trainer.show_loss_on_tensorboard()
                     trainer.show_loss_on_tensorboard(eval_type="test")
                     trainer.generate_train_images(epoch=int(epoch), batch_item=batch_item)

@@ -2,7 +2,7 @@
 """Parity report at the BASELINE configurations (SURVEY section 8d "Parity report"): the HIP trainer against the CPU oracle from
 the same initial parameters on the same synthetic batches.  Test infrastructure (it imports oracle/), not collected by pytest:
 
-    python tests/parity_report.py [c1 c2 c3 c4 c5] > profiles/rNN_parity_report.txt
+    python tests/parity_report.py [c1 c2 c3 c4 c5 percept] > profiles/rNN_parity_report.txt
 
 Per configuration: after ONE step -- rel-L2 of the latents / reconstructions / synthesised slices, relative loss differences,
 rel-L2 of the first-step gradients; SSIM and PSNR of reconstruction-vs-input and synthesis-vs-target on both sides and their
@@ -123,9 +123,33 @@ def run(tag):
     sys.stdout.flush()
 
 
+def run_percept_fixture():
+    """The one tolerated parity miss, shown every round (round-4 verdict, weak 1a): ``--use_percept_loss`` (LPIPS as the RECONSTRUCTION
+    loss) on the reference trainer's own fixture tests/golden/step_k3_cardiac_percept.npz -- first-step gradients of the HIP trainer at the
+    EXACT fixture input and one part in 1e7 beside it, per-tensor rel-L2 against the reference's gradients.  tests/test_gpu_step.py accepts a
+    miss of the 2e-4 bound at the exact input only if it stays below 3e-3 and every check passes at a neighbouring input."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_step as tgs
+    rec = dict(np.load(os.path.join(ROOT, "tests", "golden", "step_k3_cardiac_percept.npz")))
+    print("== cardiac_percept fixture (3 triplets of 32x32, LPIPS reconstruction + synthesis loss, the reference's AETrainerEndToEnd): "
+          "first-step gradients, rel-L2 per parameter tensor against the reference's (test bound 2e-4; tolerated at the exact input: 3e-3)")
+    for name, eps in (("exact input", 0.0), ("input x (1 + 1e-7)", 1e-7), ("input x (1 - 1e-7)", -1e-7)):
+        tr = tgs.make_trainer("cardiac_percept", rec)
+        batch = tgs._batch(rec, 0)
+        if eps:
+            batch["image"] = batch["image"] * (1.0 + eps)
+        tr.train(batch, keep_predictions=False)
+        errs = sorted((rel_l2(p.grad, rec["grad0/" + k]), k) for k, p in tr.model.named_parameters())
+        loss = tr.losses["loss_ae"][-1]
+        print("     %-20s worst %.2e (%s)   median %.2e   loss_ae %.6e (reference %.6e, rel diff %.1e)   -> %s"
+              % (name, errs[-1][0], errs[-1][1], errs[len(errs) // 2][0], loss, rec["losses"][0][0], abs(loss - rec["losses"][0][0]) / abs(rec["losses"][0][0]),
+                 "within 2e-4" if errs[-1][0] < 2e-4 else "MISS (one VGG max-pool / ReLU routing tie: profiles/r04_percept_sensitivity.txt)"))
+    sys.stdout.flush()
+
+
 if __name__ == "__main__":
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     print("parity report: HIP trainer (cuda:0, %s) vs oracle/ (PyTorch-CPU fp32), synthetic batches of superresolution_aniso_mri_amd.data_synth, "
           "synthetic-hash VGG backbone for LPIPS" % torch.cuda.get_device_name(0))
-    for t in (sys.argv[1:] or ["c1", "c2", "c3", "c4", "c5"]):
-        run(t)
+    for t in (sys.argv[1:] or ["c1", "c2", "c3", "c4", "c5", "percept"]):
+        run_percept_fixture() if t == "percept" else run(t)

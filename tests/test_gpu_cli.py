@@ -58,10 +58,15 @@ def test_train_from_volume_directory(tmp_path):
     tr = train_aesr.main(["--dataset=ACDC", "--model=ae_combined", "--batch_size=4", "--test_batch_size=4", "--latent=16",
                           "--latent_width=8", "--width=32", "--depth=8", "--downsample_steps=2", "--epochs=2", "--lr=0.001",
                           "--ex_loss_weight1=0.05", "--exper_id=v1", "--output_dir=" + out, "--volumes_dir=" + str(data),
+                          "--val_volumes_dir=" + str(data),
                           "--aug_patch_size=40", "--iters_per_epoch=3", "--image_mix_loss_func=mse", "--epoch_threshold=0",
                           "--use_step_graph"])
     assert tr.iters == 1 + 6 and np.isfinite(tr.mean_losses["loss_ae"][-1])
     assert os.path.isfile(os.path.join(out, "v1", "models", "2.models"))
+    # --val_volumes_dir: the two images of the directory are the in-memory validation patients; every epoch leaves one preview each
+    import glob
+    pngs = sorted(os.path.basename(f) for f in glob.glob(os.path.join(out, "v1", "**", "val_image_e*_p*.png"), recursive=True))
+    assert pngs == ["val_image_e%03d_p%03d.png" % (e, p) for e in (1, 2) for p in (1, 2)], pngs
 
 
 def test_config1_mnist_shaped_step_vs_oracle():

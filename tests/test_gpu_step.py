@@ -58,12 +58,13 @@ def _batch(rec, step):
 
 
 @pytest.mark.parametrize("tag", sorted(STEP_CASES))
-def test_three_train_steps(tag):
+def test_three_train_steps(tag, record_property):
     """Three optimisation steps of the HIP trainer classes against three steps of the reference's own trainer classes."""
     rec = dict(np.load(os.path.join(GOLDEN, "step_k3_%s.npz" % tag)))
     try:
         _three_train_steps(tag, rec)
-    except AssertionError:
+        record_property("parity_branch", "exact input")
+    except AssertionError as first:
         if "percept" not in tag:
             raise
         # LPIPS as the RECONSTRUCTION loss on 3 tiny triplets: ONE max-pool / ReLU routing decision of the VGG stack that sits within fp32
@@ -72,13 +73,26 @@ def test_three_train_steps(tag):
         # (round 4) this fixture does at exactly its input -- the forward tensors of the two BatchNorm forms differ by 2.4e-7 -- and one
         # part in 1e7 away it does not; 13 variants in profiles/r04_percept_sensitivity.txt.  So a miss at the exact input must (a) cost
         # no more than 3e-3 in the first-step gradients and (b) go away, for EVERY check of this test, at a neighbouring input.
+        # WHICH branch passed is reported: a warning in the test summary, a property in the junit record, and tests/parity_report.py
+        # prints the exact-input figure into profiles/rNN_parity_report.txt every round.
         t0 = make_trainer(tag, rec)
         t0.train(_batch(rec, 0), keep_predictions=False)
-        assert max(rel_l2(p.grad, rec["grad0/" + k]) for k, p in t0.model.named_parameters()) < 3e-3
+        errs = sorted((rel_l2(p.grad, rec["grad0/" + k]), k) for k, p in t0.model.named_parameters())
+        worst, median = errs[-1], errs[len(errs) // 2][0]
+        assert worst[0] < 3e-3, worst
         try:
             _three_train_steps(tag, rec, eps=1e-7)
+            branch = "input x (1 + 1e-7)"
         except AssertionError:
             _three_train_steps(tag, rec, eps=-1e-7)
+            branch = "input x (1 - 1e-7)"
+        msg = ("%s: the reference's EXACT fixture input is NOT reproduced within the bounds (first failed check: %s; first-step gradients worst "
+               "%.2e on %s, median %.2e against 2e-4); every check passes at %s" % (tag, str(first).splitlines()[0][:120], worst[0], worst[1], median, branch))
+        record_property("parity_branch", branch)
+        record_property("exact_input_worst_gradient_rel_l2", worst[0])
+        import warnings
+        warnings.warn(msg)
+        print("PARITY NOTE - " + msg)
 
 
 def _three_train_steps(tag, rec, eps=0.0):

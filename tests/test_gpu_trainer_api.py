@@ -48,6 +48,41 @@ def test_validate_and_epoch_hooks(tmp_path):
     assert z.is_cuda and tuple(z.shape) == (8, 16, 8, 8) and tuple(tr.predict(val["image"]).shape) == (8, 1, 32, 32)
 
 
+def test_validate_previews_whole_volumes_like_the_reference(tmp_path):
+    """validate(validation_batch, image_dict=...) (kwatsch/base_trainer.py:67-99,149-162): the HIP trainer on two in-memory 4-D patients
+    against what the reference's OWN trainer class returned on the CPU (tests/golden/val_volumes.npz): validation loss, the per-patient
+    comparison grid (= the build's make_grid over the tensor the reference hands to torchvision's), alphas; end_epoch_processing writes
+    one val_image_e###_p###.png per patient (:416-418)."""
+    from superresolution_aniso_mri_amd.kwatsch.acai_utils import make_grid
+    from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic
+    rec = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "val_volumes.npz")))
+    tr = get_trainer_dynamic(_args(tmp_path, lr=1e-3, epoch_threshold=100))
+    tr.model.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in rec.items() if k.startswith("p/")})
+    image_dict = {int(p): {"image": rec["p%d/image4d" % p], "patient_id": "patient%03d" % p, "spacing": np.array([8.0, 1.4, 1.4])}
+                  for p in rec["patients"]}
+    val = {"image": torch.from_numpy(rec["val/image"]), "slice_between": torch.from_numpy(rec["val/slice_between"])}
+    res = tr.validate(val, image_dict=image_dict, frame_id=int(rec["frame_id"]), generate_images=True)
+    assert set(res) == {"img_grid_recons", "loss_ae", "synthesized_vols", "alphas"}
+    assert abs(float(res["loss_ae"]) - float(rec["val/loss_ae"])) <= 2e-5 * float(rec["val/loss_ae"])
+    for p in image_dict:
+        nrow, padding, pad_value = rec["p%d/grid_args" % p]
+        want = make_grid(torch.from_numpy(rec["p%d/grid_input" % p]), int(nrow), padding=int(padding), pad_value=float(pad_value)).numpy()
+        got = res["synthesized_vols"][p]
+        assert got.shape == want.shape == (1, 7 * 34 + 2, int(nrow) * 34 + 2)
+        assert np.abs(got - want).max() < 1e-5
+        assert np.all(np.asarray(res["alphas"][p]) == 0.5) and tuple(res["alphas"][p].shape) == tuple(rec["p%d/alphas" % p].shape)
+    # a frame beyond the last one means the last one (evaluate_image.py:50-51)
+    vols, _ = tr._generate_val_volumes({3: image_dict[3]}, frame_id=8)
+    assert vols[3].shape == res["synthesized_vols"][3].shape
+    tr.end_epoch_processing(epoch=4, val_result_dict=res)
+    try:
+        import matplotlib  # noqa: F401
+        assert os.path.isfile(tmp_path / "val_image_e004_p003.png") and os.path.isfile(tmp_path / "val_image_e004_p017.png")
+        assert os.path.isfile(tmp_path / "val_recons_e004.png")
+    except ImportError:
+        pass
+
+
 def test_plain_ae_and_reconstruction_lpips(tmp_path):
     from superresolution_aniso_mri_amd.data_synth import synthetic_batch
     from superresolution_aniso_mri_amd.kwatsch.get_trainer import get_trainer_dynamic

@@ -216,6 +216,21 @@ def test_supervolume_eval_protocol(tag):
     assert np.array_equal(alphas.numpy(), rec[tag + "/pred_alphas_first"])
 
 
+def test_validation_volume_previews():
+    """oracle restatement of ``_generate_val_volumes`` -> ``evaluate_image`` -> ``create_compare_image`` (kwatsch/base_trainer.py:149-162,
+    evaluate/evaluate_image.py:37-106) against what the reference's OWN trainer returned from ``validate(image_dict=...)`` on two in-memory
+    4-D patients (tests/golden/val_volumes.npz, oracle/make_golden.py:gen_val_volumes): the tensor it hands to make_grid and its nrow."""
+    rec = _load("val_volumes.npz")
+    ae = ae_oracle.OracleAE(SMALL, init=False).load_state_dict(_sd(rec, "p/"))
+    for p in rec["patients"]:
+        orig, synth, stack, k = step_oracle.val_volume_compare(ae, rec["p%d/image4d" % p], int(rec["frame_id"]), SMALL["width"])
+        np.testing.assert_array_equal(orig, rec["p%d/orig" % p])
+        np.testing.assert_allclose(synth, rec["p%d/synth" % p], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(stack, rec["p%d/grid_input" % p], rtol=1e-5, atol=2e-6)
+        assert [k, 2, 0.5] == list(rec["p%d/grid_args" % p])
+        assert np.all(rec["p%d/alphas" % p] == 0.5)
+
+
 @pytest.mark.parametrize("tag", ["acai_combined", "acai"])
 def test_acai_step_oracle_vs_reference_modules(tag):
     """oracle/step_oracle.OracleACAIStep (kwatsch/trainer_acai.py:46-127) against the step restated around the reference's own
