@@ -119,6 +119,10 @@ class AEBaseTrainer(BaseTrainer):
         if g is None:
             if hasattr(self.model, "ensure_bn_barriers"):
                 self.model.ensure_bn_barriers()         # state the captured kernels own: born outside the graph's memory pool
+            # the weight-preparation launch must be a node of EVERY captured step: an eager pass since the last optimizer step (a
+            # validate() right before the capture) leaves the packed operands fresh, the capture would then record no preparation at all and
+            # every replay would run on the filters of the capture step
+            self._replayed()
             # a "_persistent" batch (data_device.TripletAugmenter: one output buffer that every batch is written into) IS the static input:
             # later batches arrive at the same addresses and nothing is copied
             adopt = bool(dev_batch.get("_persistent"))
