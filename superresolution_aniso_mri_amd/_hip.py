@@ -12,6 +12,12 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaesr_hip.so")
+if os.environ.get("AESR_LIB"):
+    # experiments only (scripts/r05_variants.py): a variant build of the library is loaded INSTEAD of the shipped one -- the shipped file
+    # is never overwritten by an A/B script -- and every process that does so says it on stderr
+    import sys as _sys
+    LIB_PATH = os.path.abspath(os.environ["AESR_LIB"])
+    _sys.stderr.write("[aesr] AESR_LIB: loading the VARIANT library %s (not the shipped libaesr_hip.so)\n" % LIB_PATH)
 
 P = c_void_p          # device pointer
 IP = ctypes.POINTER(c_int)

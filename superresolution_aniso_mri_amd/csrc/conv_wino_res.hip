@@ -32,6 +32,23 @@
 
 #include "aesr_kernels.h"
 
+// experiment switches (scripts/r05_variants.py builds variant libraries with -D...; the shipped build leaves them at their defaults)
+#ifndef WR_EXP_PRIO
+#define WR_EXP_PRIO 0       // s_setprio value OUTSIDE the MFMA runs (patch wait, LDS reads, DMA issue, row transform, epilogue); 0 = never touched
+#endif
+#ifndef WR_EXP_PRIO_MFMA
+#define WR_EXP_PRIO_MFMA 0  // s_setprio value INSIDE the MFMA runs
+#endif
+#ifndef WR_EXP_STAGGER
+#define WR_EXP_STAGGER 0    // wave w starts its items w * WR_EXP_STAGGER * 64 cycles behind the prologue barrier
+#endif
+#ifndef WR_EXP_PAIR
+#define WR_EXP_PAIR 1       // 16-cout workgroups: MFMAs of two positions interleaved (a lone accumulator chain waits 40 cycles per MFMA, not 32)
+#endif
+#ifndef WR_EXP_SPLITPRO
+#define WR_EXP_SPLITPRO 0   // prologue: start on filter chunk 0 + first patch, meet again for the rest of the filter before chunk 1
+#endif
+
 constexpr int WR_NT = 512;          // threads per workgroup: 8 independent waves, 2 per SIMD
 // TN = output channels of a workgroup: 32 (K side <= 32 channels: <= 64 KB of filter) or 16 (K side <= 64 channels: 64 KB)
 constexpr int WR_RP = 260;          // floats between patch rows: 16 pixel slots x 16 channels + 4 (shifts a row by one 16-byte bank group)
@@ -101,14 +118,17 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
     float bias_v = 0.f;
     if (tid < WR_TN && a.bias && co0 + tid < a.Cout) bias_v = a.bias[co0 + tid];
     // packed layout [chunk][32-cout tile][position][ci / 4][32 couts][4]: a 16-cout workgroup takes one half of every 32-cout row
-    for (int cc = 0; cc < nchunks; ++cc) {
+    auto filter_chunk = [&](int cc) {
         const int wbase = (int)(((size_t)cc * (a.CoutP / 32) + (co0 >> 5)) * (8192 * 4)) + ((co0 >> 4) & 1) * (WR_TN == 16 ? 256 : 0);
 #pragma unroll
         for (int j = 0; j < WR_WFL / 4 / WR_NT; ++j) {
             const int pc = tid + WR_NT * j;                        // 16-byte piece -> (row of TN couts x 4, piece in the row)
             wr_dma(rs_w, ldsW + cc * WR_WFL + j * (WR_NT * 4) + wave * 256, wbase + ((pc / WR_TN) * 128 + (pc % WR_TN) * 4) * 4);
         }
-    }
+    };
+    // (WR_EXP_SPLITPRO: only chunk 0 of the filter stands in front of the first patch; the rest is requested behind it and met at a second
+    // barrier in front of the first chunk-1 MFMAs, so the first 128 MFMAs of every wave run while 32 KB of filter are still on their way)
+    for (int cc = 0; cc < (WR_EXP_SPLITPRO ? 1 : nchunks); ++cc) filter_chunk(cc);
 
     // ---- per-lane maps ----
     // DMA: lane -> pixel slot lane >> 2 of a patch row, channel quad (lane & 3) ^ ((slot >> 2) & 1)
@@ -154,10 +174,30 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
         fetch(item, 0);
     }
     WR_STAMP(1)
+    bool second_barrier = false;            // uniform over the workgroup
+    if constexpr (WR_EXP_SPLITPRO) {
+        for (int cc = 1; cc < nchunks; ++cc) filter_chunk(cc);
+        second_barrier = nchunks > 1;
+    }
     if (tid < WR_TN) ldsBias[tid] = bias_v;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // explicit: this wave's share of the filter DMAs has landed before it arrives
-    __syncthreads();            // U and bias are in LDS (every wave waited for its own part); the only barrier of the kernel
+    if constexpr (WR_EXP_SPLITPRO) {
+        // all but this wave's (nchunks - 1) * WR_WFL / 4 / WR_NT youngest DMAs: chunk 0 of the filter and the first patch
+        constexpr int PER = WR_WFL / 4 / WR_NT;
+        switch (nchunks) {
+            case 1: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory"); break;
+        }
+        if (nchunks > 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // explicit: this wave's share of the filter DMAs has landed before it arrives
+    }
+    __syncthreads();            // U (chunk 0 at least) and bias are in LDS (every wave waited for its own part)
     WR_STAMP(2)
+    if constexpr (WR_EXP_STAGGER > 0) {
+        for (int k = 0; k < wave; ++k) __builtin_amdgcn_s_sleep(WR_EXP_STAGGER);
+    }
 
     f32x4 acc[16][WR_NB];
     int cc = 0;
@@ -165,8 +205,15 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
     while (item < a.nblk) {
         // ---- the 4x4 input pixels of this lane's tile, 4 channels each ----
         // the DMAs of this patch are the oldest outstanding memory operations; the previous item's stores may still be in flight
+        if constexpr (WR_EXP_PRIO != WR_EXP_PRIO_MFMA) __builtin_amdgcn_s_setprio(WR_EXP_PRIO);
         if (after_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * WR_NB) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (WR_EXP_SPLITPRO) {
+            if (second_barrier && cc == 1) {        // first item only; vmcnt(0) above: this wave's share of the later filter chunks has landed
+                __syncthreads();
+                second_barrier = false;
+            }
+        }
         if constexpr (STAMP) {
             if (stamped_items == 0 && cc < 4) stamp[3 + 2 * cc] = __builtin_amdgcn_s_memrealtime();
         }
@@ -176,9 +223,14 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) t[i][j] = *(const f32x4*)(ldsP + (j < 2 ? offA : offB) + i * WR_RP + j * 16);
         const float* wb = wbl + cc * WR_WFL;
-        f32x4 wnx[WR_NB];
+        // PP positions per MFMA group: with ONE accumulator register set per position (16-cout workgroups) the four MFMAs of a position
+        // form a dependent chain -- 40 cycles each instead of the 32 of independent ones -- so two positions are interleaved there
+        constexpr int PP = (WR_NB == 1 && WR_EXP_PAIR) ? 2 : 1;
+        f32x4 wnx[PP][WR_NB];
 #pragma unroll
-        for (int nb = 0; nb < WR_NB; ++nb) wnx[nb] = *(const f32x4*)(wb + nb * 64);
+        for (int pp = 0; pp < PP; ++pp)
+#pragma unroll
+            for (int nb = 0; nb < WR_NB; ++nb) wnx[pp][nb] = *(const f32x4*)(wb + pp * (4 * WR_TN * 4) + nb * 64);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // the patch is in registers: request the next one (next chunk, or chunk 0 of the next item) into the same buffer
         const int cur_item = item, cur_n = in_n, cur_y0 = in_y0, cur_x0 = in_x0;
@@ -207,34 +259,43 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
 #define WR_V(i, j) ((j) == 0 ? aesr_sub4(t[i][0], t[i][2]) : (j) == 1 ? t[i][1] + t[i][2] : (j) == 2 ? aesr_sub4(t[i][2], t[i][1]) : aesr_sub4(t[i][1], t[i][3]))
         auto positions = [&](auto firstc) {
             constexpr bool FIRST = decltype(firstc)::value;
-            f32x4 vnx = WR_V(0, 0);
+            f32x4 vnx[PP];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int pp = 0; pp < PP; ++pp) vnx[pp] = WR_V(pp >> 2, pp & 3);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int xi = i * 4 + j;
-                    f32x4 wc[WR_NB];
+            for (int grp = 0; grp < 16 / PP; ++grp) {
+                f32x4 wc[PP][WR_NB], vc[PP];
 #pragma unroll
-                    for (int nb = 0; nb < WR_NB; ++nb) wc[nb] = wnx[nb];
-                    const f32x4 vc = vnx;
-                    if (xi + 1 < 16) {
+                for (int pp = 0; pp < PP; ++pp) {
+                    vc[pp] = vnx[pp];
 #pragma unroll
-                        for (int nb = 0; nb < WR_NB; ++nb) wnx[nb] = *(const f32x4*)(wb + (xi + 1) * (4 * WR_TN * 4) + nb * 64);
-                        vnx = WR_V((xi + 1) >> 2, (xi + 1) & 3);
+                    for (int nb = 0; nb < WR_NB; ++nb) wc[pp][nb] = wnx[pp][nb];
+                }
+                if (grp + 1 < 16 / PP) {
+#pragma unroll
+                    for (int pp = 0; pp < PP; ++pp) {
+                        const int xn = (grp + 1) * PP + pp;
+#pragma unroll
+                        for (int nb = 0; nb < WR_NB; ++nb) wnx[pp][nb] = *(const f32x4*)(wb + xn * (4 * WR_TN * 4) + nb * 64);
+                        vnx[pp] = WR_V(xn >> 2, xn & 3);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int pp = 0; pp < PP; ++pp)
 #pragma unroll
                         for (int nb = 0; nb < WR_NB; ++nb) {
+                            const int xi = grp * PP + pp;
                             f32x4 c = acc[xi][nb];
                             if (FIRST && r == 0) c = xi == 5 ? *(const f32x4*)(ldsBias + nb * 16 + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                            acc[xi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nb][r], vc[r], c, 0, 0, 0);
+                            acc[xi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[pp][nb][r], vc[pp][r], c, 0, 0, 0);
                         }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
+        if constexpr (WR_EXP_PRIO != WR_EXP_PRIO_MFMA) __builtin_amdgcn_s_setprio(WR_EXP_PRIO_MFMA);
         if (cc == 0) positions(std::true_type{});
         else positions(std::false_type{});
 #undef WR_V
@@ -328,6 +389,9 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
         if constexpr (STAMP) ++stamped_items;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no DMA may still be writing this workgroup's LDS when it is released
+    if constexpr (WR_EXP_SPLITPRO) {
+        if (second_barrier) __syncthreads();        // a wave without items still owes the others its share of the filter
+    }
     if constexpr (STAMP) {
         stamp[12] = __builtin_amdgcn_s_memrealtime();
         stamp[13] = (unsigned long long)stamped_items;

@@ -70,6 +70,18 @@ def bn_fused_enabled():
     return os.environ.get("AESR_BN_FUSED", "1") != "0"
 
 
+def bn_fused_pays(N, H, W, C):
+    """Single process: the one-launch form only where it is not a loss.  It removes two launches and the second read of the layer, but its
+    256 workgroups x 512 threads stream a layer at 1.7-1.8 TB/s where the three launches reach 4-5: at 12 triplets it LOSES 15 us per C2
+    step and 15-20 us per C3 step (profiles/r05_bn_fused_ab.txt: same box, three alternating rounds), at 6 triplets 9 us; at 3 triplets
+    it wins 5 us, below that nothing either way (profiles/r05_bn_fused_threshold.txt).  Default: calls of at most 9 images
+    (AESR_BN_FUSED_MAX_IMAGES; AESR_BN_FUSED_MAX_MB bounds the layer's bytes for experiments).  The opt-in peer exchange
+    (AESR_SYNCBN=p2p) needs the kernel and keeps its own rule (_p2p_fits)."""
+    if N > int(os.environ.get("AESR_BN_FUSED_MAX_IMAGES", "9")):
+        return False
+    return float(N) * H * W * C * 4.0 <= float(os.environ.get("AESR_BN_FUSED_MAX_MB", "1000")) * 1e6
+
+
 def wino_ok(cin, cout, ks, pad, transpose):
     return bool(USE_WINO and lib.aesr_conv2d_wino_supported(int(cin), int(cout), int(ks), int(pad), int(transpose)))
 
@@ -562,7 +574,7 @@ class SequentialRunner:
             partial = torch.empty((G * _hip.BN_NWG * 2 * C,), device=dev, dtype=torch.float32)
             counts = [float((nstart[g + 1] - nstart[g]) * H * W) * self.count_scale for g in range(G)]   # host values
             st["counts"] = counts
-            if (self.sync_bn is None and out is not None and bn_fused_enabled()
+            if (self.sync_bn is None and out is not None and bn_fused_enabled() and bn_fused_pays(N, H, W, C)
                     and lib.aesr_bn_fused1_supported(N, H, W, C, run_mode, G, 0)):
                 # small batch: statistics, finalize and apply in ONE launch, the layer resident in LDS in between
                 ws = torch.empty((lib.aesr_bn_fused1_workspace_floats(C, G),), device=dev, dtype=torch.float32)
@@ -792,7 +804,8 @@ class SequentialRunner:
                 coef = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
                 dgamma, dbeta = self._grad_dst(s.mod.weight, grads), self._grad_dst(s.mod.bias, grads)
                 dpre = _empty((N, H, W, C), y)
-                if self.sync_bn is None and bn_fused_enabled() and lib.aesr_bn_fused1_supported(N, H, W, C, s.run_mode, G, 1):
+                if (self.sync_bn is None and bn_fused_enabled() and bn_fused_pays(N, H, W, C)
+                        and lib.aesr_bn_fused1_supported(N, H, W, C, s.run_mode, G, 1)):
                     ws = torch.empty((lib.aesr_bn_fused1_workspace_floats(C, G),), device=dev, dtype=torch.float32)
                     check(lib.aesr_bn_fused1_bwd(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(ws),
                                                  ptr(self._bn_barrier(dev)), _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma), ptr(dbeta),
