@@ -400,6 +400,40 @@ def e2e_bench(device, steps=300, warmup=20):
         del trainer, pool
         torch.cuda.empty_cache()
     out["e2e_over_resident"] = round(out["volume_cache"]["slices_per_s"] / out["resident_batch"]["slices_per_s"], 4)
+    out["reading"] = ("host_batch_us_idle_device = what the host spends on a batch (RandomState draws + descriptors + one launch) with nothing queued; "
+                      "host_batch_us_in_loop and host_enqueue_ms_per_step are WAITING times: the host runs ahead of the device until the launch queue "
+                      "pushes back, so inside the loop they approach the device's step time whatever the host cost is")
+    # the budget of ONE RANK of the 8-rank run (rank 1 of 8: 2 of the 12 triplets): the host draws the random numbers of ALL 12 triplets (every
+    # rank keeps the single-process stream position), assembles its own 2 and replays the 2-triplet captured step -- the host side of a batch
+    # has to fit into a 0.85 ms step
+    Br = 2
+    for _ in range(5):
+        aug.next_batch(B, step=2, reuse_output=True, shard=(1, 8))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        aug.next_batch(B, step=2, reuse_output=True, shard=(1, 8))
+    rank = {"host_batch_us_idle_device": round(1e4 * (time.perf_counter() - t0), 1)}
+    torch.cuda.synchronize()
+    for name, from_cache in (("resident_batch", False), ("volume_cache", True)):
+        trainer, pool = make_trainer("c2", device, Br, 160, npool=1)
+        def rloop(n):
+            for _ in range(n):
+                trainer.train(aug.next_batch(B, step=2, reuse_output=True, shard=(1, 8)) if from_cache else pool[0], keep_predictions=False)
+        rloop(warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rloop(steps)
+        t_enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rank[name] = {"ms_per_step": round(1e3 * dt / steps, 3), "host_enqueue_ms_per_step": round(1e3 * t_enq / steps, 3)}
+        del trainer, pool
+        torch.cuda.empty_cache()
+    rank["e2e_over_resident"] = round(rank["resident_batch"]["ms_per_step"] / rank["volume_cache"]["ms_per_step"], 4)
+    rank["workload"] = ("one rank of 8 (single process, no collectives): per step the draws of all 12 triplets, one assemble launch over its own 2, "
+                        "the replayed 2-triplet step; %d steps" % steps)
+    out["rank_of_8"] = rank
     out["workload"] = ("train_aesr.py's loop at configs[1]: %d steps, TripletAugmenter (host RandomState draws in the reference's order + one assemble "
                        "launch per batch) over a synthetic device-resident cache of 60 volumes 10x216x256 -> captured step" % steps)
     return out

@@ -83,7 +83,9 @@ __device__ __forceinline__ void bf_grid_barrier(unsigned* bar, int nb) {
             int spins = 0;
             while (__hip_atomic_load(bar + GB_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > BF_SPIN_LIMIT) {
+                // a wait gives up after BF_SPIN_LIMIT polls (counted; the host raises) -- and, once ANY wait of this process has given up, after
+                // 1 024: the results are lost already, the remaining launches of the step must not each spin for seconds on top
+                if (++spins > BF_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(&g_bn_fused_timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                     atomicAdd(&g_bn_fused_timeouts, 1u);
                     break;
                 }
@@ -183,7 +185,7 @@ __device__ __forceinline__ void bf_totals(const float* __restrict__ rec, int GC2
 // records in rank order (fixed order: the same bits on every rank).  Producers never wait for consumers: a rank reaches slot k of step
 // t + 1 only behind the gradient all-reduce of step t, which every rank enters after it has consumed all slots of step t.
 #define P2P_REC (512 * 8 + 128)
-#define P2P_SPIN_LIMIT (1 << 23)
+#define P2P_SPIN_LIMIT (1 << 21)          // ~7 s at 3.5 us per poll (round 4: 1 << 23 = 30 s per call, 16 calls per step; AESR_P2P_SPINS overrides)
 __device__ __forceinline__ void bf_exchange(const BnFusedArgs& a, int GC2, double* totd) {
     const int tid = threadIdx.x, W = a.world;
     const unsigned gen = *a.gen;
@@ -207,7 +209,9 @@ __device__ __forceinline__ void bf_exchange(const BnFusedArgs& a, int GC2, doubl
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != gen) {
             if (spins < 4096) __builtin_amdgcn_s_sleep(4);
             else __builtin_amdgcn_s_sleep(127);
-            if (++spins > a.p2p_spins) {               // a peer that never arrives: give up (counted; the host raises), never hang
+            // a peer that never arrives: give up (counted; the host raises), never hang; after the FIRST give-up of this process every
+            // later exchange gives up within 1 024 polls (the step runs on partial sums already; _bounded_sync ends the rank on the host)
+            if (++spins > a.p2p_spins || ((spins & 1023) == 0 && __hip_atomic_load(&g_bn_fused_timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                 atomicAdd(&g_bn_fused_timeouts, 1u);
                 break;
             }
@@ -558,7 +562,7 @@ int aesr_bn_fused_run(const float* y, const float* gout, float* out, float* rec,
 __global__ void p2p_tick_kernel(unsigned* gen) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         unsigned g = *gen + 1u;
-        if (g == 0u) g = 1u;          // 0 is the "never written" value of the flags
+        if (g == 0u) g = 2u;          // 0 is the "never written" value of the flags; 2 keeps the slot parity alternating across the wrap (... 0xffffffff, 2, 3 ...)
         *gen = g;
     }
 }

@@ -198,9 +198,12 @@ class TripletAugmenter:
         half = torch.full((B, 1), 0.5, device=self.device, dtype=torch.float32)
         return {"image": image, "slice_between": between, "alpha_from": half, "alpha_to": half.clone()}
 
-    def next_batch(self, B, step=2, reuse_output=False):
+    def next_batch(self, B, step=2, reuse_output=False, shard=None):
         """A random training batch: B random (volume, slice) pairs, neighbours ``step`` apart.  ``reuse_output``: the batch is written
-        into this augmenter's persistent output buffer (valid until the next call) -- what the training loop uses."""
+        into this augmenter's persistent output buffer (valid until the next call) -- what the training loop uses.  ``shard`` = (rank,
+        world): data parallel -- EVERY random number of the global batch is drawn (all ranks keep the same stream position and see the
+        batch a single process would see), but only this rank's triplets [B r / W, B (r + 1) / W) are assembled: the host cost of a
+        rank is the global batch's draws plus its own few descriptors, the device cost one launch over its own triplets."""
         trips = []
         for _ in range(B):
             vid = int(self.rs.randint(0, len(self.shapes)))
@@ -210,4 +213,9 @@ class TripletAugmenter:
             sid = int(self.rs.randint(0, Z))
             zf, zt, zb = self.draw_triplet(vid, sid, step)
             trips.append((vid, zf, zt, zb))
-        return self.assemble(trips, reuse_output=reuse_output)
+        if shard is None:
+            return self.assemble(trips, reuse_output=reuse_output)
+        rank, world = int(shard[0]), int(shard[1])
+        transforms = [self.draw_transform(t[0]) for t in trips]         # the order assemble() draws them in
+        lo, hi = (B * rank) // world, (B * (rank + 1)) // world
+        return self.assemble(trips[lo:hi], transforms[lo:hi], reuse_output=reuse_output)

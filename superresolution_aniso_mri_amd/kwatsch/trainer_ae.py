@@ -76,6 +76,7 @@ class AEBaseTrainer(BaseTrainer):
             self.dp.step_fence()                 # no gradient all-reduce in this step: keep the ranks in step for the peer exchange
         if self.opt_sched_ae is not None:
             self.opt_sched_ae.step()
+        self._poll_watchdogs()
 
     # ---- HIP-graph capture of the whole step (forward, backward, Adam) ---------------------------------------------
     def enable_step_graph(self, eager_steps=3, dp_segments=False, dp_mode=None):
@@ -167,6 +168,17 @@ class AEBaseTrainer(BaseTrainer):
         graph.replay()
         self._replayed()
         self._log_sink(sink)
+        self._poll_watchdogs()
+
+    WATCHDOG_EVERY = 512        # steps between two polls of the kernel-side watchdogs (a poll reads a device symbol: it syncs)
+
+    def _poll_watchdogs(self):
+        """Round-4 advice: a grid barrier / peer wait that gave up lets the step run on garbage; validate(), the epoch log and the
+        checkpoints refuse to go on, but an epoch can be thousands of steps long -- so the step itself looks every WATCHDOG_EVERY
+        iterations (one device sync per ~1 s of training at 2 ms per step)."""
+        if (self._iters % self.WATCHDOG_EVERY) == 0 and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            from .base_trainer import _check_watchdogs
+            _check_watchdogs(self, "train step %d" % self._iters)
 
     def _replayed(self):
         """A replay rewrote the parameters, the BatchNorm running statistics and (one step behind) the packed operands through raw

@@ -179,6 +179,15 @@ class DataParallelContext(object):
         if self.syncbn not in ("rccl", "p2p"):
             raise ValueError("AESR_SYNCBN must be 'rccl' or 'p2p', got %r" % (self.syncbn,))
         self.p2p = None
+        if self.world > 1 and os.environ.get("AESR_SINGLE_DEVICE") == "1":
+            # several ranks REHEARSED on one device: the one-launch BatchNorm kernels of all ranks must be resident TOGETHER (their grid
+            # barriers and peer waits would otherwise spin until they give up): 256 / world workgroups each, or the three-launch form
+            if self.world <= 4:
+                os.environ.setdefault("AESR_BN_FUSED_NB", "128" if self.world == 2 else "64")
+            elif os.environ.get("AESR_BN_FUSED", "1") != "0":
+                if self.syncbn == "p2p":
+                    raise ValueError("AESR_SYNCBN=p2p with %d ranks on ONE device: their one-launch BatchNorm kernels cannot all be resident" % self.world)
+                os.environ["AESR_BN_FUSED"] = "0"
 
     @property
     def active(self):

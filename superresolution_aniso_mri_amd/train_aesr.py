@@ -91,9 +91,10 @@ def main(argv=None, brain=False):
 
     def make_batch(seed, n, training=True):
         if augmenter is not None:
-            # training batches go into the augmenter's persistent output buffer, which the captured step reads directly; the validation
-            # batch is kept for the whole run and gets tensors of its own
-            b = augmenter.next_batch(n, step=step, reuse_output=training and not dp.active)
+            # training batches go into the augmenter's persistent output buffer, which the captured step reads directly (data parallel: the
+            # rank's own triplets only -- every rank draws the whole global batch's random numbers); the validation batch is kept for the
+            # whole run and gets tensors of its own
+            return augmenter.next_batch(n, step=step, reuse_output=training, shard=(dp.rank, dp.world) if dp.active else None)
         elif training:
             key = (n, int(seed) % max(1, int(args_dict.get("synthetic_pool") or 8)))
             if key not in synth_pool:

@@ -70,3 +70,27 @@ def test_assembled_batch_trains():
     for _ in range(3):
         tr.train(ta.next_batch(4), keep_predictions=False)
     assert np.isfinite(tr.losses["loss_ae"][-1])
+
+
+def test_rank_shards_of_a_batch_are_the_single_process_batch():
+    """Data parallel (train_aesr.py --volumes_dir under torch.distributed.run): every rank draws the WHOLE global batch's random numbers and
+    assembles only its own triplets -- the shards, put side by side, are bit for bit the batch a single process assembles from the same
+    RandomState, for uneven shards too (12 triplets over 8 ranks: 1,2,1,2,...), and every augmenter ends at the same stream position."""
+    from superresolution_aniso_mri_amd.data_device import TripletAugmenter
+    g = np.random.RandomState(9)
+    vols = [g.rand(9, 70, 64).astype(np.float32), g.rand(12, 40, 90).astype(np.float32), g.rand(7, 48, 48).astype(np.float32)]
+    for B, world in ((12, 8), (5, 2), (4, 4)):
+        whole = TripletAugmenter(vols, width=32, aug_patch_size=48, rs=np.random.RandomState(31))
+        for _ in range(2):
+            want = whole.next_batch(B, step=2)
+        pos = whole.rs.randint(0, 1 << 30)
+        frm, to, btw = [], [], []
+        for r in range(world):
+            ta = TripletAugmenter(vols, width=32, aug_patch_size=48, rs=np.random.RandomState(31))
+            ta.next_batch(B, step=2, shard=(r, world), reuse_output=True)
+            got = ta.next_batch(B, step=2, shard=(r, world), reuse_output=True)        # the persistent buffer, written a second time
+            n = (B * (r + 1)) // world - (B * r) // world
+            assert tuple(got["image"].shape) == (2 * n, 1, 32, 32) and got["_persistent"]
+            frm.append(got["image"][:n].clone()), to.append(got["image"][n:].clone()), btw.append(got["slice_between"].clone())
+            assert ta.rs.randint(0, 1 << 30) == pos
+        assert torch.equal(torch.cat(frm + to), want["image"]) and torch.equal(torch.cat(btw), want["slice_between"])
