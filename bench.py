@@ -225,21 +225,26 @@ def roofline_of(engine, device, nst, config, B, H, gpus, scales3=False):
          "ms_per_step": round(v["ms"] / nst, 3), "launches_per_step": v["launches"] // nst}
         for n, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]) if n != kname and n in MFMA_KINDS and v["launches"]]
     # HBM-side bytes per launch of the same kernel: PMC counters cannot be read from inside this process; they come from the
-    # committed rocprofv3 --pmc passes of this very command (scripts/profile_all.sh -> profiles/), N=1 and B=12 only, and only
+    # committed rocprofv3 --pmc passes of this very command (scripts/profile_all.sh -> profiles/rNN_<cfg>_hbm_traffic.json), N=1 and B=12 only, and only
     # while the kernel sources are the ones the passes were measured on
-    tpath = os.path.join(ROOT, "profiles", "r04_%s_hbm_traffic.json" % config)
-    if gpus == 1 and B == 12 and os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("csrc_sha") == csrc_sha():
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_hbm_traffic.json" % config)), reverse=True)      # newest round first
+    if gpus == 1 and B == 12 and cands:
+        sha = csrc_sha()
+        for tpath in cands:
+            tj = json.load(open(tpath))
+            if tj.get("csrc_sha") != sha:
+                continue
             ig = [v for name, v in tj["kernels"].items() if (kname + "<") in name or (kname + "(") in name]
             nl = sum(v["launches_per_step"] for v in ig)
             if nl > 0:
                 roofline["traffic"] = round(sum(v["MB_per_step"] for v in ig) / nl * 1e6)
-                roofline["traffic_unit"] = ("bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r04_%s_hbm_traffic.json, "
-                                            "kernel sources %s)" % (config, tj["csrc_sha"]))
+                roofline["traffic_unit"] = ("bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/%s, kernel sources %s)"
+                                            % (os.path.basename(tpath), tj["csrc_sha"]))
+            break
         else:
-            roofline["traffic_note"] = "profiles/r04_%s_hbm_traffic.json was measured on other kernel sources (%s, now %s): not quoted" % (
-                config, tj.get("csrc_sha"), csrc_sha())
+            roofline["traffic_note"] = "%s was measured on other kernel sources (%s, now %s): not quoted" % (
+                os.path.basename(cands[0]), json.load(open(cands[0])).get("csrc_sha"), sha)
     return roofline
 
 
