@@ -45,6 +45,9 @@
 #ifndef WR_EXP_PAIR
 #define WR_EXP_PAIR 1       // 16-cout workgroups: MFMAs of two positions interleaved (a lone accumulator chain waits 40 cycles per MFMA, not 32)
 #endif
+#ifndef WR_ABL
+#define WR_ABL 0            // timing-only ablations (WRONG results): 1 epilogue without its stores, 2 epilogue stores raw accumulators (no transform / activation)
+#endif
 #ifndef WR_EXP_SPLITPRO
 #define WR_EXP_SPLITPRO 0   // prologue: start on filter chunk 0 + first patch, meet again for the rest of the filter before chunk 1
 #endif
@@ -370,7 +373,13 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
                             if (a.post_pool) prow = q == 0 ? o : prow + o;
                             else wr_st(rs_out, ob[p][q] + cob, o * psc + psh);              // bn.hip bn_apply: v * scale + shift
                         } else {
+#if WR_ABL == 1
+                            if (a.slope == 12345.f) wr_st(rs_out, ob[p][q] + cob, o);          // never true: the arithmetic stays, the store does not issue
+#elif WR_ABL == 2
+                            wr_st(rs_out, ob[p][q] + cob, acc[p * 2 + q][nb]);
+#else
                             wr_st(rs_out, ob[p][q] + cob, o);
+#endif
                         }
                     }
                     if (POST && a.post_pool) pm = p == 0 ? prow : pm + prow;
