@@ -225,7 +225,7 @@ def roofline_of(engine, device, nst, config, B, H, gpus, scales3=False):
          "ms_per_step": round(v["ms"] / nst, 3), "launches_per_step": v["launches"] // nst}
         for n, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]) if n != kname and n in MFMA_KINDS and v["launches"]]
     # HBM-side bytes per launch of the same kernel: PMC counters cannot be read from inside this process; they come from the
-    # committed rocprofv3 --pmc passes of this very command (scripts/profile_all.sh -> profiles/rNN_<cfg>_hbm_traffic.json), N=1 and B=12 only, and only
+    # committed rocprofv3 --pmc passes of this very command (scripts/round_profiles.sh -> profiles/rNN_<cfg>_hbm_traffic.json), N=1 and B=12 only, and only
     # while the kernel sources are the ones the passes were measured on
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_hbm_traffic.json" % config)), reverse=True)      # newest round first

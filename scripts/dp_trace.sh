@@ -1,12 +1,12 @@
 #!/bin/bash
-OUT=$GRAFT_REPO_ROOT/gpurun_out
+# Kernel sequence of ONE RANK's replayed data-parallel step at 2 triplets (communicator of one) in both SyncBN exchange forms
 cd /tmp && export TMPDIR=/tmp
-for MODE in none whole; do
-  if [ $MODE = none ]; then unset AESR_FORCE_DP AESR_DP_GRAPH; else export AESR_FORCE_DP=1 AESR_DP_GRAPH=$MODE; fi
-  rm -rf /tmp/dpt_$MODE
-  rocprofv3 --kernel-trace -d /tmp/dpt_$MODE -o res -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 4 --config c3 --triplets 2 --no-cpu-baseline --no-roofline --no-secondary > /dev/null 2>&1
-  DB=$(find /tmp/dpt_$MODE -name "*.db" | head -1)
-  python3 $GRAFT_REPO_ROOT/scripts/kstats.py $DB 12 > $OUT/dpt_${MODE}_stats.txt
-  python3 $GRAFT_REPO_ROOT/scripts/kseq_last.py $DB > $OUT/dpt_${MODE}_seq.txt
-  tail -1 $OUT/dpt_${MODE}_seq.txt; head -1 $OUT/dpt_${MODE}_stats.txt
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+for S in rccl p2p; do
+  rm -rf /tmp/dpt_$S
+  AESR_FORCE_DP=1 AESR_SYNCBN=$S rocprofv3 --kernel-trace -d /tmp/dpt_$S -o res -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 4 --triplets 2 --no-cpu-baseline --no-roofline --no-secondary > $OUT/r04_dp_${S}_bench.json 2> /dev/null
+  DB=$(find /tmp/dpt_$S -name "*.db" | head -1)
+  python3 $GRAFT_REPO_ROOT/scripts/kseq_last.py $DB > $OUT/r04_dp_${S}_kernel_sequence.txt
+  python3 $GRAFT_REPO_ROOT/scripts/kstats_last.py $DB 4 > $OUT/r04_dp_${S}_kernel_stats.txt
+  echo "== SyncBN exchange $S"; head -1 $OUT/r04_dp_${S}_kernel_stats.txt; grep -E "bn_|nccl|rccl|Reduce|p2p_tick|copy" $OUT/r04_dp_${S}_kernel_stats.txt | cut -c1-150
 done

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""bench.py's secondary.e2e leg on its own: r04_e2e.py -> one JSON line."""
+"""bench.py's secondary.e2e leg on its own: e2e_leg.py -> one JSON line."""
 import json
 import os
 import sys

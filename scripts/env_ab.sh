@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of an environment knob at FULL batch (12 triplets): the C2 and C3 step, alternating arms, 3 rounds each
-# usage: r05_env_ab.sh OUTNAME "VAR=a" "VAR=b" ...
+# usage: env_ab.sh OUTNAME "VAR=a" "VAR=b" ...
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$1.txt
 shift

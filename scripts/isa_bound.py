@@ -4,7 +4,7 @@ non-MFMA instruction costs what scripts/micro/mfma_gap.hip measured on gfx950 (p
 32 cycles and NOTHING a wave (or its SIMD partner) issues beside it is free -- a vector ALU instruction 4-5 cycles (4.0-4.3 with one wave per
 SIMD, 4.7-6.5 with two), an LDS-DMA ~63, a 16-byte store ~63 (assumed = DMA), an LDS read ~1, s_waitcnt / s_nop ~2.
 
-    python scripts/r05_isa_bound.py file.s mangled_kernel_name LOOPHEADER      (blocks "in Loop: Header=<LOOPHEADER>" + the header itself)
+    python scripts/isa_bound.py file.s mangled_kernel_name LOOPHEADER      (blocks "in Loop: Header=<LOOPHEADER>" + the header itself)
 """
 import re
 import sys

@@ -3,7 +3,7 @@
 "put the phase stamps on the 6-image layers and commit the per-launch budget"): for the forward layers of the ACDC auto-encoder that this
 kernel serves, at N images -- the time of back-to-back launches (HIP events) and, from ONE stamped launch (AESR_WINO_RES_DBG=1: wall-clock
 stamps of every wave's first item, csrc/conv_wino_res.hip), the span of the kernel on the device and the phases of a busy wave.
-   r04_stamps.py [N ...]"""
+   res_stamps.py [N ...]"""
 import os
 import sys
 

@@ -3,7 +3,7 @@
 round-3 verdict, next 1a): for every 3x3 layer of the ACDC auto-encoder the kernel the planner picks, its time (HIP events around
 back-to-back launches), the MFMA work it executes, and the time the matrix cores need for that work if it were spread evenly over the
 1024 SIMDs ("floor") and as it is actually dealt out -- items per busiest SIMD x MFMAs per item x 32 cycles at 2.1 GHz ("dealt").
-   r04_budget.py [N_fwd N_bwd]"""
+   shard_budget.py [N_fwd N_bwd]"""
 import os
 import sys
 

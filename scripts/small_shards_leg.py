@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""The small-shard table of bench.py (secondary.small_shards) on its own: r04_small.py [tag] -> one JSON line."""
+"""The small-shard table of bench.py (secondary.small_shards) on its own: small_shards_leg.py [tag] -> one JSON line."""
 import json
 import os
 import sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Time ONE Winograd forward layer (HIP events around 10 back-to-back launches, best of 5): r04_time_one.py fwd N H W Cin Cout -> microseconds."""
+"""Time ONE Winograd forward layer (HIP events around 10 back-to-back launches, best of 5): time_one.py fwd N H W Cin Cout -> microseconds."""
 import os
 import sys
 

@@ -3,7 +3,7 @@
 with ONE source recompiled under extra -D flags, linked to csrc/build/variants/libaesr_<name>.so; a process loads it with
 AESR_LIB=<path> (superresolution_aniso_mri_amd/_hip.py says so on stderr).  Run `make -C superresolution_aniso_mri_amd/csrc` first.
 
-    python scripts/r05_variants.py name=file.hip:-DA=1,-DB=2 [name2=...]
+    python scripts/variants.py name=file.hip:-DA=1,-DB=2 [name2=...]
 """
 import os
 import subprocess

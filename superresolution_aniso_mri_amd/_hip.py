@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaesr_hip.so")
 if os.environ.get("AESR_LIB"):
-    # experiments only (scripts/r05_variants.py): a variant build of the library is loaded INSTEAD of the shipped one -- the shipped file
+    # experiments only (scripts/variants.py): a variant build of the library is loaded INSTEAD of the shipped one -- the shipped file
     # is never overwritten by an A/B script -- and every process that does so says it on stderr
     import sys as _sys
     LIB_PATH = os.path.abspath(os.environ["AESR_LIB"])

@@ -32,7 +32,7 @@
 
 #include "aesr_kernels.h"
 
-// experiment switches (scripts/r05_variants.py builds variant libraries with -D...; the shipped build leaves them at their defaults)
+// experiment switches (scripts/variants.py builds variant libraries with -D...; the shipped build leaves them at their defaults)
 #ifndef WR_EXP_PRIO
 #define WR_EXP_PRIO 0       // s_setprio value OUTSIDE the MFMA runs (patch wait, LDS reads, DMA issue, row transform, epilogue); 0 = never touched
 #endif
@@ -511,7 +511,7 @@ static int wino_res_launch_one(const WinoArgs& a, hipStream_t st) {
     int grid = 256 / ncot * ncot;                          // one workgroup per CU, a whole number of them per cout tile
     if (const char* e = getenv("AESR_WINO_GRID")) grid = atoi(e) / ncot * ncot;
     // Few blocks (a small data-parallel shard, the deep layers): at most FOUR per workgroup.  Waves 0..3 of a workgroup sit on the four
-    // SIMDs of its CU (wave i -> SIMD i % 4: measured, scripts/r04_stamps.py), so four one-item waves each have a matrix pipe to themselves;
+    // SIMDs of its CU (wave i -> SIMD i % 4: measured, scripts/res_stamps.py), so four one-item waves each have a matrix pipe to themselves;
     // the round-2 rule packed eight per workgroup and two one-item waves shared every SIMD (2.2 -> 1.5 us per 16-channel chunk at 6 images).
     static const int wpw = getenv("AESR_WINO_RES_WPW") ? atoi(getenv("AESR_WINO_RES_WPW")) : 4;
     const int per_cot = ceil_div(a.nblk, wpw >= 1 && wpw <= 8 ? wpw : 4);
