@@ -204,6 +204,8 @@ static WgradPlan plan_wgrad_wino(int N, int H, int W, int Cin, int Cout) {
         }
     }
     if (const char* e = getenv("AESR_WGRAD_WINO_S")) { const int s_ = atoi(e); if (s_ > 0) p.S = s_; }
+    // experiment knob (round-4 verdict, next 3a): cap the slab count of every layer (fewer, longer-lived workgroups; fewer slabs to sum)
+    if (const char* e = getenv("AESR_WGRAD_WINO_SMAX")) { const int s_ = atoi(e); if (s_ > 0 && p.S > s_) p.S = s_; }
     p.PWS = round_up(p.TW + 2, 4);             // LDS row strides in pixels (conv_wgrad_wino.hip)
     p.TWS = round_up(p.TW, 4);
     p.PSX = p.PSD = 0;
