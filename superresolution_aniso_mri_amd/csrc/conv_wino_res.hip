@@ -45,6 +45,9 @@
 #ifndef WR_EXP_PAIR
 #define WR_EXP_PAIR 1       // 16-cout workgroups: MFMAs of two positions interleaved (a lone accumulator chain waits 40 cycles per MFMA, not 32)
 #endif
+#ifndef WR_DYN
+#define WR_DYN 0            // 1: items of a workgroup dealt to its waves through an LDS counter (measured: +1 % on the biggest layer, -1 % on small ones, step flat)
+#endif
 #ifndef WR_ABL
 #define WR_ABL 0            // timing-only ablations (WRONG results): 1 epilogue without its stores, 2 epilogue stores raw accumulators (no transform / activation)
 #endif
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
     float* const ldsW = lds;                                        // [nchunks][16 positions][4][32][4]
     float* const ldsP = lds + nchunks * WR_WFL + wave * WR_PFL;     // this wave's patch: [10 rows][16 pixel slots][16 ch] (+ pitch)
     float* const ldsBias = lds + nchunks * WR_WFL + 8 * WR_PFL;     // [32]
+    int* const ldsNext = (int*)(ldsBias + 32);                      // the workgroup's next undealt item slot (WR_DYN)
 
     const int sh = a.in_up2 ? 1 : 0;
     const int inH = a.H >> sh, inW = a.W >> sh;                                              // stored size of the input tensor
@@ -151,8 +155,15 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
     // wave 0 of many workgroups, not on all waves of a few)
 #define WR_DIV(x, m) ((m) ? (int)__umulhi((unsigned)(x), (m)) : (int)(x))          /* m == 0: divisor 1 */
     // XCD map: round k, XCD x = blocks [(8 k + x) * 8 nwgc, + 8 nwgc), wave w of worker s takes block w * nwgc + s of them
-    int item = (xmap ? xcd * (8 * nwgc) : 0) + wgc + nwgc * wave;
-    const int istep = (xmap ? 64 : 8) * nwgc;
+    // The workgroup's items in the order they are dealt: slot j -> block; wave w takes slots w, w + 8, ...  The two waves of a SIMD do NOT progress
+    // alike -- the older one (waves 0..3) is served first and ran its equally long list in 74 us where waves 4..7 took 90 (stamps of 32 -> 32 @
+    // 162 x 162 x 36, profiles/r05_res_wave_exit.txt) -- but dealing the slots through an LDS counter (WR_DYN=1: a wave takes the next undealt slot
+    // when it finishes an item) bought only 1 % there and cost 1 % on small layers: the SIMD finishes items at one rate whichever wave owns them; the
+    // younger wave simply runs faster once it is alone.  Slots are monotonic in the block index, so the first slot past the end ends a wave.
+    auto item_of = [&](int j) { return xmap ? xcd * (8 * nwgc) + wgc + nwgc * (j & 7) + 64 * nwgc * (j >> 3) : wgc + nwgc * j; };
+    int item = item_of(wave);
+    [[maybe_unused]] int slot = wave;
+    if (WR_DYN && tid == 0) *ldsNext = 8;                   // visible behind the prologue barrier
     // the patch of (item, chunk) -> this wave's LDS buffer: 10 DMAs; out-of-range rows / columns deliver zeros
     int in_n = 0, in_y0 = 0, in_x0 = 0;
     auto locate = [&](int it) {
@@ -209,6 +220,11 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
         // ---- the 4x4 input pixels of this lane's tile, 4 channels each ----
         // the DMAs of this patch are the oldest outstanding memory operations; the previous item's stores may still be in flight
         if constexpr (WR_EXP_PRIO != WR_EXP_PRIO_MFMA) __builtin_amdgcn_s_setprio(WR_EXP_PRIO);
+        int next_slot = 0;
+        if constexpr (WR_DYN != 0) {
+            // last chunk of the item: ask for the next slot now, one lane, so that the answer returns with the patch reads below
+            if (cc + 1 == nchunks && lane == 0) next_slot = __hip_atomic_fetch_add(ldsNext, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         if (after_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * WR_NB) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (WR_EXP_SPLITPRO) {
@@ -239,7 +255,12 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
         const int cur_item = item, cur_n = in_n, cur_y0 = in_y0, cur_x0 = in_x0;
         const bool last = cc + 1 == nchunks;
         if (last) {
-            item += istep;
+            if constexpr (WR_DYN != 0) {
+                slot = __builtin_amdgcn_readfirstlane(next_slot);
+            } else {
+                slot += 8;
+            }
+            item = item_of(slot);
             if (item < a.nblk) {
                 locate(item);
                 fetch(item, 0);
@@ -425,7 +446,7 @@ static int wino_res_tn(const WinoArgs& a) {
     const double c32 = (double)((nblk * (a.CoutP / 32) + 2047) / 2048), c16 = 0.55 * (double)((nblk * (a.CoutP / 16) + 2047) / 2048);
     return c16 < c32 ? 16 : 32;
 }
-static size_t wino_res_lds_bytes(int CinP, int TN) { return ((size_t)(CinP >> 4) * (256 * TN) + 8 * WR_PFL + 32) * sizeof(float); }
+static size_t wino_res_lds_bytes(int CinP, int TN) { return ((size_t)(CinP >> 4) * (256 * TN) + 8 * WR_PFL + 32 + 4) * sizeof(float); }
 
 bool aesr_wino_res_ok(const WinoArgs& a) {
     // AESR_WINO_RES: 0 = never, 1 = K side <= 32 channels only, unset / 2 = up to 64 channels (16-cout workgroups)
@@ -490,6 +511,23 @@ static int wino_res_stamped(const WinoArgs& b_in, int grid, size_t shmem, hipStr
             grid * 8, items, (double)(t_last - t_first) * 0.01, sum[0] * q, ramp_max * 0.01, sum[1] * q, sum[2] * q);
     for (int c = 0; c < nch; ++c) fprintf(stderr, " chunk %d: wait %.2f work %.2f |", c, sum[3 + 2 * c] * q, sum[4 + 2 * c] * q);
     fprintf(stderr, " epilogue %.2f | rest of the wave %.2f\n", sum[11] * q, sum[12] * q);
+    // do the eight waves of a workgroup (wave w and w + 4 share a SIMD) finish their -- equally long -- item lists at the same time?
+    double ex[8] = {}, ex_min[8], ex_max[8] = {};
+    int nw[8] = {};
+    for (int w = 0; w < 8; ++w) ex_min[w] = 1e30;
+    for (size_t w = 0; w < (size_t)grid * 8; ++w) {
+        const unsigned long long* s_ = &host[w * 16];
+        if (!s_[13]) continue;
+        const double e = (double)(s_[12] - t_first) * 0.01;
+        const int k = (int)(w & 7);
+        ex[k] += e; ++nw[k];
+        if (e < ex_min[k]) ex_min[k] = e;
+        if (e > ex_max[k]) ex_max[k] = e;
+    }
+    fprintf(stderr, "[wino-res stamps] exit of wave w behind the grid's first entry, us (mean [min .. max] over the workgroups):");
+    for (int w = 0; w < 8; ++w)
+        if (nw[w]) fprintf(stderr, "  w%d %.1f [%.1f .. %.1f]", w, ex[w] / nw[w], ex_min[w], ex_max[w]);
+    fprintf(stderr, "\n");
     return AESR_OK;
 }
 
