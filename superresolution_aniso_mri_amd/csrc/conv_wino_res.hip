@@ -48,6 +48,9 @@
 #ifndef WR_DYN
 #define WR_DYN 0            // 1: items of a workgroup dealt to its waves through an LDS counter (measured: +1 % on the biggest layer, -1 % on small ones, step flat)
 #endif
+#ifndef WR_EXP_HALF
+#define WR_EXP_HALF 0       // 1: only waves 0..3 of a workgroup take items (one active wave per SIMD, the same code): what does the second wave buy?
+#endif
 #ifndef WR_ABL
 #define WR_ABL 0            // timing-only ablations (WRONG results): 1 epilogue without its stores, 2 epilogue stores raw accumulators (no transform / activation)
 #endif
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
     auto item_of = [&](int j) { return xmap ? xcd * (8 * nwgc) + wgc + nwgc * (j & 7) + 64 * nwgc * (j >> 3) : wgc + nwgc * j; };
     int item = item_of(wave);
     [[maybe_unused]] int slot = wave;
+    if (WR_EXP_HALF && wave >= 4) item = a.nblk;            // experiment: the younger wave of every SIMD stays idle
     if (WR_DYN && tid == 0) *ldsNext = 8;                   // visible behind the prologue barrier
     // the patch of (item, chunk) -> this wave's LDS buffer: 10 DMAs; out-of-range rows / columns deliver zeros
     int in_n = 0, in_y0 = 0, in_x0 = 0;
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
             if constexpr (WR_DYN != 0) {
                 slot = __builtin_amdgcn_readfirstlane(next_slot);
             } else {
-                slot += 8;
+                slot += WR_EXP_HALF ? 4 : 8;
             }
             item = item_of(slot);
             if (item < a.nblk) {
