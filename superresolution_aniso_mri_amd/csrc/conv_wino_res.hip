@@ -51,6 +51,9 @@
 #ifndef WR_EXP_HALF
 #define WR_EXP_HALF 0       // 1: only waves 0..3 of a workgroup take items (one active wave per SIMD, the same code): what does the second wave buy?
 #endif
+#ifndef WR_EXP_SALU
+#define WR_EXP_SALU 0       // n > 0: n extra scalar instructions in every patch fetch (two fetches per item): does a scalar instruction cost a wave time?
+#endif
 #ifndef WR_ABL
 #define WR_ABL 0            // timing-only ablations (WRONG results): 1 epilogue without its stores, 2 epilogue stores raw accumulators (no transform / activation)
 #endif
@@ -179,6 +182,11 @@ __global__ __launch_bounds__(WR_NT, 2) void conv_wino_res_f32(WinoArgs a) {
     };
     auto fetch = [&](int, int cc) {
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in + (size_t)in_n * inimg), 0, inimg, 0x00020000);
+        if constexpr (WR_EXP_SALU > 0) {
+            int dummy_ = cc;
+            asm volatile(".rept %1\n\ts_add_u32 %0, %0, 1\n\t.endr" : "+s"(dummy_) : "i"(WR_EXP_SALU));
+            if (dummy_ == 0x7fffffff) return;
+        }
         const unsigned gx = (unsigned)(in_x0 - 1 + dpx);
         const int off = (dpx < 10 && gx < (unsigned)a.W && cc * 16 + 4 * dq < a.Cin) ? lcd + ((in_x0 >> sh) - 1 + sh) * a.Cin * 4 + cc * 64 : WR_OOB;
 #pragma unroll
