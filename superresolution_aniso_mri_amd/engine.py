@@ -542,8 +542,12 @@ class SequentialRunner:
         p = self.sync_p2p
         if p is None or not bn_fused_enabled():
             return False
-        nmax = int(round(N * p.nscale))
-        return bool(lib.aesr_bn_fused1_supported(max(N, nmax), H, W, C, run_mode, G, backward))
+        nmax = max(N, int(round(N * p.nscale)))
+        # layers near the LDS limit stream at 1.7-1.8 TB/s in the one-launch kernel (the 38 MB first BatchNorm of a 2-triplet C4 shard made the
+        # rank step 3.13 instead of 2.65 ms): above AESR_P2P_MAX_MB the call keeps the all-reduce form.  Decided on the largest shard, like the fit.
+        if float(nmax) * H * W * C * 4.0 > float(os.environ.get("AESR_P2P_MAX_MB", "24")) * 1e6:
+            return False
+        return bool(lib.aesr_bn_fused1_supported(nmax, H, W, C, run_mode, G, backward))
 
     sync_bn = None      # optional callable(sums[G,2,C] double) -> all-reduced in place across ranks (data parallel SyncBN)
     count_scale = 1.0   # data parallel: global / local sub-batch size (B_global / B_local of this rank)
