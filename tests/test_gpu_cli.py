@@ -152,3 +152,47 @@ def test_bench_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-secondary",
                           "--config", "nope"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and bad.stdout.strip() == ""
+
+
+def test_two_rank_training_from_a_volume_directory_equals_single_process(tmp_path):
+    """train_cardiac_aesr.py --volumes_dir under torch.distributed.run with two ranks rehearsed on one device: every rank draws the whole global
+    batch's random numbers and assembles only its own triplets (TripletAugmenter.next_batch(shard=...)) into the buffer its captured step reads;
+    with SyncBN and the weighted gradient all-reduce the epoch means equal the single-process run's."""
+    import re
+    import socket
+    import subprocess
+    import sys
+    from superresolution_aniso_mri_amd import volume_io
+    data = tmp_path / "vols"
+    data.mkdir()
+    g = np.random.RandomState(11)
+    for i in range(3):
+        np.save(str(data / ("v%d.npy" % i)), g.rand(9, 44, 48).astype(np.float32))
+    v = (g.rand(8, 40, 52) * 900).astype(np.float32)
+    volume_io.write_volume(data / "p7.nii.gz", volume_io.Volume(v, (1.4, 1.4, 8.0), "npy", {}), v, (1.4, 1.4, 8.0))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--dataset=ACDC", "--model=ae_combined", "--batch_size=5", "--test_batch_size=4", "--latent=16", "--latent_width=8", "--width=32",
+            "--depth=8", "--downsample_steps=2", "--epochs=2", "--lr=0.001", "--ex_loss_weight1=0.05", "--volumes_dir=" + str(data),
+            "--aug_patch_size=40", "--iters_per_epoch=4", "--image_mix_loss_func=mse", "--epoch_threshold=0", "--use_step_graph"]
+
+    def epoch_lines(r):
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("epoch")]
+        assert len(lines) == 2 and all("nan" not in ln for ln in lines), r.stdout[-1500:]
+        return [[float(x) for x in re.findall(r"[-+]?\d+\.\d+(?:e[-+]?\d+)?", ln)] for ln in lines]
+
+    env1 = {k: v_ for k, v_ in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    one = subprocess.run([sys.executable, os.path.join(root, "train_cardiac_aesr.py")] + args + ["--exper_id=one", "--output_dir=" + str(tmp_path / "e1")],
+                         env=env1, cwd=root, capture_output=True, text=True, timeout=400)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env2 = dict(env1, AESR_SINGLE_DEVICE="1", AESR_DIST_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "train_cardiac_aesr.py")] + args +
+                         ["--exper_id=two", "--output_dir=" + str(tmp_path / "e2")], env=env2, cwd=root, capture_output=True, text=True, timeout=400)
+    a, b = epoch_lines(one), epoch_lines(two)
+    for la, lb in zip(a, b):
+        assert len(la) == len(lb) and len(la) >= 2
+        np.testing.assert_allclose(lb, la, rtol=2e-3, atol=1e-6)        # lr 1e-3: Adam's sign noise separates the trajectories at the 1e-3 level
