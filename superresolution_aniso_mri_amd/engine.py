@@ -543,9 +543,12 @@ class SequentialRunner:
         if p is None or not bn_fused_enabled():
             return False
         nmax = max(N, int(round(N * p.nscale)))
-        # layers near the LDS limit stream at 1.7-1.8 TB/s in the one-launch kernel (the 38 MB first BatchNorm of a 2-triplet C4 shard made the
-        # rank step 3.13 instead of 2.65 ms): above AESR_P2P_MAX_MB the call keeps the all-reduce form.  Decided on the largest shard, like the fit.
-        if float(nmax) * H * W * C * 4.0 > float(os.environ.get("AESR_P2P_MAX_MB", "24")) * 1e6:
+        # big layers are not for the one-launch kernel: it streams at 1.7-1.8 TB/s, and with the 18.9 MB second BatchNorm of a 2-triplet C4 shard
+        # (6 x 111 x 111 x 64) in it the rank step read 3.13 instead of 2.65 ms unprofiled -- not as kernel time under rocprofv3, where kernels do
+        # not overlap at their boundaries: its 256 workgroups of ~140 KB LDS each can only start once the previous kernel has left EVERY CU, and the
+        # early ones spin at the grid barrier meanwhile (profiles/r05_p2p_c4_layer_cap.txt).  Above AESR_P2P_MAX_MB (12) a call keeps the all-reduce
+        # form.  Decided on the largest shard of the step, like the fit, so that every rank answers alike.
+        if float(nmax) * H * W * C * 4.0 > float(os.environ.get("AESR_P2P_MAX_MB", "12")) * 1e6:
             return False
         return bool(lib.aesr_bn_fused1_supported(nmax, H, W, C, run_mode, G, backward))
 
