@@ -178,6 +178,7 @@ class AEBaseTrainer(BaseTrainer):
         iterations (one device sync per ~1 s of training at 2 ms per step)."""
         if (self._iters % self.WATCHDOG_EVERY) == 0 and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
             from .base_trainer import _check_watchdogs
+            self._bounded_sync()        # data parallel: the symbol read below syncs the device -- wait with the step deadline first
             _check_watchdogs(self, "train step %d" % self._iters)
 
     def _replayed(self):
