@@ -247,6 +247,7 @@ def test_eval_after_replayed_steps_sees_the_replayed_state():
     rec = dict(np.load(os.path.join(GOLDEN, "step_k3_cardiac_mse.npz")))
     eager, graphed = make_trainer("cardiac_mse", rec), make_trainer("cardiac_mse", rec)
     graphed.enable_step_graph(eager_steps=1)
+    eager.WATCHDOG_EVERY = graphed.WATCHDOG_EVERY = 2       # the periodic watchdog poll (a device sync) on every other step, replayed ones included
     val = _batch(rec, 2)
     vol = torch.from_numpy(rec["image_1"])
     got = {"eager": [], "graphed": []}
