@@ -164,14 +164,15 @@ class OracleAE:
             p.grad = None
 
     # -- execution ---------------------------------------------------------------------------
-    def _run(self, part, prog, x, train):
+    def _run(self, part, prog, x, train, route=None, tag=""):
+        """``route`` (oracle/routing.py, optional): records / forces the LeakyReLU sign decisions under the names ``<tag><part>.<i>``."""
         P, B = self.params, self.buffers
         for i, (op, kw) in enumerate(prog):
             key = "%s.%d." % (part, i)
             if op == "conv":
                 x = F.conv2d(x, P[key + "weight"], P[key + "bias"], stride=kw["stride"], padding=kw["pad"])
             elif op == "lrelu":
-                x = F.leaky_relu(x, LRELU_SLOPE)
+                x = F.leaky_relu(x, LRELU_SLOPE) if route is None else route.act("%s%s.%d" % (tag, part, i), x, LRELU_SLOPE)
             elif op == "bn":
                 if train:
                     B[key + "num_batches_tracked"] += 1
@@ -188,11 +189,11 @@ class OracleAE:
                 x = torch.sigmoid(x)
         return x
 
-    def encode(self, x, train=True):
-        return self._run("enc", self.enc_prog, x, train)
+    def encode(self, x, train=True, route=None, tag=""):
+        return self._run("enc", self.enc_prog, x, train, route, tag)
 
-    def decode(self, z, train=True):
-        return self._run("dec", self.dec_prog, z, train)
+    def decode(self, z, train=True, route=None, tag=""):
+        return self._run("dec", self.dec_prog, z, train, route, tag)
 
     def forward(self, x, train=True):
         return self.decode(self.encode(x, train), train)

@@ -72,16 +72,18 @@ def hash_vgg16_state():
     return sd
 
 
-def vgg16_taps(x, vgg_sd):
-    """x [N,3,H,W] -> the five tap activations (after relu1_2, relu2_2, relu3_3, relu4_3, relu5_3)."""
+def vgg16_taps(x, vgg_sd, route=None, tag=""):
+    """x [N,3,H,W] -> the five tap activations (after relu1_2, relu2_2, relu3_3, relu4_3, relu5_3).  ``route`` (oracle/routing.py,
+    optional) records / forces the ReLU signs (``<tag>relu<n>``, n = 1-based conv count) and max-pool winners (``<tag>pool<n>``)."""
     taps, nconv, conv_idx = [], 0, vgg16_feature_indices()
     for v in VGG16_CFG:
         if v == "M":
-            x = F.max_pool2d(x, 2)
+            x = F.max_pool2d(x, 2) if route is None else route.maxpool("%spool%d" % (tag, nconv), x)
         else:
             i = conv_idx[nconv]
-            x = F.relu(F.conv2d(x, vgg_sd["features.%d.weight" % i], vgg_sd["features.%d.bias" % i], padding=1))
+            x = F.conv2d(x, vgg_sd["features.%d.weight" % i], vgg_sd["features.%d.bias" % i], padding=1)
             nconv += 1
+            x = F.relu(x) if route is None else route.act("%srelu%d" % (tag, nconv), x, 0.0)
             if nconv in TAP_AFTER_CONV:
                 taps.append(x)
     return taps
@@ -112,14 +114,15 @@ def scaling_layer(x):
     return (x - shift) / scale
 
 
-def lpips_distance(in0, in1, vgg_sd, lin_w):
-    """PNetLin.forward (version '0.1'): inputs already in [-1, 1]."""
-    return lpips_head(vgg16_taps(scaling_layer(in0), vgg_sd), vgg16_taps(scaling_layer(in1), vgg_sd), lin_w)
+def lpips_distance(in0, in1, vgg_sd, lin_w, route=None, tag=""):
+    """PNetLin.forward (version '0.1'): inputs already in [-1, 1].  ``route``: the decisions of the two branches go by
+    ``<tag>in0/...`` and ``<tag>in1/...`` (perceptual_loss: in0 = target, in1 = pred)."""
+    return lpips_head(vgg16_taps(scaling_layer(in0), vgg_sd, route, tag + "in0/"), vgg16_taps(scaling_layer(in1), vgg_sd, route, tag + "in1/"), lin_w)
 
 
-def perceptual_loss(pred, target, vgg_sd, lin_w, normalize=True):
+def perceptual_loss(pred, target, vgg_sd, lin_w, normalize=True, route=None, tag=""):
     """lpips/perceptual.py:19-33 (note the argument swap: model.forward(target, pred))."""
     if normalize:
         target = 2 * target - 1
         pred = 2 * pred - 1
-    return lpips_distance(target, pred, vgg_sd, lin_w)
+    return lpips_distance(target, pred, vgg_sd, lin_w, route, tag)

@@ -29,17 +29,19 @@ class OracleStep:
         self.vgg_sd, self.lin_w = vgg_sd, lin_w
         self.recon_loss, self.plain = recon_loss, plain
 
-    def extra_image_loss(self, reference, synthesized):
-        # kwatsch/cardiac/trainer_ae.py:103-130 without masks / laploss
+    def extra_image_loss(self, reference, synthesized, route=None):
+        # kwatsch/cardiac/trainer_ae.py:103-130 without masks / laploss.  The synthesised slice is the TARGET argument here (= in0 of the
+        # distance network): its decisions are named ``lp_syn/in0/...`` (oracle/routing.py)
         if self.mix_loss == "perceptual":
             return lpips_oracle.perceptual_loss(reference, synthesized, self.vgg_sd, self.lin_w,
-                                                normalize=True).mean()
+                                                normalize=True, route=route, tag="lp_syn/").mean()
         return F.mse_loss(reference, synthesized)
 
-    def reconstruction_loss(self, reference, recons):
+    def reconstruction_loss(self, reference, recons, route=None):
         # kwatsch/base_trainer.py:164-198: percept_criterion(recons, reference, normalize=True).mean() or F.mse_loss(recons, reference)
+        # (the reconstruction is the PRED argument = in1: ``lp_rec/in1/...``)
         if self.recon_loss == "perceptual":
-            return lpips_oracle.perceptual_loss(recons, reference, self.vgg_sd, self.lin_w, normalize=True).mean()
+            return lpips_oracle.perceptual_loss(recons, reference, self.vgg_sd, self.lin_w, normalize=True, route=route, tag="lp_rec/").mean()
         return F.mse_loss(recons, reference, reduction="mean")
 
     def train_plain(self, image, slice_between, update=True):
@@ -64,26 +66,28 @@ class OracleStep:
         return dict(loss_ae=float(loss.detach()), loss_ae_dist=float(loss.detach()), loss_latent_1=float(loss_latent), z=z.detach(),
                     out=out.detach(), z_mix=z_mix.detach(), s_mix=s_mix)
 
-    def train(self, image, slice_between, alpha_from=None, alpha_to=None, update=True, lam=None):
+    def train(self, image, slice_between, alpha_from=None, alpha_to=None, update=True, lam=None, route=None):
         """image [2B,1,H,W] (from-slices then to-slices), slice_between [B,1,H,W].
         alpha_* None -> cardiac 0.5/0.5 (trainer_ae.py:51, cardiac/trainer_ae.py:173);
         else [B,1] per-sample coefficients (brain/trainer_ae.py:264-266).  ``lam``: this step's synthesis-loss weight when loss
-        annealing is on (kwatsch/cardiac/trainer_ae.py:80-83: ``loss_weights[epoch]``)."""
+        annealing is on (kwatsch/cardiac/trainer_ae.py:80-83: ``loss_weights[epoch]``).  ``route`` (oracle/routing.py, optional):
+        records / forces the non-smooth decisions of the differentiated passes -- ``x/enc.<i>``, ``z/dec.<i>``, ``mix/dec.<i>``,
+        ``lp_rec/in1/relu<n>|pool<n>``, ``lp_syn/in0/...``; the default (None) runs the stock F.leaky_relu / relu / max_pool2d."""
         if self.plain:
             return self.train_plain(image, slice_between, update=update)
         ae = self.ae
         B = image.shape[0] // 2
-        z = ae.encode(image, train=True)
-        out = ae.decode(z, train=True)
-        loss_ae_dist = self.reconstruction_loss(image, out)             # base_trainer.py:177
+        z = ae.encode(image, train=True, route=route, tag="x/")
+        out = ae.decode(z, train=True, route=route, tag="z/")
+        loss_ae_dist = self.reconstruction_loss(image, out, route=route)             # base_trainer.py:177
         if alpha_from is None:
             z_mix = 0.5 * z[:B] + (1 - 0.5) * z[B:]
         else:
             z_mix = alpha_from[:, :, None, None] * z[:B] + alpha_to[:, :, None, None] * z[B:]
-        s_mix = ae.decode(z_mix, train=True)
+        s_mix = ae.decode(z_mix, train=True, route=route, tag="mix/")
         z_ref = ae.encode(slice_between, train=True)       # graph never back-propagated; updates BN stats (Q6)
         loss_latent = F.mse_loss(z_mix, z_ref)
-        loss_extra = (self.lam if lam is None else lam) * self.extra_image_loss(slice_between, s_mix)
+        loss_extra = (self.lam if lam is None else lam) * self.extra_image_loss(slice_between, s_mix, route=route)
         loss = loss_ae_dist + loss_extra
         self.opt.zero_grad()
         if update:

@@ -53,6 +53,9 @@ class KernelProfiler:
 
 
 PROFILER = None
+# diagnostics / parity tests: a list collects (nn.Sequential, conv module, activation code, NHWC output tensor) for every convolution a pass
+# runs -- the values whose signs ARE the path's LeakyReLU decisions (the backward masks are taken from these very tensors)
+TRACE = None
 FUSE_STEM = os.environ.get("AESR_FUSE_STEM", "1") != "0"      # fold the encoder stem into the first 3x3 conv
 # 3x3 / padding-1 convolutions with enough channels run in Winograd F(2x2,3x3) form (csrc/conv_wino.hip: 2.25x fewer MFMA flops,
 # results equal to the implicit GEMM within 2-4e-7); AESR_WINO=0 keeps every layer on the exact-fp32 fma-chain implicit GEMM
@@ -413,6 +416,8 @@ class SequentialRunner:
                                             s.act, s.slope, stream()), "aesr_stemconv_fwd")
                 if save:
                     saved.append((cur, out))
+                if TRACE is not None:
+                    TRACE.append((self.seq, s.mod, s.act, out))
                 cur, H, W, C = out, Ho, Wo, s.cout
             elif s.kind == "conv":
                 act_k = _hip.ACT_NONE if (raw_last and s is steps[-1]) else s.act
@@ -475,6 +480,8 @@ class SequentialRunner:
                     raise NotImplementedError("conv with Cin=%d (neither <=4 nor a multiple of 4)" % s.cin)
                 if save:
                     saved.append((cur, out, full_hw) if s.s2d else (cur, out))
+                if TRACE is not None and not skip:
+                    TRACE.append((self.seq, s.mod, act_k, out))
                 cur, H, W, C = out, Ho, Wo, s.cout
             elif s.kind == "resample":
                 if C % 4 != 0:

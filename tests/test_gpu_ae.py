@@ -89,9 +89,14 @@ def test_acdc_full_size_probe():
     # BatchNorm: 1.4e-4 on enc.0.bias, median 1.7e-5; direct kernels + three-launch BatchNorm: 1.9e-5 -- profiles/r04_probe_sensitivity.txt).
     # So the bulk is held tight (median 2e-5) and a single flip is bounded by what it was measured to cost (2.5e-4, the first-step bound of
     # tests/test_gpu_baseline_parity.py): no alternate path of profiles/r0N_env_matrix.txt is left red by a tie.
+    # The DEFAULT path keeps the first bound, 1e-4 per tensor (round-5 advice: a regression confined to one tensor must not pass); only a run
+    # under an alternate-path switch (scripts/env_matrix.sh) gets the one-flip allowance.
     errs = {k: abs(p.grad.double().norm().item() - float(rec["gnorm/" + k])) / (float(rec["gnorm/" + k]) + 1e-30) for k, p in model.named_parameters()}
+    alternate = any(os.environ.get(v) not in (None, "") for v in ("AESR_WINO", "AESR_WGRAD_WINO", "AESR_WINO_RING", "AESR_RING_KSPLIT", "AESR_WINO_RES",
+                                                                  "AESR_BN_FUSED", "AESR_BN_FUSED_MAX_IMAGES", "AESR_FUSE_STEM", "AESR_FOLD_UPSAMPLE",
+                                                                  "AESR_WINO_RES_TN", "AESR_WINO_XCD", "AESR_LIB"))
     assert float(np.median(list(errs.values()))) < 2e-5, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
-    assert max(errs.values()) < 2.5e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    assert max(errs.values()) < (2.5e-4 if alternate else 1e-4), sorted(errs.items(), key=lambda kv: -kv[1])[:3]
     for k, b in model.named_buffers():
         if "running" in k:
             assert rel_l2(b, rec["bn/" + k]) < 1e-5, k

@@ -140,28 +140,49 @@ def test_baseline_configuration_vs_oracle(tag):
     assert d_ssim < 1e-3
 
 
-@pytest.mark.parametrize("seed", [892372, 20240607])
-def test_first_step_gradients_two_seeds(seed):
-    """configs[1] first-step gradients against the oracle for two different initialisations / batches: the stated 2e-4 is not a
-    property of one seed.  The same oracle evaluated in fp64 tells each fp32 side's own rounding apart from a real difference."""
-    from oracle import ae_oracle, step_oracle
+@pytest.mark.parametrize("tag,loss,seed", [("c2", "mse", 892372), ("c2", "mse", 20240607), ("c3", "perceptual", 892372)])
+def test_first_step_gradients_flip_aware(tag, loss, seed, record_property):
+    """configs[1] / configs[2] first-step gradients, flip-aware (round-5 verdict, next 6).  The 1e-4 that separates the HIP gradients from the
+    oracle's at this size is NOT rounding of the kernels: of the 1.2e8 (2.1e8 with LPIPS) non-smooth decisions of a step -- LeakyReLU / ReLU
+    signs, max-pool winners -- a few dozen sit within fp32 rounding of a tie and are decided the other way, and each moves the gradients by
+    O(1e-5 .. 1e-4) (profiles/r06_routing_report.txt: 22 at C2, 68-91 at C3, margins <= 4.1e-6 of the layer's rms).  So:
+
+      * outer bound, as before: 2.5e-4 on the whole gradient against the oracle in fp64 with ITS decisions (measured 1.0e-4 / 1.7e-5);
+      * the decisions that differ are counted (<= 1.5 per million; measured 0.19-0.44) and each must be a tie (fp64 margin <= 2e-5 of the rms);
+      * against the fp64 oracle evaluated WITH the HIP path's decisions every parameter gradient must agree to 5e-6 and the whole gradient to
+        2e-6 (measured 1.25e-6 / 3.0e-7): a second kind of difference -- a kernel regression, a wrong mask, a flip that is not a tie -- fails here
+        although it would pass the outer bound 100 times over."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import routing_util as ru
+    from oracle import ae_oracle, routing, step_oracle
     from superresolution_aniso_mri_amd.data_synth import synthetic_batch
-    tr, oracle, ost = _pair("mse", seed=seed)
+    tr, _, _ = _pair(loss, seed=seed)
+    sd = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
     cfg = dict(width=128, latent_width=32, depth=32, latent=128, colors=1, use_batchnorm=True, use_sigmoid=True)
-    o64 = ae_oracle.OracleAE(cfg, init=False).load_state_dict({k: v.detach().cpu() for k, v in tr.model.state_dict().items()})
-    o64.params = type(o64.params)((k, v.detach().double().requires_grad_(True)) for k, v in o64.params.items())
-    o64.buffers = type(o64.buffers)((k, v.double() if v.is_floating_point() else v) for k, v in o64.buffers.items())
-    ost64 = step_oracle.OracleStep(o64, lr=LR, ex_loss_weight1=0.05, image_mix_loss_func="mse")
+
+    def make_ost():
+        o = ae_oracle.OracleAE(cfg, init=False).load_state_dict(sd)
+        return step_oracle.OracleStep(o, lr=LR, ex_loss_weight1=0.05, image_mix_loss_func=loss, **(_lpips_kw() if loss == "perceptual" else {}))
+
     batch = synthetic_batch(12, 160, 160, seed=seed)
-    tr.train(batch, keep_predictions=False)
-    ost.train(batch["image"], batch["slice_between"])
-    ost64.train(batch["image"].double(), batch["slice_between"].double())
-    assert _grad_rel(tr, oracle) < 2.5e-4
-    n_h = n_o = d = 0.0
-    for k, p in tr.model.named_parameters():
-        t = o64.params[k].grad
-        n_h += float((p.grad.detach().double().cpu() - t).pow(2).sum())
-        n_o += float((oracle.params[k].grad.double() - t).pow(2).sum())
-        d += float(t.pow(2).sum())
-    # the HIP gradients are as close to the fp64 truth as the CPU fp32 ones, up to the same LeakyReLU-flip noise
-    assert (n_h / d) ** 0.5 < 2.5e-4 and (n_o / d) ** 0.5 < 2.5e-4, ((n_h / d) ** 0.5, (n_o / d) ** 0.5)
+    dec = ru.hip_step_decisions(tr, batch)
+    g_hip = {k: p.grad.detach().double().cpu() for k, p in tr.model.named_parameters()}
+    ntot = sum(v.numel() for v in dec.values())
+
+    def whole(ref):
+        num = sum(float((g_hip[k] - ref[k]).pow(2).sum()) for k in ref)
+        return (num / sum(float(ref[k].pow(2).sum()) for k in ref)) ** 0.5
+
+    r_own, g_own, _ = ru.oracle64_step(make_ost, batch)
+    assert whole(g_own) < 2.5e-4
+    diffs = routing.differing_decisions(r_own, dec)
+    record_property("decisions", ntot)
+    record_property("decisions_differing_from_fp64", len(diffs))
+    assert len(diffs) <= 1.5e-6 * ntot, "%d of %d decisions differ:\n%s" % (len(diffs), ntot, ru.describe(diffs))
+    assert all(d["rel"] <= 2e-5 for d in diffs), "decisions that are not ties:\n" + ru.describe(diffs)
+    g_same = ru.oracle64_step(make_ost, batch, forced=dec)[1] if diffs else g_own
+    worst = max((rel_l2(g_hip[k], g_same[k]), k) for k in g_same)
+    record_property("worst_gradient_rel_l2_vs_fp64_same_decisions", worst[0])
+    assert worst[0] < 5e-6, worst
+    assert whole(g_same) < 2e-6, whole(g_same)

@@ -325,3 +325,75 @@ def test_vif_oracle_vs_reference_functions():
     assert abs(vo.compute_vif_for_batch(rec["img/ref"], rec["img/dist"])[0] - float(rec["img/vif_batch"])) < 1e-12
     assert abs(vo.compute_vif_for_batch(rec["img/ref"], rec["img/ref"])[0] - float(rec["same/vif_batch"])) < 1e-12
     assert np.isnan(rec["black/vif_batch"]) and np.isnan(vo.compute_vif_for_batch(np.zeros((2, 24, 24), np.float32), np.zeros((2, 24, 24), np.float32))[0])
+
+
+# ---- the non-smooth decisions of the step (oracle/routing.py) ----------------------------------------------------------------------------
+def _fixture_step(tag):
+    kw, lr, _ = STEP_CASES[tag]
+    rec = _load("step_k3_%s.npz" % tag)
+
+    def make():
+        ae = ae_oracle.OracleAE(small_cfg(tag), init=False).load_state_dict(_sd(rec, "p0/"))
+        return step_oracle.OracleStep(ae, lr=lr, ex_loss_weight1=0.05, vgg_sd=lpips_oracle.hash_vgg16_state(), lin_w=_lin_w(), **kw)
+    batch = {"image": torch.from_numpy(rec["image_0"]), "slice_between": torch.from_numpy(rec["between_0"])}
+    if "alpha_from" in rec:
+        batch["alpha_from"], batch["alpha_to"] = torch.from_numpy(rec["alpha_from"]), torch.from_numpy(rec["alpha_to"])
+    return rec, make, batch
+
+
+@pytest.mark.parametrize("tag", ["brain_lpips", "cardiac_percept"])
+def test_recording_decisions_changes_nothing(tag):
+    """OracleStep.train(route=Routing()) with nothing forced is the plain oracle: same losses, same gradients, bit for bit."""
+    from oracle import routing
+    rec, make, batch = _fixture_step(tag)
+    a, b = make(), make()
+    ra = a.train(batch["image"], batch["slice_between"], batch.get("alpha_from"), batch.get("alpha_to"))
+    rb = b.train(batch["image"], batch["slice_between"], batch.get("alpha_from"), batch.get("alpha_to"), route=routing.Routing())
+    for k in ("loss_ae", "loss_ae_dist", "loss_ae_dist_extra", "loss_latent_1"):
+        assert ra[k] == rb[k], k
+    for k, p in a.ae.params.items():
+        assert torch.equal(p.grad, b.ae.params[k].grad), k
+        assert torch.equal(p, b.ae.params[k]), k
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
+
+
+def test_percept_fixture_sits_on_the_far_side_of_a_tie():
+    """step_k3_cardiac_percept (the reference's AETrainerEndToEnd with --use_percept_loss, fp32 on the CPU): ONE decision of the differentiated
+    reconstruction branch -- a VGG relu1_1 input that is 1.7e-7 in exact arithmetic -- is taken the other way than fp64 takes it, which moves every
+    parameter gradient by ~1e-3 (worst 2.0e-3, median 8e-4).  Evaluated in fp64 UNDER THE FIXTURE'S OWN DECISIONS the fixture's gradients are
+    reproduced to 1.2e-4: the fixture is right for its branch, and a path that lands on the other branch (the HIP path does: it decides as fp64
+    does, profiles/r06_routing_report.txt) is not wrong.  tests/test_gpu_step.py builds on exactly this."""
+    import routing_util as ru
+    from oracle import routing
+    rec, make, batch = _fixture_step("cardiac_percept")
+    fix = {k[6:]: torch.from_numpy(v) for k, v in rec.items() if k.startswith("grad0/")}
+    r32 = routing.Routing()
+    make().train(batch["image"], batch["slice_between"], route=r32)
+    fix_dec = {name: v[2] for name, v in r32.seen.items()}
+    r_own, g_own, _ = ru.oracle64_step(make, batch)
+    diffs = routing.differing_decisions(r_own, fix_dec)
+    assert 1 <= len(diffs) <= 4, ru.describe(diffs)
+    assert all(d["rel"] <= 2e-6 for d in diffs), ru.describe(diffs)                     # ties: within a few fp32 roundings of the layer's values
+    assert any(d["name"].startswith("lp_rec/in1/") for d in diffs)                      # ... one of them on the branch that is differentiated
+    far = sorted(_rel(fix[k], g_own[k]) for k in fix)
+    assert far[-1] > 1e-3 and far[len(far) // 2] > 3e-4                                 # the other branch: every gradient moved
+    _, g_same, _ = ru.oracle64_step(make, batch, forced=fix_dec)
+    near = sorted(_rel(fix[k], g_same[k]) for k in fix)
+    assert near[-1] < 2e-4 and near[len(near) // 2] < 4e-5, near                         # the same branch: 1.2e-4 / 1.6e-5 measured
+
+
+@pytest.mark.parametrize("tag", ["cardiac_lpips", "cardiac_mse", "cardiac_mse_s3"])
+def test_other_fixtures_sit_on_no_tie(tag):
+    """... and the other step fixtures decide everywhere as fp64 does: their gradients are comparable at face value."""
+    import routing_util as ru
+    from oracle import routing
+    rec, make, batch = _fixture_step(tag)
+    r32 = routing.Routing()
+    make().train(batch["image"], batch["slice_between"], batch.get("alpha_from"), batch.get("alpha_to"), route=r32)
+    r_own, g_own, _ = ru.oracle64_step(make, batch)
+    assert routing.differing_decisions(r_own, {name: v[2] for name, v in r32.seen.items()}) == []
+    for k, g in g_own.items():
+        assert _rel(torch.from_numpy(rec["grad0/" + k]), g) < 3e-5, k
