@@ -1,0 +1,348 @@
+// Bounded experiment of round 6 (round-5 verdict, next 5 -- SURVEY section 7 "hard parts", option B): fp32 convolution arithmetic on the bf16 matrix
+// pipe by a THREE-TERM SPLIT of both operands, x = hi + mid + lo with every term a bf16 (8 significant bits each, fp32's exponent range, so the split
+// of an fp32 number is EXACT), six products (hh, hm, mh, hl, lh, mm; the dropped ml, lm, ll are 2^-27 and below) accumulated in fp32 by
+// v_mfma_f32_16x16x32_bf16 -- 16 x the f32 MFMA rate, so 6 / 16 = 0.375 of the matrix cycles, AND (MI355X_MICROARCH.md, vector-instruction issue cost)
+// a bf16 MFMA holds its SIMD's vector issue for only 8 of its 16 cycles where v_mfma_f32_16x16x4_f32 holds it for all 32 (scripts/micro/mfma_gap.hip):
+// the Winograd transforms that bound the shipped kernels could run in the matrix pipe's shadow.
+//
+// Part 1, ACCURACY (real arithmetic): D[16 x 16] tiles = A[16 x K] B[K x 16], K = 288, fp32 inputs split on the fly, against fp64 on the host;
+//   variants: six products into one accumulator (small terms first / last), three products (hh, hm, mh), the f32 MFMA itself, round-to-nearest split.
+// Part 2, TIMING SKELETONS of the resident-filter Winograd item loop in the Winograd-domain form (instruction totals, no meaningful data), as
+//   scripts/micro/res_skeleton.hip did for the f32 kernel: per item of 4 x 4 tiles x 32 output channels x 32 input channels
+//     w32:  two waves per SIMD; 192 v_mfma_f32_16x16x32_bf16 (16 positions x 2 cout blocks x 6 products), input transform 256 v_add, split of the 128
+//           transformed values per lane 4 VALU each (and, sub, and, sub: truncation split) + 192 v_perm_b32 (packing), 32 + 96 ds_read_b128
+//           (patch; three bf16 planes of the filter), 20 LDS-DMAs, the shipped epilogue (312 vector instructions, 8 stores)
+//     w64:  ONE wave per SIMD, 64 output channels per wave (256 accumulators): 384 MFMAs per item, the same input work, 192 filter reads, two epilogues
+//     f32:  the shipped order with v_mfma_f32_16x16x4_f32 (= res_skeleton's seq2) on the same accounting, for the ratio
+//   Output: cycles of SIMD time per item (per 32 output channels).
+// build + run:  hipcc -O3 --offload-arch=gfx950 scripts/micro/bf16x3.hip -o /tmp/bf16x3 && /tmp/bf16x3
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+// ---------------------------------------------------------------- part 1: accuracy ----------------------------------------------------------------
+__device__ __forceinline__ void split_trunc(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const unsigned uh = __float_as_uint(x) & 0xffff0000u;
+    const float r = x - __uint_as_float(uh);                       // exact: the low 16 significand bits of x
+    const unsigned um = __float_as_uint(r) & 0xffff0000u;
+    const float r2 = r - __uint_as_float(um);                      // exact: at most 8 significant bits left
+    h = (unsigned short)(uh >> 16);
+    m = (unsigned short)(um >> 16);
+    l = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+__device__ __forceinline__ unsigned short bf16_rne(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ void split_rne(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    h = bf16_rne(x);
+    const float r = x - __uint_as_float((unsigned)h << 16);
+    m = bf16_rne(r);
+    const float r2 = r - __uint_as_float((unsigned)m << 16);
+    l = bf16_rne(r2);
+}
+
+// mode 0: six products, small terms first; 1: six products, hh first; 2: three products (hh, hm, mh); 3: v_mfma_f32_16x16x4_f32; 4: mode 0 with RNE split;
+// 5: six products into THREE accumulators (hh | hm + mh | hl + lh + mm), added once at the end
+__global__ __launch_bounds__(64) void gemm_probe(const float* A, const float* B, float* D, int K, int mode) {
+    const int lane = threadIdx.x, l15 = lane & 15, g = lane >> 4;
+    const float* a = A + ((size_t)blockIdx.x * 16 + l15) * K;      // row l15 of this tile's A
+    const float* b = B + ((size_t)blockIdx.x * 16 + l15) * K;      // column l15 of this tile's B (stored [n][k])
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = acc, acc2 = acc;
+    if (mode == 3) {
+        for (int k = 0; k < K; k += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k + g], b[k + g], acc, 0, 0, 0);
+    } else {
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            u16x8 ah, am, al, bh, bm, bl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                unsigned short h, m, l;
+                if (mode == 4) split_rne(a[k0 + 8 * g + j], h, m, l); else split_trunc(a[k0 + 8 * g + j], h, m, l);
+                ah[j] = h; am[j] = m; al[j] = l;
+                if (mode == 4) split_rne(b[k0 + 8 * g + j], h, m, l); else split_trunc(b[k0 + 8 * g + j], h, m, l);
+                bh[j] = h; bm[j] = m; bl[j] = l;
+            }
+#define MM(acc_, x, y) acc_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), acc_, 0, 0, 0)
+            if (mode == 0 || mode == 4) { MM(acc, am, bm); MM(acc, al, bh); MM(acc, ah, bl); MM(acc, am, bh); MM(acc, ah, bm); MM(acc, ah, bh); }
+            else if (mode == 1) { MM(acc, ah, bh); MM(acc, ah, bm); MM(acc, am, bh); MM(acc, ah, bl); MM(acc, al, bh); MM(acc, am, bm); }
+            else if (mode == 2) { MM(acc, ah, bm); MM(acc, am, bh); MM(acc, ah, bh); }
+            else { MM(acc2, am, bm); MM(acc2, al, bh); MM(acc2, ah, bl); MM(acc1, am, bh); MM(acc1, ah, bm); MM(acc, ah, bh); }
+        }
+        if (mode == 5) acc = acc + (acc1 + acc2);
+    }
+    // D tile: lane (l15, g) holds column n = l15, rows 4 g .. 4 g + 3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) D[((size_t)blockIdx.x * 16 + 4 * g + i) * 16 + l15] = acc[i];
+}
+
+static double urand() { return (rand() + 0.5) / ((double)RAND_MAX + 1.0); }
+static double nrand() { return sqrt(-2.0 * log(urand())) * cos(6.283185307179586 * urand()); }
+
+static void accuracy() {
+    const int T = 256, K = 288;
+    const char* dist_name[3] = {"N(0,1) x N(0,1)", "N(0,1) x 10^U(-4,0) (activations of mixed scale) x N(0,0.06) (filter-like)", "positive, strongly correlated (mean 1, sd 0.05: cancellation-free sums)"};
+    const char* mode_name[6] = {"bf16 x 3, six products, small terms first", "bf16 x 3, six products, hh first", "bf16 x 3, THREE products (hh, hm, mh)",
+                                "v_mfma_f32_16x16x4_f32 (the shipped arithmetic)", "bf16 x 3 with round-to-nearest split, six products", "bf16 x 3, six products, three accumulators"};
+    float *dA, *dB, *dD;
+    (void)hipMalloc(&dA, (size_t)T * 16 * K * 4); (void)hipMalloc(&dB, (size_t)T * 16 * K * 4); (void)hipMalloc(&dD, (size_t)T * 256 * 4);
+    std::vector<float> A((size_t)T * 16 * K), B((size_t)T * 16 * K), D((size_t)T * 256);
+    std::vector<double> R((size_t)T * 256);
+    printf("# part 1: accuracy of D = A B (K = %d, %d tiles of 16 x 16) against fp64; rel-L2 = |D - R| / |R|, worst element error in units of the rms of R\n", K, T);
+    for (int dist = 0; dist < 3; ++dist) {
+        srand(1234 + dist);
+        for (size_t i = 0; i < A.size(); ++i) {
+            if (dist == 0) { A[i] = (float)nrand(); B[i] = (float)nrand(); }
+            else if (dist == 1) { A[i] = (float)(nrand() * pow(10.0, -4.0 * urand())); B[i] = (float)(0.06 * nrand()); }
+            else { A[i] = (float)(1.0 + 0.05 * nrand()); B[i] = (float)(1.0 + 0.05 * nrand()); }
+        }
+        double rr = 0;
+        for (int t = 0; t < T; ++t)
+            for (int m = 0; m < 16; ++m)
+                for (int n = 0; n < 16; ++n) {
+                    double s = 0;
+                    for (int k = 0; k < K; ++k) s += (double)A[((size_t)t * 16 + m) * K + k] * (double)B[((size_t)t * 16 + n) * K + k];
+                    R[((size_t)t * 16 + m) * 16 + n] = s;
+                    rr += s * s;
+                }
+        const double rms = sqrt(rr / R.size());
+        (void)hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+        printf("  %s\n", dist_name[dist]);
+        for (int mode = 0; mode < 6; ++mode) {
+            hipLaunchKernelGGL(gemm_probe, dim3(T), dim3(64), 0, 0, dA, dB, dD, K, mode);
+            (void)hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost);
+            double e2 = 0, mx = 0;
+            for (size_t i = 0; i < R.size(); ++i) { const double e = (double)D[i] - R[i]; e2 += e * e; if (fabs(e) > mx) mx = fabs(e); }
+            printf("    %-56s rel-L2 %.2e   worst %.2e of the rms\n", mode_name[mode], sqrt(e2 / rr), mx / rms);
+        }
+    }
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dD);
+}
+
+// ---------------------------------------------------------------- part 2: timing skeletons --------------------------------------------------------
+#define MFMA32(acc, a, b) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+#define MFMAB(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+#define PK(n) asm volatile(".rept %3\n\tv_pk_add_f32 %0, %2, %2\n\tv_pk_add_f32 %1, %2, %2\n\t.endr" : "=v"(p0), "=v"(p1) : "v"(pa), "i"((n) / 2))
+#define VA(n) asm volatile(".rept %4\n\tv_add_f32 %0, %2, %3\n\tv_max_f32 %1, %2, %3\n\t.endr" : "=v"(f0), "=v"(f1) : "v"(a0), "v"(b0), "i"((n) / 2))
+// the split of n values: and, sub, and, sub (a dependent chain of four per value, values independent of each other)
+#define SPLIT(n) asm volatile(".rept %5\n\tv_and_b32 %0, 0xffff0000, %4\n\tv_sub_f32 %1, %4, %0\n\tv_and_b32 %2, 0xffff0000, %1\n\tv_sub_f32 %3, %1, %2\n\t.endr" \
+                              : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3) : "v"(a0), "i"(n))
+#define PERM(n) asm volatile(".rept %3\n\tv_perm_b32 %0, %1, %2, %2\n\t.endr" : "=v"(s4) : "v"(a0), "v"(b0), "i"(n))
+#define DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(n))
+#define VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n))
+
+__device__ __forceinline__ void dma(__amdgpu_buffer_rsrc_t rs, float* lds_wave_base, int byte_off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, byte_off, 0, 0, 0);
+}
+__device__ __forceinline__ void st(__amdgpu_buffer_rsrc_t rs, int byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), rs, byte_off, 0, 0);
+}
+
+constexpr int PFL = 2600;            // floats of a wave's patch buffer (10 rows x 260, as in conv_wino_res.hip)
+constexpr int UFL = 24576;           // floats of the filter image in LDS: 96 KB (three bf16 planes of 16 positions x 32 ci x 32 co)
+
+// MODE 0 "f32": shipped order, f32 MFMA.  1 "w32": bf16 x 3, two waves per SIMD, 32 couts per wave.  2 "w64": one wave per SIMD, 64 couts per wave.
+// 3 "w32-nosplit": w32 without the split instructions (what the split costs).  4 "w32-mfma-only".
+template <int MODE>
+__global__ __launch_bounds__(MODE == 2 ? 256 : 512, MODE == 2 ? 1 : 2) void skel(const float* src, float* out, long long* cyc, int items, unsigned src_bytes, unsigned out_bytes) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = MODE == 2 ? 4 : 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (patch buffers: the f32 form keeps 8 x 10.4 KB beside its 64 KB filter; the bf16 forms share the remaining 64 KB: timing only, the buffers overlap)
+    for (int i = tid; i < UFL + 4 * PFL; i += blockDim.x) lds[i] = (float)(i & 15) * 0.0625f;
+    __syncthreads();
+    float* const ldsP = lds + UFL + (wave & 3) * PFL;
+    const unsigned uaddr = (unsigned)(unsigned long long)(lds + lane * 4);
+    const unsigned paddr = (unsigned)(unsigned long long)(ldsP + lane * 4);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, out_bytes, 0x00020000);
+    const unsigned wg = (unsigned)(blockIdx.x * NW + wave);
+    const unsigned dmask = (16u << 20) / 2 - 1, omask = (64u << 20) - 1;           // sources L2-resident, results absorbed by the Infinity Cache
+    unsigned doff = (wg * 20u * 1024u + lane * 16) & dmask;
+    const unsigned ooff = (wg * 8u * 1024u + lane * 16) & omask;
+    constexpr int NACC = MODE == 2 ? 64 : 32;
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x2 p0 = {1.f, 2.f}, p1 = {3.f, 4.f}, pa = {0.5f, 0.25f};
+    float f0 = 1.f, f1 = 2.f, a0 = lane * 0.001f, b0 = 1.f + lane * 0.002f, s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    f32x4 u[2][6], t0 = {1.f, 1.f, 1.f, 1.f};
+    f32x4 u64[2][12];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) u[0][i] = u[1][i] = t0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) u64[0][i] = u64[1][i] = t0;
+    const f32x4 sv = {1.f, 2.f, 3.f, 4.f}, vb = {0.25f, 0.5f, 0.75f, 1.f};
+    const long long c0 = (long long)__builtin_amdgcn_s_memtime();
+    auto epilogue = [&]() {
+        PK(20);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            PK(2);
+            VA(34);
+            st(rs_out, (int)(ooff + s * 1024), sv);
+        }
+        VA(4);
+    };
+    if constexpr (MODE == 0) {
+#pragma unroll 1
+        for (int it = 0; it < items; ++it) {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                VM(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) DSR(t0, paddr, (r & 7) * 1040);
+                DSR(u[0][0], uaddr, 0);
+                DSR(u[0][1], uaddr, 1024);
+                LGKM(0);
+#pragma unroll
+                for (int r = 0; r < 10; ++r) dma(rs_in, ldsP + r * 260, (int)(doff + r * 1024));
+                doff = (doff + 10 * 1024) & dmask;
+                PK(32);
+                VA(24);
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int c = g & 1, n = c ^ 1;
+                    if (g + 1 < 16) {
+                        DSR(u[n][0], uaddr, ((g + 1) & 15) * 2048);
+                        DSR(u[n][1], uaddr, ((g + 1) & 15) * 2048 + 1024);
+                    }
+                    PK(2);
+                    if (g + 1 < 16) LGKM(2); else LGKM(0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        MFMA32(acc[2 * g], u[c][0][r], b0);
+                        MFMA32(acc[2 * g + 1], u[c][1][r], b0);
+                    }
+                }
+            }
+            epilogue();
+        }
+    } else if constexpr (MODE == 2) {
+#pragma unroll 1
+        for (int it = 0; it < items; ++it) {
+            VM(0);
+#pragma unroll
+            for (int r = 0; r < 32; ++r) DSR(t0, paddr, (r & 7) * 1040);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) DSR(u64[0][i], uaddr, i * 1024);
+            LGKM(0);
+#pragma unroll
+            for (int r = 0; r < 20; ++r) dma(rs_in, ldsP + (r % 10) * 260, (int)(doff + r * 1024));
+            doff = (doff + 20 * 1024) & dmask;
+            VA(128);                                                    // row half of the input transform, 8 channels per lane
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int c = g & 1, n = c ^ 1;
+                if (g + 1 < 16) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) DSR(u64[n][i], uaddr, (((g + 1) * 12 + i) & 63) * 1024);
+                }
+                VA(8);                                                  // column half, one position ahead
+                SPLIT(8);
+                PERM(12);
+                if (g + 1 < 16) LGKM(12); else LGKM(0);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr) MFMAB(acc[4 * g + nb], u64[c][nb * 3 + (pr % 3)], vb);
+            }
+            epilogue();
+            epilogue();
+        }
+    } else {
+#pragma unroll 1
+        for (int it = 0; it < items; ++it) {
+            if constexpr (MODE != 4) {
+                VM(0);
+#pragma unroll
+                for (int r = 0; r < 32; ++r) DSR(t0, paddr, (r & 7) * 1040);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) DSR(u[0][i], uaddr, i * 1024);
+            LGKM(0);
+            if constexpr (MODE != 4) {
+#pragma unroll
+                for (int r = 0; r < 20; ++r) dma(rs_in, ldsP + (r % 10) * 260, (int)(doff + r * 1024));
+                doff = (doff + 20 * 1024) & dmask;
+                VA(128);
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int c = g & 1, n = c ^ 1;
+                if (g + 1 < 16) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) DSR(u[n][i], uaddr, (((g + 1) * 6 + i) & 63) * 1024);
+                }
+                if constexpr (MODE != 4) {
+                    VA(8);
+                    if constexpr (MODE == 1) {
+                        SPLIT(8);
+                        PERM(12);
+                    }
+                }
+                if (g + 1 < 16) LGKM(6); else LGKM(0);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr) MFMAB(acc[2 * g + nb], u[c][nb * 3 + (pr % 3)], vb);
+            }
+            if constexpr (MODE != 4) epilogue();
+        }
+    }
+    VM(0);
+    LGKM(0);
+    const long long c1 = (long long)__builtin_amdgcn_s_memtime();
+    float s = f0 + f1 + p0[0] + p1[1] + t0[0] + s0 + s1 + s2 + s3 + s4;
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) s += acc[j][0];
+    if (s == 12345.678f) out[tid] = s;
+    if (lane == 0) cyc[blockIdx.x * NW + wave] = c1 - c0;
+}
+
+template <int MODE>
+static double run(const char* name, const float* src, float* out, long long* cyc, unsigned src_bytes, unsigned out_bytes, double mfma_cycles) {
+    constexpr int NW = MODE == 2 ? 4 : 8, NT = MODE == 2 ? 256 : 512;
+    const size_t shmem = (size_t)(UFL + 4 * PFL) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)skel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int items = 32;                                               // per wave; w64's items are twice as wide
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((skel<MODE>), dim3(256), dim3(NT), shmem, 0, src, out, cyc, items, src_bytes, out_bytes);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed: %s\n", name, hipGetErrorString(hipGetLastError())); return 0; }
+    static long long h[256 * 8];
+    (void)hipMemcpy(h, cyc, 256 * NW * sizeof(long long), hipMemcpyDeviceToHost);
+    double sum = 0, mx = 0;
+    for (int i = 0; i < 256 * NW; ++i) { sum += h[i]; if (h[i] > mx) mx = h[i]; }
+    // cycles of SIMD time per 32-output-channel item: two waves of a SIMD finish two items in a wave's item time; a w64 item is two of them
+    const double div = 2.0;
+    const double mean = sum / (256 * NW) / items / div, slow = mx / items / div;
+    printf("  %-14s %7.0f cycles of SIMD time per item (32 couts) by the mean wave, %7.0f by the slowest; its MFMAs alone %5.0f -> matrix pipe %4.1f %% busy\n", name, mean, slow,
+           mfma_cycles, 100.0 * mfma_cycles / slow);
+    return slow;
+}
+
+int main() {
+    accuracy();
+    const unsigned src_bytes = 64u << 20, out_bytes = 128u << 20;
+    float *src, *out;
+    long long* cyc;
+    (void)hipMalloc(&src, src_bytes); (void)hipMalloc(&out, out_bytes); (void)hipMalloc(&cyc, 256 * 8 * sizeof(long long));
+    (void)hipMemset(src, 0, src_bytes);
+    printf("# part 2: timing skeletons of the resident-filter Winograd item loop (4 x 4 tiles x 32 couts x 32 input channels per item), sources cache-resident\n");
+    const double f = run<0>("f32 (shipped)", src, out, cyc, src_bytes, out_bytes, 8192.0);
+    const double w = run<1>("w32 bf16x3", src, out, cyc, src_bytes, out_bytes, 192 * 16.0);
+    const double w64 = run<2>("w64 bf16x3", src, out, cyc, src_bytes, out_bytes, 192 * 16.0);
+    run<3>("w32 no split", src, out, cyc, src_bytes, out_bytes, 192 * 16.0);
+    run<4>("w32 MFMA only", src, out, cyc, src_bytes, out_bytes, 192 * 16.0);
+    if (f > 0 && w > 0 && w64 > 0)
+        printf("  ratio to the f32 skeleton: w32 %.2f x, w64 %.2f x   (the shipped kernel runs 1.26 x its skeleton: 13 800 cycles per item, profiles/r05_res_skeleton.txt)\n", f / w, f / w64);
+    return 0;
+}

@@ -27,6 +27,24 @@ static void cout_padding(int Cout, int* CoutP, int* NB) {
     else { *CoutP = round_up(Cout, 64); *NB = 4; }
 }
 
+// Every convolution entry point and query decides FIRST, in 64 bits, whether the tensors stay inside the kernels' 32-bit element offsets (the
+// launchers refuse 0x1C000000 elements and more): the planners below do their tile arithmetic in int and must never see sizes beyond that
+// (found by the host-side sanitizer sweep of round 6, tests/test_host_sanitized.py: ceil_div(INT_MAX, 2) in plan_wino from a query).
+static bool conv_dims_ok(int N, int H, int W, int Cin, int Cout) {
+    if (N < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return false;
+    if (N > (1 << 24) || H > (1 << 15) || W > (1 << 15) || Cin > (1 << 15) || Cout > (1 << 15)) return false;
+    const unsigned long long px = (unsigned long long)N * (unsigned)(H + 2) * (unsigned)(W + 2);       // <= 2^24 * 2^16 * 2^16: no overflow
+    return px * (unsigned long long)(Cin > Cout ? Cin : Cout) < 0x1C000000ull;
+}
+#define AESR_CHECK_DIMS(who, N, H, W, Cin, Cout)                                                                                            \
+    do {                                                                                                                                    \
+        if (!conv_dims_ok(N, H, W, Cin, Cout)) {                                                                                            \
+            aesr_set_error("%s: %d x %d x %d with %d -> %d channels is empty or beyond the kernels' 32-bit element offsets (469M elements)", who, N, H, \
+                           W, Cin, Cout);                                                                                                   \
+            return AESR_ERR_UNSUPPORTED;                                                                                                    \
+        }                                                                                                                                   \
+    } while (0)
+
 struct ConvPlan { int TI, TH, TW, NB, MBW, CinP, CoutP, NT, ksplit; };
 static std::mutex g_plan_mu;
 
@@ -316,7 +334,9 @@ int aesr_conv2d_pack(const float* w, float* packed, int Cout, int Cin, int KS, i
 static int run_igemm(const float* in, const float* packed, const float* bias, const float* ysave, float* out, int N, int H,
                      int W, int Cin, int Cout, int KS, int pad, int act, int mask_act, float slope, float* workspace,
                      hipStream_t st) {
+    AESR_CHECK_DIMS("aesr_conv2d (implicit GEMM)", N, H, W, Cin, Cout);
     const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
+    AESR_CHECK_ARG(Ho > 0 && Wo > 0, "aesr_conv2d: the %d x %d input is smaller than the %d x %d filter", H, W, KS, KS);
     const ConvPlan p = plan_conv(N, Ho, Wo, Cin, Cout, KS);
     IgemmArgs a;
     a.in = in; a.wpk = packed; a.bias = bias; a.ysave = ysave; a.out = out;
@@ -414,14 +434,16 @@ int aesr_conv2d_fwd(const float* in, const float* packed, const float* bias, flo
 }
 
 size_t aesr_conv2d_workspace_floats(int N, int H, int W, int Cin, int Cout, int KS, int pad) {
+    if (!conv_dims_ok(N, H, W, Cin, Cout) || (KS != 1 && KS != 3) || pad < 0 || pad >= KS) return 0;
     const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
-    if (N <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || (KS != 1 && KS != 3)) return 0;
+    if (Ho <= 0 || Wo <= 0) return 0;
     const ConvPlan p = plan_conv(N, Ho, Wo, Cin, Cout, KS);
     return p.ksplit > 1 ? (size_t)p.ksplit * N * Ho * Wo * Cout : 0;
 }
 
 size_t aesr_conv2d_dgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int KS, int pad) {
     // the data gradient is the forward kernel on dy [N,Ho,Wo,Cout] with Cout and Cin swapped and padding KS-1-pad
+    if (!conv_dims_ok(N, H, W, Cin, Cout) || (KS != 1 && KS != 3) || pad < 0 || pad >= KS) return 0;
     const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
     return aesr_conv2d_workspace_floats(N, Ho, Wo, Cout, Cin, KS, KS - 1 - pad);
 }
@@ -462,7 +484,7 @@ int aesr_conv2d_wino_supported(int Cin, int Cout, int KS, int pad, int transpose
 }
 
 int aesr_conv2d_wino_kernel(int N, int H, int W, int Cin, int Cout, int KS, int pad, int transpose) {
-    if (!aesr_conv2d_wino_supported(Cin, Cout, KS, pad, transpose) || N < 1 || H < 1 || W < 1) return 0;
+    if (!aesr_conv2d_wino_supported(Cin, Cout, KS, pad, transpose) || !conv_dims_ok(N, H, W, Cin, Cout)) return 0;
     const int kin = transpose ? Cout : Cin, nout = transpose ? Cin : Cout;
     const WinoPlan p = plan_wino(N, H, W, kin, nout);
     WinoArgs a = {};
@@ -476,7 +498,7 @@ int aesr_conv2d_wino_kernel(int N, int H, int W, int Cin, int Cout, int KS, int 
 }
 
 size_t aesr_conv2d_wino_workspace_floats(int N, int H, int W, int Cin, int Cout, int transpose) {
-    if (!aesr_conv2d_wino_supported(Cin, Cout, 3, 1, transpose) || N < 1 || H < 1 || W < 1) return 0;
+    if (!aesr_conv2d_wino_supported(Cin, Cout, 3, 1, transpose) || !conv_dims_ok(N, H, W, Cin, Cout)) return 0;
     const int kin = transpose ? Cout : Cin, nout = transpose ? Cin : Cout;
     const WinoPlan p = plan_wino(N, H, W, kin, nout);
     WinoArgs a = {};
@@ -525,6 +547,7 @@ int aesr_conv2d_wino_pack_many(const aesr_pack_job* jobs_host, int njobs, void* 
 static int run_wino(const float* in, const float* upk, const float* bias, const float* ysave, float* out, int N, int H, int W,
                     int Cin, int Cout, int act, int mask_act, float slope, hipStream_t st, int in_up2 = 0, int out_sum2 = 0,
                     float* ws = nullptr, size_t ws_floats = 0) {
+    AESR_CHECK_DIMS("aesr_conv2d_wino", N, H, W, Cin, Cout);
     const WinoPlan p = plan_wino(N, H, W, Cin, Cout);
     WinoArgs a = {};
     a.in = in; a.upk = upk; a.bias = bias; a.ysave = ysave; a.out = out;
@@ -569,7 +592,7 @@ int aesr_conv2d_wino_dgrad_ws(const float* dy, const float* upacked_t, const flo
 /* conv + activation + eval-mode BatchNorm (per-channel scale / shift) [+ AvgPool2d(2)] as one launch: the resident-filter kernel, and the
    ring kernel where it takes the layer WITHOUT a workspace (no channel split: the epilogue has to see the finished sums) */
 int aesr_conv2d_wino_fwd_bn_supported(int N, int H, int W, int Cin, int Cout) {
-    if (!aesr_conv2d_wino_supported(Cin, Cout, 3, 1, 0) || N < 1 || H < 1 || W < 1) return 0;
+    if (!aesr_conv2d_wino_supported(Cin, Cout, 3, 1, 0) || !conv_dims_ok(N, H, W, Cin, Cout)) return 0;
     const WinoPlan p = plan_wino(N, H, W, Cin, Cout);
     WinoArgs a = {};
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
@@ -612,7 +635,9 @@ int aesr_conv2d_wino_dgrad_sum2(const float* dy, const float* upacked_t, float* 
 }
 
 size_t aesr_conv2d_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int KS, int pad) {
+    if (!conv_dims_ok(N, H, W, Cin, Cout) || (KS != 1 && KS != 3) || pad < 0 || pad >= KS) return 0;
     const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
+    if (Ho <= 0 || Wo <= 0) return 0;
     return plan_wgrad(N, Ho, Wo, Cin, Cout, KS, pad).slab_floats;
 }
 
@@ -641,6 +666,8 @@ int aesr_conv2d_wgrad_reduce_many(const aesr_wgrad_reduce_job* jobs_host, int nj
         for (int k = 0; k < t.njobs; ++k) {
             const aesr_wgrad_reduce_job& jb = jobs_host[j0 + k];
             AESR_CHECK_ARG(jb.workspace && jb.dw && jb.N > 0 && (jb.KS == 1 || jb.KS == 3), "aesr_conv2d_wgrad_reduce_many: bad job %d", j0 + k);
+            AESR_CHECK_ARG(conv_dims_ok(jb.N, jb.H, jb.W, jb.Cin, jb.Cout) && jb.pad >= 0 && jb.pad < jb.KS && jb.H + 2 * jb.pad >= jb.KS && jb.W + 2 * jb.pad >= jb.KS,
+                           "aesr_conv2d_wgrad_reduce_many: job %d: bad shape", j0 + k);
             const int Ho = jb.H + 2 * jb.pad - jb.KS + 1, Wo = jb.W + 2 * jb.pad - jb.KS + 1;
             const WgradPlan p = plan_wgrad(jb.N, Ho, Wo, jb.Cin, jb.Cout, jb.KS, jb.pad);      // the plan the partial launch used
             ReduceJob& o = t.job[k];
@@ -668,7 +695,9 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* db, flo
     AESR_CHECK_ARG(x && dy && workspace && N > 0, "aesr_conv2d_wgrad: null pointer or empty shape");
     AESR_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0, "aesr_conv2d_wgrad: Cin=%d, Cout=%d must be multiples of 4", Cin, Cout);
     AESR_CHECK_ARG((KS == 1 || KS == 3) && pad >= 0 && pad < KS, "aesr_conv2d_wgrad: unsupported KS=%d pad=%d", KS, pad);
+    AESR_CHECK_DIMS("aesr_conv2d_wgrad", N, H, W, Cin, Cout);
     const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
+    AESR_CHECK_ARG(Ho > 0 && Wo > 0, "aesr_conv2d_wgrad: the %d x %d input is smaller than the %d x %d filter", H, W, KS, KS);
     const WgradPlan p = plan_wgrad(N, Ho, Wo, Cin, Cout, KS, pad);
     WgradArgs a;
     a.x = x; a.dy = dy; a.slab = workspace;
@@ -1252,7 +1281,10 @@ int aesr_ssim_mse(const float* a, const float* b, double* workspace, double* ssi
     return aesr_launch_ssim_mse(a, b, workspace, ssim, mse, Z, H, W, win, data_range, k1, k2, (hipStream_t)stream);
 }
 
-size_t aesr_vif_workspace_bytes(int Z, int H, int W) { return (Z > 0 && H > 0 && W > 0) ? aesr_vif_workspace_bytes_impl(Z, H, W) : 0; }
+// (the shapes aesr_vif_mscale takes; anything else has no workspace: the layout arithmetic is int -- sanitizer sweep, round 6)
+size_t aesr_vif_workspace_bytes(int Z, int H, int W) {
+    return (Z > 0 && Z <= 65535 && H > 0 && W > 0 && (size_t)H * W < ((size_t)1 << 30)) ? aesr_vif_workspace_bytes_impl(Z, H, W) : 0;
+}
 
 int aesr_vif_mscale(const float* ref, const float* dist, void* workspace, double* vif, int Z, int H, int W, const double* weights_host,
                     const int* radii_host, double sigma_nsq, void* stream) {

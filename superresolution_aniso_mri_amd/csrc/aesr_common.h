@@ -69,5 +69,5 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int ceil_div(int a, int b) { return a / b + (a % b != 0); }       // (a, b > 0; no a + b - 1 to overflow)
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
