@@ -13,7 +13,7 @@ if [ -n "$T" ]; then NAME=${TAG}_${CFG}_${T}triplets; EXTRA="--triplets $T"; fi
 rm -rf /tmp/rp_$NAME
 rocprofv3 --kernel-trace -d /tmp/rp_$NAME/kt -o res -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 4 --config $CFG $EXTRA --no-cpu-baseline --no-roofline --no-secondary > $OUT/${NAME}_prof_bench.json 2> /dev/null
 DB=$(find /tmp/rp_$NAME/kt -name "*.db" | head -1)
-python3 $S/kstats_last.py $DB 4 > $OUT/${NAME}_kernel_stats.txt
+python3 $S/kstats_last.py $DB 4 "" $OUT/${NAME}_kernel_stats.json > $OUT/${NAME}_kernel_stats.txt
 python3 $S/kseq_last.py $DB > $OUT/${NAME}_kernel_sequence.txt
 head -14 $OUT/${NAME}_kernel_stats.txt | cut -c1-170
 if [ "$PMC" = "pmc" ]; then

@@ -544,7 +544,7 @@ int aesr_bn_fused_run(const float* y, const float* gout, float* out, float* rec,
                       float momentum, float eps, int update_running, int act, float slope, int backward, const BnP2P* p2p, hipStream_t st) {
     BnFusedArgs a = {};
     if (p2p) {
-        const char* e = getenv("AESR_P2P_SPINS");             // tests shorten the wait for a peer that never comes (default ~30 s)
+        const char* e = getenv("AESR_P2P_SPINS");             // tests shorten the wait for a peer that never comes (default P2P_SPIN_LIMIT: ~7 s -- the peer-skew tolerance of AESR_SYNCBN=p2p)
         a.p2p_spins = e && atoi(e) > 0 ? atoi(e) : P2P_SPIN_LIMIT;
         a.world = p2p->world; a.rank = p2p->rank; a.slot = p2p->slot; a.gen = p2p->gen;
         for (int r = 0; r < 8; ++r) a.peers[r] = r < p2p->world ? (unsigned char*)p2p->peers[r] : nullptr;

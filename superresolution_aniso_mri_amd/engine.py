@@ -26,28 +26,31 @@ LRELU_SLOPE = 0.01
 
 
 class KernelProfiler:
-    """Optional HIP-event timing of the MFMA convolution launches (bench.py roofline): one event pair per launch on the
-    launching stream; durations are read after a synchronize.  Off (None) in normal operation."""
+    """Optional HIP-event timing of the step's launches (bench.py roofline): one event pair per call on the launching stream; durations are
+    read after a synchronize.  MFMA convolution launches carry their algorithmic flops, the bandwidth-bound calls of the step's tail
+    (BatchNorm, the single-channel-side "thin" convolutions, slab sums, losses, lerp, Adam, the LPIPS head) their ALGORITHMIC BYTES: every
+    tensor of the call read or written once.  Off (None) in normal operation."""
 
     def __init__(self):
-        self.records = []      # (kind, flops, start_event, end_event)
+        self.records = []      # (kind, flops, bytes, start_event, end_event)
 
-    def begin(self, kind, flops):
+    def begin(self, kind, flops, nbytes=0.0):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream())
-        self.records.append((kind, flops, e0, e1))
+        self.records.append((kind, flops, nbytes, e0, e1))
 
     def end(self):
-        self.records[-1][3].record(torch.cuda.current_stream())
+        self.records[-1][4].record(torch.cuda.current_stream())
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind, flops, e0, e1 in self.records:
-            d = out.setdefault(kind, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        for kind, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(kind, {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["flops"] += flops
+            d["bytes"] += nbytes
             d["ms"] += e0.elapsed_time(e1)
         return out
 
@@ -108,12 +111,13 @@ def wgrad_kind(cin, cout, ks, pad):
     return "conv_wgrad_wino_f32" if (ks == 3 and pad == 1 and lib.aesr_conv2d_wgrad_up2_supported(int(cin), int(cout))) else "conv_wgrad_f32"
 
 
-def _pb(kind, flops):
-    """``kind``: a kernel label, or ("wino" | "wgrad", layer arguments...) resolved through the library only while profiling."""
+def _pb(kind, flops, nbytes=0.0):
+    """``kind``: a kernel label, or ("wino" | "wgrad", layer arguments...) resolved through the library only while profiling.  ``nbytes``:
+    algorithmic bytes of a bandwidth-bound call (its tensors read / written once)."""
     if PROFILER is not None:
         if isinstance(kind, tuple):
             kind = wino_kind(*kind[1:]) if kind[0] == "wino" else wgrad_kind(*kind[1:])
-        PROFILER.begin(kind, flops)
+        PROFILER.begin(kind, flops, nbytes)
 
 
 def _pe():
@@ -412,8 +416,10 @@ class SequentialRunner:
                     raise RuntimeError("channel mismatch: tensor has %d channels, the stem expects 1" % C)
                 Ho, Wo = s.out_hw(H, W)
                 out = _empty((N, Ho, Wo, s.cout), x)
+                _pb("thin_expand", 0.0, 4.0 * (cur.numel() + out.numel()))
                 check(lib.aesr_stemconv_fwd(ptr(cur), ptr(s.folded), ptr(s.mod.bias), ptr(out), N, H, W, s.cout, s.stem_pad,
                                             s.act, s.slope, stream()), "aesr_stemconv_fwd")
+                _pe()
                 if save:
                     saved.append((cur, out))
                 if TRACE is not None:
@@ -441,8 +447,10 @@ class SequentialRunner:
                                                        s.slope, stream()), "aesr_conv2d_wino_fwd_up2")
                     _pe()
                 elif s.cout == 1 and s.ks == 3 and s.pad == 1 and s.cin % 4 == 0:
+                    _pb("thin_collapse", 0.0, 4.0 * (cur.numel() + out.numel()))
                     check(lib.aesr_conv2d_cout1_fwd(ptr(cur), ptr(s.mod.weight), ptr(bias), ptr(out), N, H, W, s.cin, act_k,
                                                     s.slope, stream()), "aesr_conv2d_cout1_fwd")
+                    _pe()
                 elif (s.wino_fwd and FUSE_EVAL_BN and not train and not save and G == 1 and idx + 1 < len(steps) and steps[idx + 1].kind == "bn"
                       and steps[idx + 1].run_mode in (_hip.BN_NONE, _hip.BN_POOL) and steps[idx + 1].mod.running_mean is not None
                       and not (raw_last and s is steps[-1]) and (steps[idx + 1].run_mode == _hip.BN_NONE or (H >= 2 and W >= 2))
@@ -496,10 +504,12 @@ class SequentialRunner:
                 bn = s.mod
                 Ho, Wo = s.out_hw(H, W)
                 out = _empty((N, Ho, Wo, C), x)
+                _pb("bn_fwd", 0.0, 4.0 * (cur.numel() + out.numel()))
                 st = self._bn_forward_stats(bn, cur, N, H, W, C, nstart, train, out, s.run_mode)
                 if not st.pop("applied", False):
                     check(lib.aesr_bn_apply(ptr(cur), ptr(st["scale"]), ptr(st["shift"]), ptr(out), N, H, W, C, s.run_mode, G,
                                             _hip.int_array(nstart), stream()), "aesr_bn_apply")
+                _pe()
                 if save:
                     saved.append((cur, st))
                 cur, H, W = out, Ho, Wo
@@ -691,9 +701,11 @@ class SequentialRunner:
                 dw1 = self._grad_dst(s.mod.weight, grads)
                 db1 = self._grad_dst(s.mod.bias, grads) if s.mod.bias is not None else None
                 ws = _empty((lib.aesr_stemconv_workspace_floats(s.cout),), g)
+                _pb("thin_reduce", 0.0, 4.0 * (ngrad * H * W + g.numel()))
                 check(lib.aesr_stemconv_wgrad(ptr(xin), ptr(g), ptr(s.stem.weight), ptr(s.stem.bias), ptr(s.mod.weight),
                                               ptr(dws), ptr(dbs), ptr(dw1), ptr(db1), ptr(ws), ngrad, H, W, s.cs, s.cout,
                                               s.stem_pad, stream()), "aesr_stemconv_wgrad")
+                _pe()
                 g = None
                 break
             if s.kind == "conv":
@@ -734,8 +746,10 @@ class SequentialRunner:
                                                          s.pad, stream()), "aesr_conv2d_smallcin_wgrad")
                 elif s.cout == 1 and s.ks == 3 and s.pad == 1 and db is not None:
                     ws = _empty((lib.aesr_conv2d_cout1_workspace_floats(s.cin),), g)
+                    _pb("thin_reduce", 0.0, 4.0 * (N * H * W * s.cin + g.numel()))
                     check(lib.aesr_conv2d_cout1_wgrad(ptr(xin), ptr(g), ptr(dw), ptr(db), ptr(ws), N, H, W, s.cin, stream()),
                           "aesr_conv2d_cout1_wgrad")
+                    _pe()
                 else:
                     raise NotImplementedError("no wgrad kernel for conv %d->%d k%d" % (s.cin, s.cout, s.ks))
                 if s.s2d:       # [Cout, (ky,kx,c)] -> [Cout, c, ky, kx]
@@ -777,8 +791,10 @@ class SequentialRunner:
                     w = s.mod.weight
                     if s.flipped is not None and s.packed_epoch == (self.weights_epoch, w._version, w.data_ptr()):
                         # the flipped filter was made with the rest of the step's operands (prepare_weights): one launch
+                        _pb("thin_expand", 0.0, 4.0 * (g.numel() + dx.numel() * (2 if mask is not None else 1)))
                         check(lib.aesr_conv2d_cout1_dgrad_pre(ptr(g), ptr(s.flipped), ptr(mask), ptr(dx), N, H, W, s.cin, mask_act, mslope,
                                                               stream()), "aesr_conv2d_cout1_dgrad_pre")
+                        _pe()
                     else:
                         wsf = _empty((9 * s.cin,), g)
                         check(lib.aesr_conv2d_cout1_dgrad(ptr(g), ptr(w), ptr(mask), ptr(dx), ptr(wsf), N, H, W, s.cin,
@@ -818,6 +834,7 @@ class SequentialRunner:
                 coef = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
                 dgamma, dbeta = self._grad_dst(s.mod.weight, grads), self._grad_dst(s.mod.bias, grads)
                 dpre = _empty((N, H, W, C), y)
+                _pb("bn_bwd", 0.0, 4.0 * (g.numel() + 2.0 * N * H * W * C))
                 if (self.sync_bn is None and bn_fused_enabled() and bn_fused_pays(N, H, W, C)
                         and lib.aesr_bn_fused1_supported(N, H, W, C, s.run_mode, G, 1)):
                     ws = torch.empty((lib.aesr_bn_fused1_workspace_floats(C, G),), device=dev, dtype=torch.float32)
@@ -843,6 +860,7 @@ class SequentialRunner:
                     check(lib.aesr_bn_bwd_apply(ptr(g), ptr(y), ptr(st["mean"]), ptr(st["invstd"]), ptr(st["scale"]), ptr(sums),
                                                 _hip.double_array(st["counts"][:G]), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dpre),
                                                 N, H, W, C, s.run_mode, prev.act, prev.slope, G, nsa, stream()), "aesr_bn_bwd_apply")
+                _pe()
                 g = dpre
         return g
 
@@ -858,7 +876,9 @@ def prepare_weights(pairs):
         commits += c
     if jobs:
         arr = (_hip.PrepJob * len(jobs))(*jobs)
+        _pb("prep_many", 0.0, 0.0)
         check(lib.aesr_weight_prep_many(arr, len(jobs), stream()), "aesr_weight_prep_many")
+        _pe()
     for c in commits:
         c()
 
@@ -870,7 +890,9 @@ def flush_wgrad_reductions(jobs):
     for k in range(0, len(jobs), _hip.REDUCE_MAX_JOBS):
         part = jobs[k:k + _hip.REDUCE_MAX_JOBS]
         arr = (_hip.WgradReduceJob * len(part))(*[j[0] for j in part])
+        _pb("wgrad_reduce_many", 0.0, 4.0 * sum(j[1].numel() + j[2].numel() for j in part))
         check(lib.aesr_conv2d_wgrad_reduce_many(arr, len(part), stream()), "aesr_conv2d_wgrad_reduce_many")
+        _pe()
 
 
 class deferred_wgrad_reductions(object):

@@ -298,10 +298,10 @@ class BaseTrainer(object):
             from .acai_utils import generate_recon_grid
             grid = generate_recon_grid(validation_batch["image"], self.test_predictions["img_recons"])
         result = {"img_grid_recons": grid, "loss_ae": self.losses_test["loss_ae"][-1]}
-        _check_watchdogs(self, "validate")
         if image_dict is not None:
             vols, alphas = self._generate_val_volumes(image_dict, frame_id=frame_id)
             result.update(synthesized_vols=vols, alphas=alphas)
+        _check_watchdogs(self, "validate")      # behind the whole-volume previews too: nothing of this call is handed out unchecked
         return result
 
     def _generate_val_volumes(self, image_dict, frame_id):
@@ -394,4 +394,9 @@ class BaseTrainer(object):
                 save_image_grid(grid, os.path.join(self.args["dir_images"], "val_image_e{:03d}_p{:03d}.png".format(epoch, int(p_id))))
             if val.get("img_grid_recons") is not None:
                 save_image_grid(val["img_grid_recons"], os.path.join(self.args["dir_images"], "val_recons_e{:03d}.png".format(epoch)))
+        dp = getattr(self, "dp", None)
+        if dp is not None and dp.active and dp.world > 1:
+            # the writer-only work above (checkpoint, npz, PNGs on a possibly slow filesystem) must not run into the next step's in-kernel peer
+            # waits (AESR_SYNCBN=p2p gives a late peer ~7 s, not AESR_STEP_TIMEOUT): every rank meets here on the control plane first
+            dp.barrier()
         self.epoch += 1      # initialised with 0 in AEBaseTrainer.__init__

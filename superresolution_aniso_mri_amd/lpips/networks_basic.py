@@ -214,8 +214,10 @@ class PNetLin(nn.Module):
         cur = torch.empty((N, H, W, 64), device=x.device)
         if FOLD_CONV1_1:
             folded, _ = self._conv1_1_folded(pk, mul, add)
+            engine._pb("thin_expand", 0.0, 4.0 * (x.numel() + cur.numel()))
             check(lib.aesr_stemconv_fwd(ptr(x), ptr(folded), ptr(c0.bias), ptr(cur), N, H, W, 64, 0, _hip.ACT_RELU, 0.0, stream()),
                   "aesr_stemconv_fwd(vgg conv1_1)")
+            engine._pe()
         else:
             ca, cb = self._affine(mul, add)
             x4 = torch.empty((N, H, W, 4), device=x.device)
@@ -231,7 +233,9 @@ class PNetLin(nn.Module):
                 if h < 2 or w < 2:
                     raise ValueError("LPIPS-VGG needs images of at least 16x16 pixels")
                 out = torch.empty((N, h // 2, w // 2, cin), device=x.device)
+                engine._pb("maxpool2", 0.0, 4.0 * (cur.numel() + out.numel()))
                 check(lib.aesr_maxpool2_fwd(ptr(cur), ptr(out), N, h, w, cin, stream()), "aesr_maxpool2_fwd")
+                engine._pe()
                 pool_in[nconv] = cur
                 cur, h, w = out, h // 2, w // 2
                 continue
@@ -254,7 +258,9 @@ class PNetLin(nn.Module):
             if nconv in TAP_AFTER_CONV:
                 k = len(taps)
                 part = torch.empty((B, _hip.LPIPS_NCH), device=x.device)
+                engine._pb("lpips_tap", 0.0, 4.0 * cur.numel())
                 check(lib.aesr_lpips_tap_fwd(ptr(cur), ptr(pk["lin"][k]), ptr(part), B, h * w, v, stream()), "aesr_lpips_tap_fwd")
+                engine._pe()
                 taps.append((cur, h, w, v))
                 partials.append(part)
                 hws.append(h * w)
@@ -282,14 +288,20 @@ class PNetLin(nn.Module):
             if n in tap_of:
                 k = tap_of[n]
                 gtap = torch.empty((B, h, w, c), device=dev)
+                engine._pb("lpips_tap", 0.0, 4.0 * (a.numel() + gtap.numel()))
                 check(lib.aesr_lpips_tap_bwd(ptr(a), ptr(pk["lin"][k]), ptr(gd), ptr(gtap), B, h * w, c, stream()), "aesr_lpips_tap_bwd")
+                engine._pe()
                 if n == 13:
                     g = torch.empty_like(gtap)
+                    engine._pb("act_bwd", 0.0, 12.0 * gtap.numel())
                     check(lib.aesr_act_bwd(ptr(gtap), ptr(a), ptr(g), gtap.numel(), _hip.ACT_RELU, 0.0, stream()), "aesr_act_bwd")
+                    engine._pe()
                 else:
                     # g currently holds the gradient w.r.t. the pooled tensor feeding conv n+1
                     dpre = torch.empty((B, h, w, c), device=dev)
+                    engine._pb("maxpool2", 0.0, 4.0 * (g.numel() + 3 * dpre.numel()))
                     check(lib.aesr_maxpool2_bwd(ptr(g), ptr(a), ptr(gtap), ptr(dpre), B, h, w, c, 1, stream()), "aesr_maxpool2_bwd")
+                    engine._pe()
                     g = dpre
             # now g = d/d(pre-activation of conv n); push it through conv n to its input
             if _TRACE is not None:
@@ -298,8 +310,10 @@ class PNetLin(nn.Module):
                 # data gradient of the folded layer with respect to the 1-channel slice: a 64 -> 1 convolution with the flipped filter
                 _, wflip = self._conv1_1_folded(pk, mul, None)
                 dx = torch.empty((B, H, W, 1), device=dev)
+                engine._pb("thin_collapse", 0.0, 4.0 * (g.numel() + dx.numel()))
                 check(lib.aesr_conv2d_cout1_fwd(ptr(g), ptr(wflip), None, ptr(dx), B, H, W, 64, _hip.ACT_NONE, 0.0, stream()),
                       "aesr_conv2d_cout1_fwd(vgg conv1_1 dgrad)")
+                engine._pe()
                 return dx
             if n == 1:
                 ca, _ = self._affine(mul, 0.0)

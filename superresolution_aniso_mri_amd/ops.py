@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from . import _hip, engine
+from .engine import _pb, _pe
 from ._hip import check, lib, ptr, stream
 
 
@@ -48,7 +49,9 @@ class _LerpCatFn(torch.autograd.Function):
     def forward(ctx, z, a_from, a_to):
         B = z.shape[0] // 2
         zcat = torch.empty((3 * B,) + tuple(z.shape[1:]), device=z.device, dtype=torch.float32)
+        _pb("lerp_cat", 0.0, 4.0 * (z.numel() + zcat.numel()))
         check(lib.aesr_lerp_cat_fwd(ptr(z), ptr(a_from), ptr(a_to), ptr(zcat), B, z[0].numel(), stream()), "aesr_lerp_cat_fwd")
+        _pe()
         ctx.save_for_backward(a_from, a_to)
         return zcat
 
@@ -58,7 +61,9 @@ class _LerpCatFn(torch.autograd.Function):
         g = g.contiguous()
         B = g.shape[0] // 3
         dz = torch.empty((2 * B,) + tuple(g.shape[1:]), device=g.device, dtype=torch.float32)
+        _pb("lerp_cat", 0.0, 4.0 * (g.numel() + dz.numel()))
         check(lib.aesr_lerp_cat_bwd(ptr(g), ptr(a_from), ptr(a_to), ptr(dz), B, g[0].numel(), stream()), "aesr_lerp_cat_bwd")
+        _pe()
         return dz, None, None
 
 
@@ -155,7 +160,9 @@ class _MseFn(torch.autograd.Function):
     def forward(ctx, a, b):
         partial = torch.empty(_hip.MSE_NPART, device=a.device, dtype=torch.float64)
         loss = torch.empty(1, device=a.device, dtype=torch.float32)
+        _pb("mse", 0.0, 8.0 * a.numel())
         check(lib.aesr_mse_fwd(ptr(a), ptr(b), ptr(partial), ptr(loss), a.numel(), stream()), "aesr_mse_fwd")
+        _pe()
         ctx.save_for_backward(a, b)
         return loss.reshape(())
 
@@ -216,9 +223,11 @@ class _CombinedMseFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)       # the three logged outputs carry no gradient: no zero tensors for them
         res = torch.empty(4, device=o3.device, dtype=torch.float32)
         flat = o3.reshape(-1)
+        _pb("mse3", 0.0, 4.0 * (2 * (n1 + n2) + 2 * (z_mix.numel() if z_mix is not None else 0)))
         check(lib.aesr_mse3_fwd(ptr(flat), ptr(x), n1, ptr(flat[n1:]), ptr(between), n2, ptr(z_mix), ptr(z_ref),
                                 z_mix.numel() if z_mix is not None else 0, ptr(lam), ptr(_mse3_workspace(o3.device, owner)), ptr(res), stream()),
               "aesr_mse3_fwd")
+        _pe()
         ctx.save_for_backward(o3, x, between, lam)
         outs = tuple(res[i].reshape(()) for i in range(4))
         ctx.mark_non_differentiable(*outs[1:])
@@ -233,8 +242,10 @@ class _CombinedMseFn(torch.autograd.Function):
         g = g.reshape(1).contiguous().float()
         d = torch.empty_like(o3)
         flat, dflat = o3.reshape(-1), d.reshape(-1)
+        _pb("mse3", 0.0, 4.0 * 3 * (n1 + n2))
         check(lib.aesr_mse3_bwd(ptr(flat), ptr(x), n1, ptr(flat[n1:]), ptr(between), n2, ptr(lam), ptr(g), ptr(dflat), ptr(dflat[n1:]),
                                 stream()), "aesr_mse3_bwd")
+        _pe()
         return d, None, None, None, None, None, None
 
 
@@ -368,9 +379,11 @@ class HipAdam(torch.optim.Adam):
         b1, b2 = g["betas"]
         if (float(b1), float(b2)) != self._state_betas:            # betas changed between steps: the running powers start over
             self._init_state(float(self.dev_state[0].item()))
+        _pb("adam_step", 0.0, 28.0 * self.numel)
         check(lib.aesr_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), ptr(self.dev_state),
                                  self.numel, float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
                                  0, stream()), "aesr_adam_step")
+        _pe()
         self._host_step += 1
         if self.on_step is not None:
             self.on_step()

@@ -179,15 +179,31 @@ class DataParallelContext(object):
         if self.syncbn not in ("rccl", "p2p"):
             raise ValueError("AESR_SYNCBN must be 'rccl' or 'p2p', got %r" % (self.syncbn,))
         self.p2p = None
+        self._env_saved = {}            # process environment this context changed (rehearsal settings): restored by shutdown()
         if self.world > 1 and os.environ.get("AESR_SINGLE_DEVICE") == "1":
             # several ranks REHEARSED on one device: the one-launch BatchNorm kernels of all ranks must be resident TOGETHER (their grid
-            # barriers and peer waits would otherwise spin until they give up): 256 / world workgroups each, or the three-launch form
+            # barriers and peer waits would otherwise spin until they give up): 256 / world workgroups each, or the three-launch form.
+            # The library reads both switches per call, so they live in the environment -- for the life of THIS context only (round-5
+            # advice: a later single-process trainer in the same process must not inherit the shrunken grid or the disabled kernel)
             if self.world <= 4:
-                os.environ.setdefault("AESR_BN_FUSED_NB", "128" if self.world == 2 else "64")
+                if "AESR_BN_FUSED_NB" not in os.environ:
+                    self._set_env("AESR_BN_FUSED_NB", "128" if self.world == 2 else "64")
             elif os.environ.get("AESR_BN_FUSED", "1") != "0":
                 if self.syncbn == "p2p":
                     raise ValueError("AESR_SYNCBN=p2p with %d ranks on ONE device: their one-launch BatchNorm kernels cannot all be resident" % self.world)
-                os.environ["AESR_BN_FUSED"] = "0"
+                self._set_env("AESR_BN_FUSED", "0")
+
+    def _set_env(self, key, value):
+        self._env_saved.setdefault(key, os.environ.get(key))
+        os.environ[key] = value
+
+    def _restore_env(self):
+        for key, old in self._env_saved.items():
+            if old is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = old
+        self._env_saved = {}
 
     @property
     def active(self):
@@ -422,6 +438,7 @@ class DataParallelContext(object):
 
     def shutdown(self):
         """Tear the communicator and the process group down (quiet exit under torch.distributed.run)."""
+        self._restore_env()
         if self.p2p is not None:
             try:
                 if torch.cuda.is_available():
