@@ -129,6 +129,7 @@ static void accuracy() {
 // ---------------------------------------------------------------- part 2: timing skeletons --------------------------------------------------------
 #define MFMA32(acc, a, b) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 #define MFMAB(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+#define MFMAK16(acc, a, b) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 #define PK(n) asm volatile(".rept %3\n\tv_pk_add_f32 %0, %2, %2\n\tv_pk_add_f32 %1, %2, %2\n\t.endr" : "=v"(p0), "=v"(p1) : "v"(pa), "i"((n) / 2))
 #define VA(n) asm volatile(".rept %4\n\tv_add_f32 %0, %2, %3\n\tv_max_f32 %1, %2, %3\n\t.endr" : "=v"(f0), "=v"(f1) : "v"(a0), "v"(b0), "i"((n) / 2))
 // the split of n values: and, sub, and, sub (a dependent chain of four per value, values independent of each other)
@@ -151,10 +152,12 @@ constexpr int UFL = 24576;           // floats of the filter image in LDS: 96 KB
 
 // MODE 0 "f32": shipped order, f32 MFMA.  1 "w32": bf16 x 3, two waves per SIMD, 32 couts per wave.  2 "w64": one wave per SIMD, 64 couts per wave.
 // 3 "w32-nosplit": w32 without the split instructions (what the split costs).  4 "w32-mfma-only".
+// 5 "k16 MFMA only": 384 v_mfma_f32_16x16x16_bf16 per item (what does the K = 16 instruction cost?).  6 "w32-k16": the shipped kernel's structure (two
+// 16-channel chunks per item, 4 channels per lane) with 192 K = 16 MFMAs per chunk, split of 64 values per chunk.
 template <int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 256 : 512, MODE == 2 ? 1 : 2) void skel(const float* src, float* out, long long* cyc, int items, unsigned src_bytes, unsigned out_bytes) {
+__global__ __launch_bounds__((MODE == 2 || MODE == 7) ? 256 : 512, (MODE == 2 || MODE == 7) ? 1 : 2) void skel(const float* src, float* out, long long* cyc, int items, unsigned src_bytes, unsigned out_bytes) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NW = MODE == 2 ? 4 : 8;
+    constexpr int NW = (MODE == 2 || MODE == 7) ? 4 : 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (patch buffers: the f32 form keeps 8 x 10.4 KB beside its 64 KB filter; the bf16 forms share the remaining 64 KB: timing only, the buffers overlap)
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 512, MODE == 2 ? 1 : 2) void skel
     const unsigned dmask = (16u << 20) / 2 - 1, omask = (64u << 20) - 1;           // sources L2-resident, results absorbed by the Infinity Cache
     unsigned doff = (wg * 20u * 1024u + lane * 16) & dmask;
     const unsigned ooff = (wg * 8u * 1024u + lane * 16) & omask;
-    constexpr int NACC = MODE == 2 ? 64 : 32;
+    constexpr int NACC = (MODE == 2 || MODE == 7) ? 64 : 32;
     f32x4 acc[NACC];
 #pragma unroll
     for (int j = 0; j < NACC; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -227,6 +230,42 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 512, MODE == 2 ? 1 : 2) void skel
             }
             epilogue();
         }
+    } else if constexpr (MODE == 7) {
+        // f32 MFMA, ONE wave per SIMD, 64 output channels per wave (round-5 verdict, next 3: "price 64 output channels per wave"): the input transform
+        // of a chunk feeds 256 MFMAs instead of 128; four filter reads per position; two epilogues per item
+#pragma unroll 1
+        for (int it = 0; it < items; ++it) {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                VM(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) DSR(t0, paddr, (r & 7) * 1040);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) DSR(u64[0][i], uaddr, i * 1024);
+                LGKM(0);
+#pragma unroll
+                for (int r = 0; r < 10; ++r) dma(rs_in, ldsP + r * 260, (int)(doff + r * 1024));
+                doff = (doff + 10 * 1024) & dmask;
+                PK(32);
+                VA(24);
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int c = g & 1, n = c ^ 1;
+                    if (g + 1 < 16) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) DSR(u64[n][i], uaddr, (((g + 1) * 4 + i) & 63) * 1024);
+                    }
+                    PK(2);
+                    if (g + 1 < 16) LGKM(4); else LGKM(0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) MFMA32(acc[4 * g + nb], u64[c][nb][r], b0);
+                }
+            }
+            epilogue();
+            epilogue();
+        }
     } else if constexpr (MODE == 2) {
 #pragma unroll 1
         for (int it = 0; it < items; ++it) {
@@ -258,6 +297,51 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 512, MODE == 2 ? 1 : 2) void skel
             }
             epilogue();
             epilogue();
+        }
+    } else if constexpr (MODE == 5 || MODE == 6) {
+        const f32x2 vb2 = {0.25f, 0.5f};
+#pragma unroll 1
+        for (int it = 0; it < items; ++it) {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                if constexpr (MODE == 6) {
+                    VM(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) DSR(t0, paddr, (r & 7) * 1040);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) DSR(u[0][i], uaddr, i * 1024);
+                LGKM(0);
+                if constexpr (MODE == 6) {
+#pragma unroll
+                    for (int r = 0; r < 10; ++r) dma(rs_in, ldsP + r * 260, (int)(doff + r * 1024));
+                    doff = (doff + 10 * 1024) & dmask;
+                    VA(64);                                             // row half, 4 channels per lane
+                }
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int c = g & 1, n = c ^ 1;
+                    if (g + 1 < 16) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) DSR(u[n][i], uaddr, (((g + 1) * 3 + i) & 63) * 1024);      // three planes x two cout blocks as 8-byte halves
+                    }
+                    if constexpr (MODE == 6) {
+                        VA(4);
+                        SPLIT(4);
+                        PERM(6);
+                    }
+                    if (g + 1 < 16) LGKM(3); else LGKM(0);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int pr = 0; pr < 6; ++pr) {
+                            const f32x4 uu = u[c][pr % 3];
+                            const f32x2 ua = nb ? (f32x2){uu[2], uu[3]} : (f32x2){uu[0], uu[1]};
+                            MFMAK16(acc[2 * g + nb], ua, vb2);
+                        }
+                }
+            }
+            if constexpr (MODE == 6) epilogue();
         }
     } else {
 #pragma unroll 1
@@ -311,7 +395,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 512, MODE == 2 ? 1 : 2) void skel
 
 template <int MODE>
 static double run(const char* name, const float* src, float* out, long long* cyc, unsigned src_bytes, unsigned out_bytes, double mfma_cycles) {
-    constexpr int NW = MODE == 2 ? 4 : 8, NT = MODE == 2 ? 256 : 512;
+    constexpr int NW = (MODE == 2 || MODE == 7) ? 4 : 8, NT = (MODE == 2 || MODE == 7) ? 256 : 512;
     const size_t shmem = (size_t)(UFL + 4 * PFL) * sizeof(float);
     (void)hipFuncSetAttribute((const void*)skel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int items = 32;                                               // per wave; w64's items are twice as wide
@@ -342,6 +426,11 @@ int main() {
     const double w64 = run<2>("w64 bf16x3", src, out, cyc, src_bytes, out_bytes, 192 * 16.0);
     run<3>("w32 no split", src, out, cyc, src_bytes, out_bytes, 192 * 16.0);
     run<4>("w32 MFMA only", src, out, cyc, src_bytes, out_bytes, 192 * 16.0);
+    run<5>("k16 MFMA only", src, out, cyc, src_bytes, out_bytes, 384 * 8.0);
+    const double wk = run<6>("w32-k16 bf16x3", src, out, cyc, src_bytes, out_bytes, 384 * 8.0);
+    const double f64 = run<7>("f32 w64", src, out, cyc, src_bytes, out_bytes, 8192.0);
+    if (f > 0 && f64 > 0) printf("  ratio to the f32 skeleton: f32 with 64 couts per wave (one wave per SIMD) %.2f x\n", f / f64);
+    if (f > 0 && wk > 0) printf("  ratio to the f32 skeleton: w32-k16 %.2f x\n", f / wk);
     if (f > 0 && w > 0 && w64 > 0)
         printf("  ratio to the f32 skeleton: w32 %.2f x, w64 %.2f x   (the shipped kernel runs 1.26 x its skeleton: 13 800 cycles per item, profiles/r05_res_skeleton.txt)\n", f / w, f / w64);
     return 0;
