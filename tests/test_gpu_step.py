@@ -130,7 +130,10 @@ def test_three_train_steps(tag, record_property):
             record_property("decisions_differing_from_fp64", len(diffs))
             assert len(diffs) <= 8 and all(d["rel"] <= 2e-5 for d in diffs), "decisions that are not ties:\n" + ru.describe(diffs)
             g_ref = ru.oracle64_step(lambda: _oracle_step(tag, rec), batch, forced=dec)[1] if diffs else g_own
-            tight = 6e-5 if percept else 3e-5           # measured: 1.9e-5 (LPIPS as the reconstruction loss), 1.2e-5 (three pooling stages), <= 4.4e-6 else
+            # measured on the product path: 1.9e-5 (LPIPS as the reconstruction loss), 1.2e-5 (three pooling stages), <= 4.4e-6 else.  The control
+            # run through the direct fp32 kernels (and whatever alternate-path switch it inherits, scripts/env_matrix.sh) keeps round 1's
+            # scale: its small-channel reductions sum in fp32 over all pixels (1.2e-4 on the 8-element enc.0.bias with the stem unfolded)
+            tight = 1.5e-4 if DIRECT_CONTROL else (6e-5 if percept else 3e-5)
             worst = max((rel_l2(g_hip[k], g_ref[k]), k) for k in g_ref)
             record_property("worst_gradient_rel_l2_vs_fp64_same_decisions", worst[0])
             assert worst[0] < tight, worst
@@ -165,7 +168,8 @@ def test_three_train_steps(tag, record_property):
         if ost_branch is not None:
             r = ost_branch.train(batch["image"], batch["slice_between"], batch.get("alpha_from"), batch.get("alpha_to"), route=routing.Routing(dec))
             want = [r[k] for k in keys]
-        np.testing.assert_allclose(got, want, rtol=2e-5 if lr < 1e-4 else later)
+        # (atol: the logged latent term is ~5e-5 of a total of ~0.15; 2.7e-7 of absolute difference on it read 5.2e-3 relative under AESR_LPIPS_FOLD=0)
+        np.testing.assert_allclose(got, want, rtol=2e-5 if lr < 1e-4 else later, atol=0.0 if lr < 1e-4 else 1e-6)
     assert trainer.iters == int(rec["iters"]) == 4
     sd = trainer.model.state_dict()
     final = {k[3:]: v for k, v in rec.items() if k.startswith("p3/")}
