@@ -1,7 +1,8 @@
 #!/bin/bash
-# full-size soak at the end of round 4: every BASELINE configuration's replayed step for 1 000 - 2 000 steps, twice -- identical final losses, no watchdog
+# full-size soak (soak_full.sh [tag rNN]): every BASELINE configuration's replayed step for 1 000 - 2 000 steps, twice -- identical final losses, no watchdog
 OUT=$GRAFT_REPO_ROOT/gpurun_out
-F=$OUT/r04_soak_full.txt
+TAG=${1:-r04}
+F=$OUT/${TAG}_soak_full.txt
 : > $F
 line() { python3 -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$1: %d steps, %.3f ms/step, final loss %.6f, ring watchdog %d, BatchNorm barrier watchdog %d' % (d['steps'], d['ms_per_step'], d['final_loss'], d['ring_watchdog_timeouts'], d['bn_barrier_timeouts']))" >> $F; }
