@@ -339,6 +339,14 @@ def roofline_of(engine, device, nst, config, B, H, gpus, scales3=False):
                 roofline["traffic"] = round(sum(v["MB_per_step"] for v in ig) / nl * 1e6)
                 roofline["traffic_unit"] = ("bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/%s, kernel sources %s)"
                                             % (os.path.basename(tpath), tj["csrc_sha"]))
+            # the tail's kinds: HBM-side MB per step of the kernels that serve them, beside their algorithmic MB (well above = re-reads: the
+            # three-launch BatchNorm reads its layer twice)
+            for row in roofline["tail"]["kinds"]:
+                pre = TAIL_ROCPROF.get(row["kind"], ())
+                hit = [v for name, v in tj["kernels"].items() if any(name.startswith(p_) or (" " + p_) in name for p_ in pre)]
+                if hit:
+                    row["traffic_MB_per_step"] = round(sum(v["MB_per_step"] for v in hit), 1)
+            roofline["tail"]["traffic_MB_per_step"] = round(sum(r_.get("traffic_MB_per_step", 0.0) for r_ in roofline["tail"]["kinds"]), 1)
             break
         else:
             roofline["traffic_note"] = "%s was measured on other kernel sources (%s, now %s): not quoted" % (

@@ -152,6 +152,9 @@ constexpr int UFL = 24576;           // floats of the filter image in LDS: 96 KB
 
 // MODE 0 "f32": shipped order, f32 MFMA.  1 "w32": bf16 x 3, two waves per SIMD, 32 couts per wave.  2 "w64": one wave per SIMD, 64 couts per wave.
 // 3 "w32-nosplit": w32 without the split instructions (what the split costs).  4 "w32-mfma-only".
+// 8 "w32-pair": two waves per SIMD and the SHIPPED kernel's 16-channel chunks (4 channels per lane): every K = 32 MFMA carries TWO of the six products of a
+// 16-channel chunk -- A = [U_h | U_m] . B = [V_h | V_m] = hh + mm, A . [V_m | V_h] = hm + mh, [U_l | U_h] . [V_h | V_l] = lh + hl: 3 MFMAs per (chunk, position, cout block),
+// 2 filter reads (ds_read2_b64), split of 4 values + 12 packing v_perm per (chunk, position).
 // 5 "k16 MFMA only": 384 v_mfma_f32_16x16x16_bf16 per item (what does the K = 16 instruction cost?).  6 "w32-k16": the shipped kernel's structure (two
 // 16-channel chunks per item, 4 channels per lane) with 192 K = 16 MFMAs per chunk, split of 64 values per chunk.
 template <int MODE>
@@ -298,6 +301,42 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 7) ? 256 : 512, (MODE == 2 ||
             epilogue();
             epilogue();
         }
+    } else if constexpr (MODE == 8) {
+#pragma unroll 1
+        for (int it = 0; it < items; ++it) {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                VM(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) DSR(t0, paddr, (r & 7) * 1040);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) DSR(u[0][i], uaddr, i * 1024);
+                LGKM(0);
+#pragma unroll
+                for (int r = 0; r < 10; ++r) dma(rs_in, ldsP + r * 260, (int)(doff + r * 1024));
+                doff = (doff + 10 * 1024) & dmask;
+                VA(64);                                                 // row half, 4 channels per lane
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int c = g & 1, n = c ^ 1;
+                    if (g + 1 < 16) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) DSR(u[n][i], uaddr, (((g + 1) * 4 + i) & 63) * 1024);      // (h, m) and (l, h) of two cout blocks
+                    }
+                    VA(4);
+                    SPLIT(4);
+                    PERM(12);
+                    if (g + 1 < 16) LGKM(4); else LGKM(0);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        MFMAB(acc[2 * g + nb], u[c][2 * nb], vb);
+                        MFMAB(acc[2 * g + nb], u[c][2 * nb], vb);
+                        MFMAB(acc[2 * g + nb], u[c][2 * nb + 1], vb);
+                    }
+                }
+            }
+            epilogue();
+        }
     } else if constexpr (MODE == 5 || MODE == 6) {
         const f32x2 vb2 = {0.25f, 0.5f};
 #pragma unroll 1
@@ -428,6 +467,8 @@ int main() {
     run<4>("w32 MFMA only", src, out, cyc, src_bytes, out_bytes, 192 * 16.0);
     run<5>("k16 MFMA only", src, out, cyc, src_bytes, out_bytes, 384 * 8.0);
     const double wk = run<6>("w32-k16 bf16x3", src, out, cyc, src_bytes, out_bytes, 384 * 8.0);
+    const double wp = run<8>("w32-pair bf16x3", src, out, cyc, src_bytes, out_bytes, 192 * 16.0);
+    if (f > 0 && wp > 0) printf("  ratio to the f32 skeleton: w32-pair (two waves per SIMD, 16-channel chunks, two products per MFMA) %.2f x\n", f / wp);
     const double f64 = run<7>("f32 w64", src, out, cyc, src_bytes, out_bytes, 8192.0);
     if (f > 0 && f64 > 0) printf("  ratio to the f32 skeleton: f32 with 64 couts per wave (one wave per SIMD) %.2f x\n", f / f64);
     if (f > 0 && wk > 0) printf("  ratio to the f32 skeleton: w32-k16 %.2f x\n", f / wk);
