@@ -8,7 +8,6 @@ import ctypes
 import os
 import sys
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 

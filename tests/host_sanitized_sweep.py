@@ -11,7 +11,7 @@ the process (non-zero exit); the parent asserts on the exit code and on the summ
 import ctypes
 import random
 import sys
-from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
 
 # fake device pointers must never reach a real device: this sweep only runs where the HIP runtime sees NO GPU (the parent hides them)
 try:

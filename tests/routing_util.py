@@ -8,7 +8,7 @@ the reconstruction is the ``pred`` argument), ``lp_syn/in0/...`` (LPIPS synthesi
 argument) -- n = 1-based VGG conv count."""
 import torch
 
-from oracle import routing, step_oracle
+from oracle import routing
 
 
 def nchw(t):
