@@ -238,8 +238,15 @@ def test_vgg_weights_file_is_loaded(tmp_path):
     a = torch.rand(3, 1, 48, 40, generator=g)
     b = torch.rand(3, 1, 48, 40, generator=g)
     bd = b.cuda().requires_grad_(True)
-    d = crit(a.cuda(), bd, normalize=True)
-    d.mean().backward()
+    from superresolution_aniso_mri_amd.lpips import networks_basic as nb
+    nb._TRACE = []                      # the activations of the stack: its ReLU / max-pool decisions (oracle/routing.py)
+    try:
+        d = crit(a.cuda(), bd, normalize=True)
+        d.mean().backward()
+        torch.cuda.synchronize()
+        acts = [t for t in nb._TRACE if t[0] == "acts"][0][1]
+    finally:
+        nb._TRACE = None
     lin = np.load(os.path.join(root, "superresolution_aniso_mri_amd", "lpips", "weights", "v0.1", "vgg_lin.npz"))
     lin_w = [torch.from_numpy(lin["lin%d" % k]).reshape(1, -1, 1, 1) for k in range(5)]
     br = b.clone().requires_grad_(True)
@@ -258,6 +265,23 @@ def test_vgg_weights_file_is_loaded(tmp_path):
     gmax = float(b64.grad.abs().max())
     assert float(err.flatten().quantile(0.9)) < 2e-5 * gmax
     assert float(err.norm() / b64.grad.norm()) < 1e-2
+    # ... and since round 6 that account is CHECKED, not assumed: the decisions the HIP stack took on the differentiated branch, the ones fp64 takes
+    # otherwise (each must be a tie), and the gradient against fp64 evaluated under the HIP stack's decisions
+    from oracle import routing
+    dec = {}
+    for n, act in enumerate(acts, start=1):
+        a0 = act[:3].detach().permute(0, 3, 1, 2).cpu()
+        dec["in0/relu%d" % n] = a0 > 0
+        if n in lpips_oracle.TAP_AFTER_CONV[:-1]:
+            dec["in0/pool%d" % n] = routing.Routing.windows(a0).argmax(-1)
+    sd64, lin64 = {k: v.double() for k, v in sd.items()}, [w.double() for w in lin_w]
+    r_own = routing.Routing()
+    lpips_oracle.perceptual_loss(a.double(), b.double(), sd64, lin64, normalize=True, route=r_own)
+    diffs = routing.differing_decisions(r_own, dec)
+    assert len(diffs) <= 6 and all(x["rel"] <= 2e-5 for x in diffs), diffs
+    bf = b.double().clone().requires_grad_(True)
+    lpips_oracle.perceptual_loss(a.double(), bf, sd64, lin64, normalize=True, route=routing.Routing(dec)).mean().backward()
+    assert float((bd.grad.double().cpu() - bf.grad).norm() / bf.grad.norm()) < 3e-5, (len(diffs), float((bd.grad.double().cpu() - bf.grad).norm() / bf.grad.norm()))
     assert float((br.grad.double() - b64.grad).norm() / b64.grad.norm()) < 1e-4           # the fp32 CPU oracle itself: 1.8e-6
     d_syn = synth(a.cuda(), b.cuda(), normalize=True)
     assert float((d_syn.cpu() - d.detach().cpu()).abs().max()) > 1e-3 * float(d.detach().abs().max())
