@@ -4,7 +4,10 @@
 //     conv_wino_res_f32: 125 against 78 us on 32 -> 32 @ 160 x 160 x 36 -- the allocator spilled accumulator tuples around every MFMA group, and scratch fills
 //     wait on vmcnt(0), i.e. on the patch DMA in flight;
 //   * THIS form (accumulators pinned to the accumulation registers by "a" constraints, fragments by ds_read2st64_b64 asm, hand-counted lgkmcnt) removes those
-//     spills but measured 139-159 us and is NOT correct (1.4e-3 .. 3e-3: a hazard the compiler no longer sees into) -- do not build it as it is.
+//     spills but measured 139-159 us and is NOT correct (1.4e-3 .. 3e-3) -- do not build it as it is.  Most likely cause of both: ~50 registers still spill
+//     (constants in the prologue, the epilogue), and scratch stores / fills are vector-memory operations -- they count in vmcnt, so the hand-counted
+//     "s_waitcnt vmcnt(8)" at the top of an item (exactly 8 stores behind the patch DMAs) no longer guarantees that the patch has landed, while the
+//     compiler's own vmcnt(0) in front of every fill waits for the patch DMA in flight.  A version of this kernel is only worth timing at ZERO spills.
 // Why neither pays: the item loop came out at ~3 100 instructions per item (6 v_mov per position for the duplicated operand halves, 128 v_accvgpr_read, waits,
 // address work) against ~1 850 in the timing skeleton (scripts/micro/bf16x3.hip, mode w32-pair: 1.34 x) and ~850 in conv_wino_res_f32, whose 256 f32 MFMAs
 // fill 8 192 of its 13 800 cycles by themselves: on the bf16 pipe the kernel is bound by instruction ISSUE, and the compiler's schedule is 1.7 x the skeleton's
