@@ -1,3 +1,5 @@
+// (SUPERSEDED by scripts/micro/wino_b3v2.hip, which is correct and 1.05 - 1.15 x: the spills and the errors below came from the "if (lane < 40)" around the
+// patch DMA -- lane-dependent resources, waterfall loops -- and from register copies of hand-waited reads placed before their wait: profiles/r06_bf16x3_second_try.txt)
 // ATTEMPT, NOT BUILT (round 6): the two-waves-per-SIMD bf16 x 3 form of conv_wino_res.hip INSIDE the library (dispatch from aesr_launch_conv_wino_res, the split
 // filter image written by wino_pack_elements behind the f32 one, kernel id 4) -- tried and reverted the same day; kept for whoever picks it up.  Status:
 //   * the plain-C++ form of this file (builtin MFMAs, C++ fragment loads) was CORRECT through the C ABI (tests/test_gpu_kernels.py: 301 passed) and SLOWER than
