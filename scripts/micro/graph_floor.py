@@ -71,3 +71,25 @@ N = M
 tb, _ = timed(graphed(bigs))
 tp, _ = timed(graphed(pairs))
 print("graph of %d x (118 MB in-place add): %.2f us each; with a tiny kernel behind each: %.2f us per pair -> the tiny kernel costs %.2f us there" % (M, tb, tp, tp - tb))
+
+# the same with TEN DIFFERENT tiny kernels in rotation behind the big one (cold code / arguments each time?)
+ops = [lambda: x.add_(1.0), lambda: x.mul_(1.0), lambda: x.sin_(), lambda: x.cos_(), lambda: x.abs_(), lambda: x.neg_(), lambda: x.exp_(), lambda: x.tanh_(),
+       lambda: x.sigmoid_(), lambda: x.sqrt_()]
+
+
+def pairs_distinct():
+    for i in range(M):
+        big.add_(1.0)
+        ops[i % 10]()
+
+
+def tiny_distinct():
+    for i in range(N):
+        ops[i % 10]()
+
+
+td, _ = timed(graphed(pairs_distinct))
+print("with ten DIFFERENT tiny kernels in rotation behind the big one: %.2f us per pair -> %.2f us per tiny kernel" % (td, td - tb))
+N = 200
+tt, _ = timed(graphed(tiny_distinct))
+print("chain of 200 tiny kernels, ten different ones in rotation: %.2f us per node" % tt)
